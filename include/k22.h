@@ -1,0 +1,136 @@
+/* k22.h — C ABI of libk22hip.so, the MI355X (gfx950) native Kandinsky-2 sampling engine.
+ *
+ * The reference (ai-forever/Kandinsky-2, pure PyTorch) has no FFI; its seams on the sampling hot path
+ * are Python objects.  Each entry point below names the reference call it replaces
+ * (paths relative to the reference tree).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - extern "C"; every function returns 0 (K22_OK) or a negative K22_E* code; k22_last_error()
+ *     returns a thread-local message.  No C++ exception crosses the boundary.
+ *   - The CALLER owns every buffer (inputs, outputs, weight arena, workspace).  All pointers are
+ *     device pointers valid on the current HIP device unless a parameter says "host".
+ *   - All work is ENQUEUED on the hipStream_t passed as `stream` (void* here so the header needs no
+ *     HIP include); nothing synchronises, nothing allocates device memory.
+ *   - Activations inside the engine are NHWC (channels last); the public tensors keep the reference's
+ *     NCHW fp32 layout so the Python modules stay drop-in.
+ */
+#ifndef K22_H
+#define K22_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define K22_OK 0
+#define K22_EINVAL (-1)
+#define K22_EHIP (-2)
+#define K22_ENOMEM (-3)
+
+#define K22_BF16 0 /* product path: bf16 storage, v_mfma_f32_32x32x16_bf16, fp32 accumulate */
+#define K22_F32 1  /* parity path : fp32 storage, v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain) */
+
+int k22_version(void);
+const char* k22_last_error(void);
+
+/* ---- UNet engine --------------------------------------------------------------------------
+ * Replaces Text2ImUNet.forward / InpaintText2ImUNet.forward (kandinsky2/model/text2im_model2_1.py:
+ * 85-103, 146-155) and everything below it: UNetModel blocks (kandinsky2/model/unet.py:343-611),
+ * ResBlock (:110-220), AttentionBlock/QKVAttention (:223-340), GroupNorm32 (kandinsky2/model/nn.py:
+ * 26-37), timestep_embedding (nn.py:101-121).  Hyper-parameters mirror create_model()
+ * (kandinsky2/model/model_creation.py:9-83) / CONFIG_2_1["model_config"] (kandinsky2/configs.py:125-149).
+ */
+typedef struct K22UNetConfig {
+  int dtype;               /* K22_BF16 | K22_F32 */
+  int in_channels;         /* 4, or 9 for the inpainting UNet (x, image*mask, mask) */
+  int model_channels;      /* 384 */
+  int out_channels;        /* 8 = eps + learned variance */
+  int num_res_blocks;      /* 3 */
+  int n_levels;            /* len(channel_mult) */
+  int channel_mult[8];     /* (1,2,3,4) */
+  int n_attention_ds;      /* attention at these downsample rates */
+  int attention_ds[8];     /* (2,4,8) */
+  int num_head_channels;   /* 64 (only 64 is implemented) */
+  int ctx_dim;             /* model_dim / encoder_channels, 768 */
+  int ctx_len;             /* num_image_embs + text_ctx = 10 + 77 */
+  int n_image_embs;        /* 10 */
+  int text_dim1;           /* text_encoder_in_dim1, 1024 */
+  int text_dim2;           /* text_encoder_in_dim2, 768 (pooled) */
+  int image_dim;           /* image_encoder_in_dim, 768 */
+} K22UNetConfig;
+
+/* One packed parameter tensor inside the caller's weight arena (see kandinsky-2_amd/pack.py for the
+ * layouts; names follow the reference state_dict keys so reference checkpoints load). */
+typedef struct K22Weight {
+  const char* name;
+  const void* ptr;
+} K22Weight;
+
+typedef struct K22UNet K22UNet; /* opaque */
+
+/* Builds the op graph description.  `weights` pointers must stay valid for the engine's lifetime. */
+int k22_unet_create(const K22UNetConfig* cfg, const K22Weight* weights, int n_weights, K22UNet** out);
+void k22_unet_destroy(K22UNet* u);
+
+/* Plans a forward for batch B (= 2*bs with classifier-free guidance) and latent H x W; returns the
+ * workspace size the caller must provide to k22_unet_bind().  Re-planning invalidates the binding. */
+int k22_unet_plan(K22UNet* u, int B, int H, int W, size_t* workspace_bytes);
+int k22_unet_bind(K22UNet* u, void* workspace, size_t workspace_bytes);
+
+/* Conditioning head, once per generation: Text2ImUNet.get_text_emb (text2im_model2_1.py:57-80) plus
+ * the step-invariant AttentionBlock.encoder_kv projections (unet.py:263-264).
+ * full_emb [B,77,text_dim1], pooled_emb [B,text_dim2], image_emb [B,image_dim], all fp32 contiguous. */
+int k22_unet_set_condition(K22UNet* u, const float* full_emb, const float* pooled_emb, const float* image_emb,
+                           void* stream);
+
+/* One UNet evaluation.  x [B,4,H,W] fp32 NCHW, timesteps [B] fp32 (already mapped/rescaled exactly as
+ * _WrappedModel.__call__ does, kandinsky2/model/respace.py:128-133), inpaint_image [B,4,H,W] and
+ * inpaint_mask [B,1,H,W] (NULL unless in_channels == 9; the product image*mask is formed inside like
+ * text2im_model2_1.py:151), out [B,out_channels,H,W] fp32 NCHW.
+ * use_graph != 0 replays a captured hipGraph of the whole forward (captured on first use). */
+int k22_unet_forward(K22UNet* u, const float* x, const float* timesteps, const float* inpaint_image,
+                     const float* inpaint_mask, float* out, int use_graph, void* stream);
+
+/* Number of kernel launches in one planned forward (diagnostics). */
+int k22_unet_num_ops(const K22UNet* u);
+
+/* ---- sampler step ---------------------------------------------------------------------------
+ * Replaces one iteration of GaussianDiffusion.p_sample_loop_progressive
+ * (kandinsky2/model/gaussian_diffusion.py:463-475): the CFG combine of Kandinsky2_1.generate_img.model_fn
+ * (kandinsky2/kandinsky2_1_model.py:222-233) applied to the raw UNet output, p_mean_variance
+ * (gaussian_diffusion.py:223-322) including the host-side np.percentile dynamic threshold
+ * (:284-294, done on device here) and p_sample (:352-382).
+ *   x, noise, x_out, x0_out(nullable): [N,4,H,W] fp32;  model_out: [N,8,H,W] fp32 (raw UNet output);
+ *   init_img [N,4,H,W] / mask [N,1,H,W]: inpainting blend of denoised_fun (kandinsky2_1_model.py:238-240)
+ *   or NULL;  table: device [steps][8] fp32 (see k22_sampler_table_columns); step_index selects the row;
+ *   pct_index / pct_gamma: order-statistic index and weight of the 99.5 percentile (host computes them
+ *   with numpy's own formula), pct_index < 0 disables thresholding (clip_denoised=False);
+ *   scratch: device, >= k22_sampler_scratch_bytes(N,HW).
+ */
+size_t k22_sampler_scratch_bytes(int N, int HW);
+int k22_sampler_step(const float* x, const float* model_out, const float* noise, const float* init_img,
+                     const float* mask, const float* table, int step_index, float guidance, int use_cfg,
+                     float clamp_lo, float clamp_hi, int pct_index, double pct_gamma, void* scratch,
+                     float* x_out, float* x0_out, int N, int HW, void* stream);
+
+/* ---- individual kernels (unit-parity surface; the engine calls the same launchers) -------------
+ * dtype-typed buffers are bf16 or fp32 according to `dtype`.  Layouts: see the headers in kandinsky-2_amd/csrc. */
+int k22_gemm(const void* A0, const void* A1, const void* Wp, const float* bias, const void* residual, void* out,
+             void* partial, int M, int N, int Npad, int K0, int K1, long lda0, long lda1, int ldo, int ldr,
+             int out_f32, int act, int splitk, int bm, int bn, int dtype, void* stream);
+int k22_conv3x3(const void* x_padded, const void* Wp, const float* bias, const void* residual, void* out,
+                void* partial, int B, int H, int W, int Cin, int Cout, int Npad, int out_mode, int act, int splitk,
+                int bm, int bn, int dtype, void* stream);
+int k22_groupnorm(const void* x0, const void* x1, int C0, int C1, int B, int H, int W, const float* gamma,
+                  const float* beta, const float* film, long film_ld, float eps, int act, int mode, int pad,
+                  void* scratch, void* out, int dtype, void* stream);
+size_t k22_groupnorm_scratch_bytes(int B, int C);
+int k22_attention(const void* qkv, const void* ctxkv, void* kall, void* vtall, void* out, int B, int H, int T, int S,
+                  int dtype, void* stream);
+int k22_linear_smallm(const float* x, const void* W, const float* bias, const float* add, float* out, int M, int N,
+                      int K, int act_in, int act_out, int wdtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* K22_H */

@@ -1,0 +1,193 @@
+// k22 — fused attention with prepended context keys (flash-style, online softmax in fp32).
+//
+// Restates QKVAttention.forward's einsum path (kandinsky2/model/unet.py:286-340): per (batch, head)
+// softmax((q*s)(k*s)^T) v with s = ch^-0.25, keys = [encoder K | self K], fp32 softmax.  The
+// [B*H, T, S] score tensor of the reference is never materialised.
+//
+// Work split: workgroup = 4 waves = 128 queries of one (b, head); wave = 32 queries.
+//   S^T[key][q] = K[key][:] . Q[q][:]   (A = K tile rows from LDS, B = Q fragments in registers)
+//     -> C layout puts ONE query per lane column (lane&31) and 32 keys of the 64-key tile in the
+//        lane's 32 accumulator registers: row max / row sum are lane-local plus one xor-32 shuffle.
+//   O^T[d][q] += V^T[d][key] . P^T[key][q]   (A = V^T tile rows from LDS, B = P straight from the
+//        S^T accumulator registers: no LDS round trip, the rescale factor is lane-local).
+// K_all / V^T_all are produced by kv_pack_kernel (elementwise.hip), zero padded to 64 keys.
+#include "kernels.h"
+#include "elementwise.h"
+
+// V^T fragment whose K (= key) order matches the S^T accumulator registers:
+// element j<4 -> key 16a + 4h + j ; j>=4 -> key 16a + 8 + 4h + (j-4).
+__device__ __forceinline__ void ld_frag_split(Frag<bf16_t>& f, const char* tile, int r, int a, int h) {
+  const uint2 lo = *reinterpret_cast<const uint2*>(tile + lds_chunk_off(r, 2 * a) + 8 * h);
+  const uint2 hi = *reinterpret_cast<const uint2*>(tile + lds_chunk_off(r, 2 * a + 1) + 8 * h);
+  f.v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+__device__ __forceinline__ void ld_frag_split(Frag<float>& f, const char* tile, int r, int a, int h) {
+  const char* sub = tile + (a >> 1) * 8192;
+  const int al = a & 1;
+  const float4 lo = *reinterpret_cast<const float4*>(sub + lds_chunk_off(r, 4 * al + h));
+  const float4 hi = *reinterpret_cast<const float4*>(sub + lds_chunk_off(r, 4 * al + 2 + h));
+  f.v[0] = lo.x; f.v[1] = lo.y; f.v[2] = lo.z; f.v[3] = lo.w;
+  f.v[4] = hi.x; f.v[5] = hi.y; f.v[6] = hi.z; f.v[7] = hi.w;
+}
+__device__ __forceinline__ void make_pfrag(Frag<bf16_t>& f, const float* p) {
+  f.v.x = (uint32_t)f32_to_bf16(p[0]) | ((uint32_t)f32_to_bf16(p[1]) << 16);
+  f.v.y = (uint32_t)f32_to_bf16(p[2]) | ((uint32_t)f32_to_bf16(p[3]) << 16);
+  f.v.z = (uint32_t)f32_to_bf16(p[4]) | ((uint32_t)f32_to_bf16(p[5]) << 16);
+  f.v.w = (uint32_t)f32_to_bf16(p[6]) | ((uint32_t)f32_to_bf16(p[7]) << 16);
+}
+__device__ __forceinline__ void make_pfrag(Frag<float>& f, const float* p) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = p[j];
+}
+__device__ __forceinline__ void ld_qfrag(Frag<bf16_t>& f, const bf16_t* p) { f.v = *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void ld_qfrag(Frag<float>& f, const float* p) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
+  f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+}
+template <typename T> __device__ __forceinline__ float exp_t(float x);
+template <> __device__ __forceinline__ float exp_t<bf16_t>(float x) { return __expf(x); }
+template <> __device__ __forceinline__ float exp_t<float>(float x) { return expf(x); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void attention_kernel(AttentionParams p) {
+  using TR = TT<T>;
+  constexpr int EPC = TR::EPC, BK = TR::BK, KSTEPS = TR::KSTEPS;
+  constexpr int NSUB = 64 / BK;   // 128-byte sub-tiles per 64-element row (1 bf16, 2 fp32)
+  constexpr int CPR = 64 / EPC;   // 16-byte chunks per 64-element row
+  constexpr int LCH = CPR / 4;    // chunks per thread per 64x64 tile
+  __shared__ __attribute__((aligned(16))) char smem[2 * NSUB * 8192];
+  char* Ks = smem;
+  char* Vs = smem + NSUB * 8192;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int hd = blockIdx.y, b = blockIdx.z;
+  const int t = blockIdx.x * 128 + wave * 32 + l31;
+  const int tq = t < p.T ? t : p.T - 1;
+
+  const T* qrow = reinterpret_cast<const T*>(p.q) + (int64_t)(b * p.T + tq) * p.ldq + hd * 64;
+  Frag<T> qf[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) ld_qfrag(qf[a], qrow + 16 * a + 8 * h);
+
+  const T* Kg = reinterpret_cast<const T*>(p.kall) + (int64_t)(b * p.H + hd) * p.Tkp * 64;
+  const T* Vg = reinterpret_cast<const T*>(p.vtall) + (int64_t)(b * p.H + hd) * 64 * p.Tkp;
+  const int nkt = (p.Tk + 63) / 64;
+
+  uint4 kreg[LCH], vreg[LCH];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < LCH; ++i) {
+      const int q = tid + i * 256, row = q / CPR, cc = q - row * CPR;
+      kreg[i] = *reinterpret_cast<const uint4*>(Kg + (int64_t)(kt * 64 + row) * 64 + cc * EPC);
+      vreg[i] = *reinterpret_cast<const uint4*>(Vg + (int64_t)row * p.Tkp + kt * 64 + cc * EPC);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < LCH; ++i) {
+      const int q = tid + i * 256, row = q / CPR, cc = q - row * CPR;
+      const int off = (cc >> 3) * 8192 + lds_chunk_off(row, cc & 7);
+      *reinterpret_cast<uint4*>(Ks + off) = kreg[i];
+      *reinterpret_cast<uint4*>(Vs + off) = vreg[i];
+    }
+  };
+
+  f32x16_t o[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+  float m_run = -1e30f, l_run = 0.f;
+
+  gload(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();  // every wave finished reading the previous tile
+    lstore();
+    __syncthreads();
+    if (kt + 1 < nkt) gload(kt + 1);
+
+    f32x16_t s[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        Frag<T> kf;
+        ld_frag(kf, Ks + (a / KSTEPS) * 8192, kb * 32 + l31, a % KSTEPS, h);
+        mma_atom(s[kb], kf, qf[a]);
+      }
+
+    float pv[2][16];
+    float mloc = -1e30f;
+    const bool tail = (kt * 64 + 64 > p.Tk);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = s[kb][r] * p.scale;
+        if (tail && (kt * 64 + kb * 32 + c_row(r, lane) >= p.Tk)) v = -INFINITY;
+        pv[kb][r] = v;
+        mloc = fmaxf(mloc, v);
+      }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = exp_t<T>(m_run - m_new);
+    float lsum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = exp_t<T>(pv[kb][r] - m_new);
+        pv[kb][r] = e;
+        lsum += e;
+      }
+    l_run = l_run * alpha + lsum;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      Frag<T> pf;
+      make_pfrag(pf, &pv[a >> 1][8 * (a & 1)]);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        Frag<T> vf;
+        ld_frag_split(vf, Vs, db * 32 + l31, a, h);
+        mma_atom(o[db], vf, pf);
+      }
+    }
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.f / l_tot;
+  if (t < p.T) {
+    T* orow = reinterpret_cast<T*>(p.out) + (int64_t)(b * p.T + t) * p.ldo + hd * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = db * 32 + 8 * g + 4 * h;
+        if constexpr (sizeof(T) == 2) {
+          uint2 w;
+          w.x = (uint32_t)f32_to_bf16(o[db][4 * g] * inv) | ((uint32_t)f32_to_bf16(o[db][4 * g + 1] * inv) << 16);
+          w.y = (uint32_t)f32_to_bf16(o[db][4 * g + 2] * inv) | ((uint32_t)f32_to_bf16(o[db][4 * g + 3] * inv) << 16);
+          *reinterpret_cast<uint2*>(orow + d) = w;
+        } else {
+          *reinterpret_cast<float4*>(orow + d) =
+              make_float4(o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+        }
+      }
+  }
+}
+
+int launch_attention(const AttentionParams& p, int dtype, hipStream_t s) {
+  if (p.Tkp % 64 || p.Tkp < p.Tk) return k22_set_error(K22_EINVAL, "attention: Tkp must be roundup(Tk,64)");
+  dim3 grid((p.T + 127) / 128, p.H, p.B);
+  if (dtype == K22_BF16) hipLaunchKernelGGL(attention_kernel<bf16_t>, grid, dim3(256), 0, s, p);
+  else if (dtype == K22_F32) hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(256), 0, s, p);
+  else return k22_set_error(K22_EINVAL, "attention: bad dtype");
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}

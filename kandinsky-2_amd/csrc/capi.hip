@@ -1,0 +1,115 @@
+// k22 — C ABI glue: error reporting and the kernel-level entry points declared in include/k22.h.
+#include "kernels.h"
+#include "elementwise.h"
+#include "../../include/k22.h"
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+int k22_set_error(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg ? msg : "");
+  return code;
+}
+int k22_set_error_hip(hipError_t e, const char* file, int line) {
+  snprintf(g_err, sizeof(g_err), "HIP error %d (%s) at %s:%d", (int)e, hipGetErrorString(e), file, line);
+  return K22_EHIP;
+}
+
+extern "C" {
+
+int k22_version(void) { return 100; }
+const char* k22_last_error(void) { return g_err; }
+
+int k22_gemm(const void* A0, const void* A1, const void* Wp, const float* bias, const void* residual, void* out,
+             void* partial, int M, int N, int Npad, int K0, int K1, long lda0, long lda1, int ldo, int ldr,
+             int out_f32, int act, int splitk, int bm, int bn, int dtype, void* stream) {
+  IgemmParams p = {};
+  p.A0 = A0; p.A1 = A1; p.Wp = Wp; p.bias = bias; p.residual = residual; p.out = out;
+  p.partial = reinterpret_cast<float*>(partial);
+  p.M = M; p.N = N; p.Npad = Npad; p.Kc = K0 + K1; p.K0 = K0; p.taps = 1; p.lda0 = lda0; p.lda1 = lda1;
+  p.ldo = ldo; p.ldr = ldr; p.out_mode = out_f32 ? IG_OUT_ROWMAJOR_F32 : IG_OUT_ROWMAJOR; p.act = act;
+  p.splitk = splitk; p.force_bm = bm; p.force_bn = bn;
+  if (p.splitk == 0) p.splitk = partial ? igemm_choose_splitk(p, dtype) : 1;
+  return launch_igemm(p, dtype, reinterpret_cast<hipStream_t>(stream));
+}
+
+int k22_conv3x3(const void* x_padded, const void* Wp, const float* bias, const void* residual, void* out,
+                void* partial, int B, int H, int W, int Cin, int Cout, int Npad, int out_mode, int act, int splitk,
+                int bm, int bn, int dtype, void* stream) {
+  IgemmParams p = {};
+  p.A0 = x_padded; p.Wp = Wp; p.bias = bias; p.residual = residual; p.out = out;
+  p.partial = reinterpret_cast<float*>(partial);
+  p.M = B * H * W; p.N = Cout; p.Npad = Npad; p.Kc = Cin; p.K0 = Cin; p.taps = 9; p.H = H; p.W = W;
+  p.ldo = Cout; p.ldr = Cout; p.out_mode = out_mode; p.act = act; p.splitk = splitk; p.force_bm = bm; p.force_bn = bn;
+  if (p.splitk == 0) p.splitk = partial ? igemm_choose_splitk(p, dtype) : 1;
+  return launch_igemm(p, dtype, reinterpret_cast<hipStream_t>(stream));
+}
+
+size_t k22_groupnorm_scratch_bytes(int B, int C) {
+  return (size_t)B * 256 * 64 * sizeof(float) + (size_t)B * C * 2 * sizeof(float) + 512;
+}
+
+int k22_groupnorm(const void* x0, const void* x1, int C0, int C1, int B, int H, int W, const float* gamma,
+                  const float* beta, const float* film, long film_ld, float eps, int act, int mode, int pad,
+                  void* scratch, void* out, int dtype, void* stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int C = C0 + C1, HW = H * W;
+  const int nsplit = gn_nsplit(B, HW);
+  float* partial = reinterpret_cast<float*>(scratch);
+  float* coeff = partial + (size_t)B * 256 * 64;
+  GnStatsParams sp;
+  sp.x0 = x0; sp.x1 = x1; sp.C0 = C0; sp.C1 = C1; sp.HW = HW; sp.B = B; sp.groups = 32; sp.nsplit = nsplit; sp.partial = partial;
+  int rc = launch_gn_stats(sp, dtype, st);
+  if (rc) return rc;
+  GnCoeffParams cp;
+  cp.partial = partial; cp.nsplit = nsplit; cp.HW = HW; cp.C = C; cp.groups = 32; cp.eps = eps; cp.gamma = gamma; cp.beta = beta;
+  cp.film = film; cp.film_ld = film_ld; cp.coeff = coeff;
+  rc = launch_gn_coeff(cp, B, st);
+  if (rc) return rc;
+  GnApplyParams ap;
+  ap.x0 = x0; ap.x1 = x1; ap.C0 = C0; ap.C1 = C1; ap.B = B; ap.H = H; ap.W = W; ap.mode = mode; ap.pad = pad; ap.act = act;
+  ap.coeff = coeff; ap.out = out;
+  return launch_gn_apply(ap, dtype, st);
+}
+
+int k22_attention(const void* qkv, const void* ctxkv, void* kall, void* vtall, void* out, int B, int H, int T, int S,
+                  int dtype, void* stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int C = H * 64, Tk = S + T, Tkp = (Tk + 63) / 64 * 64;
+  KvPackParams kp;
+  kp.qkv = qkv; kp.ctxkv = ctxkv; kp.kall = kall; kp.vtall = vtall; kp.B = B; kp.H = H; kp.T = T; kp.S = S; kp.Tkp = Tkp;
+  int rc = launch_kv_pack(kp, dtype, st);
+  if (rc) return rc;
+  AttentionParams ap;
+  ap.q = qkv; ap.ldq = 3 * C; ap.kall = kall; ap.vtall = vtall; ap.out = out; ap.ldo = C;
+  ap.B = B; ap.H = H; ap.T = T; ap.Tk = Tk; ap.Tkp = Tkp; ap.scale = 0.125f;
+  return launch_attention(ap, dtype, st);
+}
+
+int k22_linear_smallm(const float* x, const void* W, const float* bias, const float* add, float* out, int M, int N,
+                      int K, int act_in, int act_out, int wdtype, void* stream) {
+  LinearSmallParams lp = {};
+  lp.x = x; lp.ldx = K; lp.W = W; lp.bias = bias; lp.add = add; lp.ld_add = N; lp.out = out; lp.ldo = N;
+  lp.M = M; lp.N = N; lp.K = K; lp.act_in = act_in; lp.act_out = act_out;
+  return launch_linear_smallm(lp, wdtype, reinterpret_cast<hipStream_t>(stream));
+}
+
+size_t k22_sampler_scratch_bytes(int N, int HW) { return (size_t)N * 4 * HW * sizeof(float) + 256; }
+
+int k22_sampler_step(const float* x, const float* model_out, const float* noise, const float* init_img,
+                     const float* mask, const float* table, int step_index, float guidance, int use_cfg,
+                     float clamp_lo, float clamp_hi, int pct_index, double pct_gamma, void* scratch,
+                     float* x_out, float* x0_out, int N, int HW, void* stream) {
+  SamplerParams p = {};
+  p.x = x; p.model_out = model_out; p.noise = noise; p.init_img = init_img; p.mask = mask; p.table = table;
+  p.step = nullptr; p.step_host = step_index; p.guidance = guidance; p.clamp_lo = clamp_lo; p.clamp_hi = clamp_hi;
+  p.use_cfg = use_cfg; p.n_lo = pct_index; p.gamma = pct_gamma;
+  p.s_buf = reinterpret_cast<float*>(scratch);
+  p.x0_buf = reinterpret_cast<float*>(scratch) + 64;
+  p.x_out = x_out; p.x0_out = x0_out; p.N = N; p.HW = HW;
+  if (pct_index >= 4 * HW) return k22_set_error(K22_EINVAL, "sampler: percentile index out of range");
+  return launch_sampler_step(p, reinterpret_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

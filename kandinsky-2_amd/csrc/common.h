@@ -1,0 +1,130 @@
+// k22 — MI355X (gfx950 / CDNA4) native Kandinsky-2 sampling engine: shared device helpers.
+//
+// Element types: the torso of the UNet runs either in bf16 (product path; MFMA
+// v_mfma_f32_32x32x16_bf16) or in fp32 (parity path; v_mfma_f32_32x32x2_f32, exact
+// fp32 FMA chain).  Both paths share one kernel structure: every LDS tile row is 128
+// bytes = 8 chunks of 16 B, and an "atom" is a 32x32x16 matrix product whose A/B
+// fragments are 8 consecutive K elements per lane.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;  // bf16 storage type
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+enum K22DType { K22_BF16 = 0, K22_F32 = 1 };
+enum K22Act { K22_ACT_NONE = 0, K22_ACT_SILU = 1, K22_ACT_GELU = 2 };
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                           // round-to-nearest-even
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float to_f32(bf16_t v) { return bf16_to_f32(v); }
+__device__ __forceinline__ float to_f32(float v) { return v; }
+template <typename T> __device__ __forceinline__ T from_f32(float f);
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float f) { return f32_to_bf16(f); }
+template <> __device__ __forceinline__ float from_f32<float>(float f) { return f; }
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float apply_act(float x, int act) {
+  if (act == K22_ACT_SILU) return silu_f(x);
+  if (act == K22_ACT_GELU) return gelu_f(x);
+  return x;
+}
+
+// ---- per-type tile traits ------------------------------------------------------------
+template <typename T> struct TT;
+template <> struct TT<bf16_t> {
+  static constexpr int BK = 64;      // K elements per 128-byte LDS row
+  static constexpr int EPC = 8;      // elements per 16-byte chunk
+  static constexpr int KSTEPS = 4;   // 32x32x16 atoms per LDS row
+};
+template <> struct TT<float> {
+  static constexpr int BK = 32;
+  static constexpr int EPC = 4;
+  static constexpr int KSTEPS = 2;
+};
+
+// A/B fragment of one 32x32x16 atom: 8 consecutive K elements of one row.
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { uint4 v; };
+template <> struct Frag<float> { float v[8]; };
+
+// Swizzled LDS tile: row r (128 B), logical chunk c (16 B) lives at physical chunk c ^ (r & 7).
+// With this image a ds_read_b128 of "row = lane&31, chunk = const" is bank-conflict free.
+__device__ __forceinline__ int lds_chunk_off(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
+
+// lane-half h (= lane>>5) reads K elements [16*ks + 8*h, +8) of row r.
+__device__ __forceinline__ void ld_frag(Frag<bf16_t>& f, const char* tile, int r, int ks, int h) {
+  f.v = *reinterpret_cast<const uint4*>(tile + lds_chunk_off(r, 2 * ks + h));
+}
+__device__ __forceinline__ void ld_frag(Frag<float>& f, const char* tile, int r, int ks, int h) {
+  const float4 a = *reinterpret_cast<const float4*>(tile + lds_chunk_off(r, 4 * ks + 2 * h));
+  const float4 b = *reinterpret_cast<const float4*>(tile + lds_chunk_off(r, 4 * ks + 2 * h + 1));
+  f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
+  f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+}
+
+// acc(32x32, C layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) += A(32x16) * B(16x32)
+// A fragment: row = lane&31; B fragment: col = lane&31; both hold K = 8*(lane>>5) + j.
+__device__ __forceinline__ void mma_atom(f32x16_t& acc, const Frag<bf16_t>& a, const Frag<bf16_t>& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a.v), __builtin_bit_cast(bf16x8_t, b.v),
+                                                acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_atom(f32x16_t& acc, const Frag<float>& a, const Frag<float>& b) {
+  // 8 exact-fp32 MFMAs (K=2 each): call j pairs element j of lane-half 0 with element j of lane-half 1.
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ int c_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// ---- 64-lane reductions --------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- vector load/store of 8 (bf16) / 4 (f32) elements = 16 bytes -----------------------
+template <typename T> struct Vec16;
+template <> struct Vec16<bf16_t> {
+  static constexpr int N = 8;
+  uint4 raw;
+  __device__ __forceinline__ float get(int i) const {
+    const uint32_t w = (&raw.x)[i >> 1];
+    return __uint_as_float((i & 1) ? (w & 0xffff0000u) : (w << 16));
+  }
+  __device__ __forceinline__ void set2(int pair, float lo, float hi) {
+    (&raw.x)[pair] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  }
+};
+template <> struct Vec16<float> {
+  static constexpr int N = 4;
+  float4 raw;
+  __device__ __forceinline__ float get(int i) const { return (&raw.x)[i]; }
+  __device__ __forceinline__ void set2(int pair, float lo, float hi) {
+    (&raw.x)[2 * pair] = lo;
+    (&raw.x)[2 * pair + 1] = hi;
+  }
+};
+
+#define K22_CHECK_LAUNCH()                                   \
+  do {                                                       \
+    hipError_t e__ = hipGetLastError();                      \
+    if (e__ != hipSuccess) return k22_set_error_hip(e__, __FILE__, __LINE__); \
+  } while (0)
+
+int k22_set_error(int code, const char* msg);
+int k22_set_error_hip(hipError_t e, const char* file, int line);

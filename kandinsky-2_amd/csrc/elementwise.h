@@ -1,0 +1,82 @@
+// k22 — parameter blocks + launchers of the HBM-bound kernels (elementwise.hip), attention
+// (attention.hip) and the sampler step (sampler.hip).
+#pragma once
+#include "common.h"
+
+struct GnStatsParams {
+  const void* x0; const void* x1;   // NHWC [B][HW][C0] (+ [B][HW][C1] virtual concat)
+  int C0, C1, HW, B, groups, nsplit;
+  float* partial;                    // [B][nsplit][64] = (sum, sumsq) x 32 groups
+};
+struct GnCoeffParams {
+  const float* partial; int nsplit, HW, C, groups; float eps;
+  const float* gamma; const float* beta;  // [C]
+  const float* film; int64_t film_ld;      // optional [B][film_ld]: scale at +c, shift at +C+c
+  float* coeff;                            // [B][C][2] = (A, Bc):  y = x*A + Bc
+};
+struct GnApplyParams {
+  const void* x0; const void* x1; int C0, C1;
+  int B, H, W;          // input spatial dims
+  int mode;             // 0 same, 1 avgpool2 after activation, 2 nearest-up2 after activation
+  int pad;              // 1 -> write [B][Ho+2][Wo+2][C] with a zero border
+  int act;              // K22Act
+  const float* coeff;
+  void* out;
+};
+struct ConvInParams {
+  const float* x; const float* img; const float* mask;  // NCHW fp32; img/mask only for Cin == 9
+  const float* w; const float* bias;                    // [Cout][Cin][3][3], [Cout] fp32
+  void* out;                                            // NHWC T [B][H][W][Cout]
+  int B, H, W, Cin, Cout;
+};
+struct LinearSmallParams {
+  const float* x; int64_t ldx;  // [M][K] fp32
+  const void* W;                // [N][K] (dtype given at launch)
+  const float* bias;            // [N] or null
+  const float* add; int64_t ld_add;  // optional [M][N] added after the output activation
+  float* out; int64_t ldo;
+  int M, N, K, act_in, act_out;
+};
+struct KvPackParams {
+  const void* qkv; const void* ctxkv; void* kall; void* vtall;
+  int B, H, T, S, Tkp;
+};
+struct AttentionParams {
+  const void* q; int64_t ldq;   // query rows [B*T] with stride ldq; head h at column h*64
+  const void* kall; const void* vtall;  // [B][H][Tkp][64], [B][H][64][Tkp]
+  void* out; int64_t ldo;       // [B*T][ldo], head h at column h*64
+  int B, H, T, Tk, Tkp;
+  float scale;                  // applied to q.k (reference: ch^-0.25 on both q and k => 1/8)
+};
+struct SamplerParams {
+  const float* x;          // [N][4][HW] current latent (fp32 NCHW)
+  const float* model_out;  // [N][8][HW] raw UNet output (before classifier-free guidance)
+  const float* noise;      // [N][4][HW]
+  const float* init_img;   // inpainting: [N][4][HW] or null
+  const float* mask;       // inpainting: [N][1][HW] or null
+  const float* table;      // [steps][8] per-step scalars (see sampler.hip)
+  const int* step;         // device step counter (index into table) or null -> step_host
+  int step_host;
+  float guidance, clamp_lo, clamp_hi;
+  int use_cfg;             // 1: eps = u + g (c - u) with halves [cond | uncond]; 0: eps as is
+  int n_lo; double gamma;  // percentile order statistic index and interpolation weight; n_lo < 0: off
+  float* x0_buf;           // scratch [N][4][HW]
+  float* s_buf;            // scratch [1]
+  float* x_out;            // [N][4][HW]
+  float* x0_out;           // pred_xstart [N][4][HW] or null
+  int N, HW;
+};
+
+int gn_nsplit(int B, int HW);
+int launch_gn_stats(const GnStatsParams& p, int dtype, hipStream_t s);
+int launch_gn_coeff(const GnCoeffParams& p, int B, hipStream_t s);
+int launch_gn_apply(const GnApplyParams& p, int dtype, hipStream_t s);
+int launch_resample(const void* x, void* y, int B, int H, int W, int C, int mode, int dtype, hipStream_t s);
+int launch_conv_in(const ConvInParams& p, int dtype, hipStream_t s);
+int launch_timestep_embedding(const float* t, const float* freqs, float* out, int B, int half, hipStream_t s);
+int launch_linear_smallm(const LinearSmallParams& p, int wdtype, hipStream_t s);
+int launch_layernorm_f32(const float* x, const float* g, const float* b, float* y, int rows, int D, float eps, hipStream_t s);
+int launch_cast_rows(const float* x, void* y, int rows, int cols, int64_t ldx, int64_t ldy, int dtype, hipStream_t s);
+int launch_kv_pack(const KvPackParams& p, int dtype, hipStream_t s);
+int launch_attention(const AttentionParams& p, int dtype, hipStream_t s);
+int launch_sampler_step(const SamplerParams& p, hipStream_t s);

@@ -1,0 +1,470 @@
+// k22 — HBM-bound kernels of the UNet step: GroupNorm32 (+SiLU, +FiLM, +fused 2x resample, zero
+// border for the consuming 3x3 conv), raw resample, stem conv, timestep embedding, skinny
+// (M<=8) linear, LayerNorm, K / V^T packing for attention and small casts.
+//
+// Reference behaviour restated (file:line relative to /root/reference):
+//   GroupNorm32.forward            kandinsky2/model/nn.py:26-37      (fp32 stats, 32 groups, eps 1e-5)
+//   ResBlock scale-shift norm      kandinsky2/model/unet.py:212-216  (h = GN(h)*(1+scale)+shift ; SiLU)
+//   Upsample / Downsample no-conv  kandinsky2/model/unet.py:67-77, 105-107 (nearest x2 / AvgPool2d(2))
+//   timestep_embedding             kandinsky2/model/nn.py:101-121
+//   QKVAttention K/V concat        kandinsky2/model/unet.py:296-302  (encoder K/V prepended)
+#include "kernels.h"
+#include "elementwise.h"
+
+// ------------------------------------------------------------------------------------------
+// 4-element loads (one GroupNorm group never splits a 4-channel vector: C % 128 == 0)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load4(const bf16_t* p, float* f) {
+  const uint2 r = *reinterpret_cast<const uint2*>(p);
+  f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+  f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+}
+__device__ __forceinline__ void load4(const float* p, float* f) {
+  const float4 r = *reinterpret_cast<const float4*>(p);
+  f[0] = r.x; f[1] = r.y; f[2] = r.z; f[3] = r.w;
+}
+
+// ---- GroupNorm pass 1: per (batch, pixel-range) partial sums of x and x^2 per group ------------
+// grid (nsplit, B), 256 threads. Threads own fixed channel vectors so the sums stay in registers;
+// pixels of the block's range are walked with every wave reading whole contiguous NHWC rows.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(GnStatsParams p) {
+  __shared__ float ls[64];
+  const int tid = threadIdx.x, b = blockIdx.y, s = blockIdx.x;
+  if (tid < 64) ls[tid] = 0.f;
+  __syncthreads();
+  const int C = p.C0 + p.C1, cg = C / p.groups, VP = C / 4;
+  const int per = (p.HW + p.nsplit - 1) / p.nsplit;
+  const int pix0 = s * per, pix1 = min(p.HW, pix0 + per);
+  const T* x0 = reinterpret_cast<const T*>(p.x0) + (int64_t)b * p.HW * p.C0;
+  const T* x1 = p.x1 ? reinterpret_cast<const T*>(p.x1) + (int64_t)b * p.HW * p.C1 : nullptr;
+  int PL, pl;
+  if (VP >= 256) { PL = 1; pl = 0; } else { PL = 256 / VP; pl = tid / VP; }
+  float sum[3] = {0.f, 0.f, 0.f}, sq[3] = {0.f, 0.f, 0.f};
+  int vj[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    int v = (VP >= 256) ? tid + 256 * j : ((j == 0 && pl < PL) ? tid - pl * VP : VP);
+    vj[j] = v < VP ? v : -1;
+  }
+  for (int pix = pix0 + pl; pix < pix1; pix += PL) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (vj[j] >= 0) {
+        const int c = vj[j] * 4;
+        float f[4];
+        if (c < p.C0) load4(x0 + (int64_t)pix * p.C0 + c, f);
+        else load4(x1 + (int64_t)pix * p.C1 + (c - p.C0), f);
+        sum[j] += (f[0] + f[1]) + (f[2] + f[3]);
+        sq[j] += (f[0] * f[0] + f[1] * f[1]) + (f[2] * f[2] + f[3] * f[3]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    if (vj[j] >= 0) {
+      const int g = (vj[j] * 4) / cg;
+      atomicAdd(&ls[2 * g], sum[j]);
+      atomicAdd(&ls[2 * g + 1], sq[j]);
+    }
+  }
+  __syncthreads();
+  if (tid < 2 * p.groups) p.partial[((int64_t)b * p.nsplit + s) * 64 + tid] = ls[tid];
+}
+
+// ---- GroupNorm pass 2: fold mean/rstd, gamma/beta and FiLM into y = x*A[c] + Bc[c] -------------
+// grid (B), 256 threads.  coeff[b][c] = (A, Bc).
+__global__ __launch_bounds__(256) void gn_coeff_kernel(GnCoeffParams p) {
+  __shared__ float mean_s[32], rstd_s[32];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  if (tid < p.groups) {
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < p.nsplit; ++i) {
+      s += (double)p.partial[((int64_t)b * p.nsplit + i) * 64 + 2 * tid];
+      q += (double)p.partial[((int64_t)b * p.nsplit + i) * 64 + 2 * tid + 1];
+    }
+    const double n = (double)p.HW * (double)(p.C / p.groups);
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_s[tid] = (float)mean;
+    rstd_s[tid] = (float)(1.0 / sqrt(var + (double)p.eps));
+  }
+  __syncthreads();
+  const int cg = p.C / p.groups;
+  for (int c = tid; c < p.C; c += 256) {
+    const int g = c / cg;
+    float A = rstd_s[g] * p.gamma[c];
+    float Bc = p.beta[c] - mean_s[g] * A;
+    if (p.film != nullptr) {
+      const float sc = 1.f + p.film[(int64_t)b * p.film_ld + c];
+      const float sh = p.film[(int64_t)b * p.film_ld + p.C + c];
+      A *= sc;
+      Bc = Bc * sc + sh;
+    }
+    p.coeff[((int64_t)b * p.C + c) * 2] = A;
+    p.coeff[((int64_t)b * p.C + c) * 2 + 1] = Bc;
+  }
+}
+
+// ---- GroupNorm pass 3: apply (+act) (+avgpool2 / nearest-up2) and write the (optionally
+// zero-bordered) NHWC tensor the next conv / GEMM consumes.  One thread = 16 bytes of output.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyParams p) {
+  constexpr int EPV = Vec16<T>::N;
+  const int C = p.C0 + p.C1, CV = C / EPV;
+  const int Ho = p.mode == 1 ? p.H / 2 : (p.mode == 2 ? p.H * 2 : p.H);
+  const int Wo = p.mode == 1 ? p.W / 2 : (p.mode == 2 ? p.W * 2 : p.W);
+  const int pad = p.pad, Hp = Ho + 2 * pad, Wp = Wo + 2 * pad;
+  const int64_t total = (int64_t)p.B * Hp * Wp * CV;
+  T* out = reinterpret_cast<T*>(p.out);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    int64_t t = i / CV;
+    const int xo = (int)(t % Wp) - pad; t /= Wp;
+    const int yo = (int)(t % Hp) - pad;
+    const int b = (int)(t / Hp);
+    Vec16<T> o;
+    if (xo < 0 || yo < 0 || xo >= Wo || yo >= Ho) {
+#pragma unroll
+      for (int k = 0; k < EPV / 2; ++k) o.set2(k, 0.f, 0.f);
+    } else {
+      const int c = cv * EPV;
+      const T* src; int cs, ld;
+      if (c < p.C0) { src = reinterpret_cast<const T*>(p.x0); cs = c; ld = p.C0; }
+      else { src = reinterpret_cast<const T*>(p.x1); cs = c - p.C0; ld = p.C1; }
+      float A[EPV], Bc[EPV];
+      const float* cf = p.coeff + ((int64_t)b * C + c) * 2;
+#pragma unroll
+      for (int k = 0; k < EPV; k += 2) {
+        const float4 q = *reinterpret_cast<const float4*>(cf + 2 * k);
+        A[k] = q.x; Bc[k] = q.y; A[k + 1] = q.z; Bc[k + 1] = q.w;
+      }
+      float r[EPV];
+      if (p.mode == 1) {
+#pragma unroll
+        for (int k = 0; k < EPV; ++k) r[k] = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            Vec16<T> v;
+            v.raw = *reinterpret_cast<const decltype(v.raw)*>(src + ((int64_t)(b * p.H + 2 * yo + dy) * p.W + 2 * xo + dx) * ld + cs);
+#pragma unroll
+            for (int k = 0; k < EPV; ++k) r[k] += apply_act(v.get(k) * A[k] + Bc[k], p.act);
+          }
+#pragma unroll
+        for (int k = 0; k < EPV; ++k) r[k] *= 0.25f;
+      } else {
+        const int yi = p.mode == 2 ? yo >> 1 : yo, xi = p.mode == 2 ? xo >> 1 : xo;
+        Vec16<T> v;
+        v.raw = *reinterpret_cast<const decltype(v.raw)*>(src + ((int64_t)(b * p.H + yi) * p.W + xi) * ld + cs);
+#pragma unroll
+        for (int k = 0; k < EPV; ++k) r[k] = apply_act(v.get(k) * A[k] + Bc[k], p.act);
+      }
+#pragma unroll
+      for (int k = 0; k < EPV / 2; ++k) o.set2(k, r[2 * k], r[2 * k + 1]);
+    }
+    *reinterpret_cast<decltype(o.raw)*>(out + i * EPV) = o.raw;
+  }
+}
+
+// ---- raw 2x resample of the residual branch (x_upd), unpadded NHWC -> unpadded NHWC ------------
+template <typename T>
+__global__ __launch_bounds__(256) void resample_kernel(const void* xin, void* yout, int B, int H, int W, int C, int mode) {
+  constexpr int EPV = Vec16<T>::N;
+  const int CV = C / EPV;
+  const int Ho = mode == 1 ? H / 2 : H * 2, Wo = mode == 1 ? W / 2 : W * 2;
+  const int64_t total = (int64_t)B * Ho * Wo * CV;
+  const T* x = reinterpret_cast<const T*>(xin);
+  T* y = reinterpret_cast<T*>(yout);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    int64_t t = i / CV;
+    const int xo = (int)(t % Wo); t /= Wo;
+    const int yo = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    Vec16<T> o;
+    if (mode == 1) {
+      float r[EPV];
+#pragma unroll
+      for (int k = 0; k < EPV; ++k) r[k] = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          Vec16<T> v;
+          v.raw = *reinterpret_cast<const decltype(v.raw)*>(x + ((int64_t)(b * H + 2 * yo + dy) * W + 2 * xo + dx) * C + cv * EPV);
+#pragma unroll
+          for (int k = 0; k < EPV; ++k) r[k] += v.get(k);
+        }
+#pragma unroll
+      for (int k = 0; k < EPV / 2; ++k) o.set2(k, r[2 * k] * 0.25f, r[2 * k + 1] * 0.25f);
+    } else {
+      o.raw = *reinterpret_cast<const decltype(o.raw)*>(x + ((int64_t)(b * H + (yo >> 1)) * W + (xo >> 1)) * C + cv * EPV);
+    }
+    *reinterpret_cast<decltype(o.raw)*>(y + i * EPV) = o.raw;
+  }
+}
+
+// ---- stem: conv3x3 over the fp32 NCHW latent (4 ch, or 9 = [x, img*mask, mask] for inpainting)
+// (unet.py:426 input_blocks[0]; text2im_model2_1.py:146-155).  One block = 32 pixels of one row.
+template <typename T, int CIN>
+__global__ __launch_bounds__(128) void conv_in_kernel(ConvInParams p) {
+  __shared__ float patch[CIN][3][34];
+  const int tid = threadIdx.x;
+  const int xt = blockIdx.x, y = blockIdx.y, b = blockIdx.z;
+  const int x0 = xt * 32;
+  const int hw = p.H * p.W;
+  for (int i = tid; i < CIN * 3 * 34; i += 128) {
+    const int c = i / 102, r = (i / 34) % 3, xx = i % 34;
+    const int yy = y + r - 1, xs = x0 + xx - 1;
+    float v = 0.f;
+    if (yy >= 0 && yy < p.H && xs >= 0 && xs < p.W) {
+      const int64_t o = (int64_t)yy * p.W + xs;
+      if (c < 4) v = p.x[((int64_t)b * 4 + c) * hw + o];
+      else if (c < 8) v = p.img[((int64_t)b * 4 + (c - 4)) * hw + o] * p.mask[(int64_t)b * hw + o];
+      else v = p.mask[(int64_t)b * hw + o];
+    }
+    patch[c][r][xx] = v;
+  }
+  __syncthreads();
+  T* out = reinterpret_cast<T*>(p.out);
+  for (int n = tid; n < p.Cout; n += 128) {
+    float w[CIN * 9];
+#pragma unroll
+    for (int k = 0; k < CIN * 9; ++k) w[k] = p.w[(int64_t)n * CIN * 9 + k];
+    const float bias = p.bias[n];
+    for (int px = 0; px < 32 && x0 + px < p.W; ++px) {
+      float acc = bias;
+#pragma unroll
+      for (int c = 0; c < CIN; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) acc += w[c * 9 + r * 3 + q] * patch[c][r][px + q];
+      out[((int64_t)(b * p.H + y) * p.W + x0 + px) * p.Cout + n] = from_f32<T>(acc);
+    }
+  }
+}
+
+// ---- sinusoidal timestep embedding with a host-supplied frequency table (nn.py:101-121) --------
+__global__ void timestep_embedding_kernel(const float* t, const float* freqs, float* out, int B, int half) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * half) return;
+  const int b = i / half, k = i - b * half;
+  const float a = t[b] * freqs[k];
+  out[(int64_t)b * 2 * half + k] = cosf(a);
+  out[(int64_t)b * 2 * half + half + k] = sinf(a);
+}
+
+// ---- skinny linear: out[m][n] = act_out( sum_k act_in(x[m][k]) * W[n][k] + bias[n] ) + add[m][n]
+// M <= 8 rows, one wave per output feature, weights streamed once (HBM-bound GEMV).
+template <typename TW>
+__global__ __launch_bounds__(256) void linear_smallm_kernel(LinearSmallParams p) {
+  constexpr int EPC = 16 / sizeof(TW);
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= p.N) return;
+  const TW* w = reinterpret_cast<const TW*>(p.W) + (int64_t)n * p.K;
+  float acc[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) acc[m] = 0.f;
+  for (int k = lane * EPC; k < p.K; k += 64 * EPC) {
+    Vec16<TW> wv;
+    wv.raw = *reinterpret_cast<const decltype(wv.raw)*>(w + k);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      if (m < p.M) {
+        const float* xr = p.x + (int64_t)m * p.ldx + k;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          float xv = xr[e];
+          if (p.act_in == K22_ACT_SILU) xv = silu_f(xv);
+          acc[m] += xv * wv.get(e);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    if (m < p.M) {
+      float v = wave_sum(acc[m]);
+      if (lane == 0) {
+        if (p.bias) v += p.bias[n];
+        v = apply_act(v, p.act_out);
+        if (p.add) v += p.add[(int64_t)m * p.ld_add + n];
+        p.out[(int64_t)m * p.ldo + n] = v;
+      }
+    }
+  }
+}
+
+// ---- LayerNorm over the last dim of fp32 rows (text2im_model2_1.py:71 ln_model_n; prior.py) ----
+__global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* x, const float* g, const float* bta, float* y, int D, float eps) {
+  __shared__ float red[8];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* xr = x + (int64_t)row * D;
+  float s = 0.f;
+  for (int i = tid; i < D; i += 256) s += xr[i];
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  const float mean = (red[0] + red[1] + red[2] + red[3]) / D;
+  float q = 0.f;
+  for (int i = tid; i < D; i += 256) { const float d = xr[i] - mean; q += d * d; }
+  q = wave_sum(q);
+  if ((tid & 63) == 0) red[4 + (tid >> 6)] = q;
+  __syncthreads();
+  const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / D + eps);
+  for (int i = tid; i < D; i += 256) y[(int64_t)row * D + i] = (xr[i] - mean) * rstd * g[i] + bta[i];
+}
+
+// ---- fp32 -> T cast with row re-striding (ctx assembly) -----------------------------------
+template <typename T>
+__global__ void cast_rows_kernel(const float* x, void* yout, int rows, int cols, int64_t ldx, int64_t ldy) {
+  T* y = reinterpret_cast<T*>(yout);
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+    y[r * ldy + c] = from_f32<T>(x[r * ldx + c]);
+  }
+}
+
+// ---- attention operand packing ----------------------------------------------------------------
+// K_all[b][h][j][64]  and  VT_all[b][h][d][Tkp]  with keys j = [ctx(0..S-1) | self(S..S+T-1) | 0-pad].
+// qkv  : [B*T][3C] columns [q | k | v], each [H][64];   ctxkv : [B*S][2C] columns [k | v].
+// grid (Tkp/64, H, B), 256 threads; V tile transposed through LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void kv_pack_kernel(KvPackParams p) {
+  __shared__ T vt[64][66];
+  const int tid = threadIdx.x, jt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int C = p.H * 64, Tk = p.S + p.T;
+  const T* qkv = reinterpret_cast<const T*>(p.qkv);
+  const T* ckv = reinterpret_cast<const T*>(p.ctxkv);
+  T* Kall = reinterpret_cast<T*>(p.kall) + ((int64_t)(b * p.H + h) * p.Tkp) * 64;
+  T* VTall = reinterpret_cast<T*>(p.vtall) + ((int64_t)(b * p.H + h) * 64) * p.Tkp;
+  for (int i = tid; i < 64 * 64; i += 256) {
+    const int jj = i >> 6, d = i & 63;
+    const int j = jt * 64 + jj;
+    T kv = from_f32<T>(0.f), vv = from_f32<T>(0.f);
+    if (j < p.S) {
+      const T* r = ckv + (int64_t)(b * p.S + j) * 2 * C + h * 64 + d;
+      kv = r[0]; vv = r[C];
+    } else if (j < Tk) {
+      const T* r = qkv + (int64_t)(b * p.T + (j - p.S)) * 3 * C + C + h * 64 + d;
+      kv = r[0]; vv = r[C];
+    }
+    Kall[(int64_t)j * 64 + d] = kv;
+    vt[d][jj] = vv;
+  }
+  __syncthreads();
+  for (int i = tid; i < 64 * 64; i += 256) {
+    const int d = i >> 6, jj = i & 63;
+    VTall[(int64_t)d * p.Tkp + jt * 64 + jj] = vt[d][jj];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+static inline int grid_for(int64_t total, int threads, int cap) {
+  int64_t nb = (total + threads - 1) / threads;
+  if (nb > cap) nb = cap;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+int gn_nsplit(int B, int HW) {
+  int ns = 1024 / (B > 0 ? B : 1);
+  if (ns > 256) ns = 256;
+  while (ns > 1 && HW / ns < 8) ns >>= 1;
+  return ns < 1 ? 1 : ns;
+}
+
+int launch_gn_stats(const GnStatsParams& p, int dtype, hipStream_t s) {
+  const int C = p.C0 + p.C1;
+  if (p.groups != 32 || C % 128 != 0 || p.C0 % 4 != 0) return k22_set_error(K22_EINVAL, "gn_stats: need 32 groups, C % 128 == 0");
+  if (C / 4 > 768) return k22_set_error(K22_EINVAL, "gn_stats: C too large (max 3072)");
+  dim3 grid(p.nsplit, p.B);
+  if (dtype == K22_BF16) hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, s, p);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+int launch_gn_coeff(const GnCoeffParams& p, int B, hipStream_t s) {
+  hipLaunchKernelGGL(gn_coeff_kernel, dim3(B), dim3(256), 0, s, p);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+int launch_gn_apply(const GnApplyParams& p, int dtype, hipStream_t s) {
+  const int C = p.C0 + p.C1;
+  const int epv = dtype == K22_BF16 ? 8 : 4;
+  if (C % epv || p.C0 % epv) return k22_set_error(K22_EINVAL, "gn_apply: channel alignment");
+  const int Ho = p.mode == 1 ? p.H / 2 : (p.mode == 2 ? p.H * 2 : p.H);
+  const int Wo = p.mode == 1 ? p.W / 2 : (p.mode == 2 ? p.W * 2 : p.W);
+  const int64_t total = (int64_t)p.B * (Ho + 2 * p.pad) * (Wo + 2 * p.pad) * (C / epv);
+  const int nb = grid_for(total, 256, 8192);
+  if (dtype == K22_BF16) hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(nb), dim3(256), 0, s, p);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+int launch_resample(const void* x, void* y, int B, int H, int W, int C, int mode, int dtype, hipStream_t s) {
+  const int epv = dtype == K22_BF16 ? 8 : 4;
+  const int Ho = mode == 1 ? H / 2 : H * 2, Wo = mode == 1 ? W / 2 : W * 2;
+  const int nb = grid_for((int64_t)B * Ho * Wo * (C / epv), 256, 8192);
+  if (dtype == K22_BF16) hipLaunchKernelGGL(resample_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, x, y, B, H, W, C, mode);
+  else hipLaunchKernelGGL(resample_kernel<float>, dim3(nb), dim3(256), 0, s, x, y, B, H, W, C, mode);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+int launch_conv_in(const ConvInParams& p, int dtype, hipStream_t s) {
+  dim3 grid((p.W + 31) / 32, p.H, p.B);
+  if (p.Cin == 4) {
+    if (dtype == K22_BF16) hipLaunchKernelGGL((conv_in_kernel<bf16_t, 4>), grid, dim3(128), 0, s, p);
+    else hipLaunchKernelGGL((conv_in_kernel<float, 4>), grid, dim3(128), 0, s, p);
+  } else if (p.Cin == 9) {
+    if (dtype == K22_BF16) hipLaunchKernelGGL((conv_in_kernel<bf16_t, 9>), grid, dim3(128), 0, s, p);
+    else hipLaunchKernelGGL((conv_in_kernel<float, 9>), grid, dim3(128), 0, s, p);
+  } else {
+    return k22_set_error(K22_EINVAL, "conv_in: in_channels must be 4 or 9");
+  }
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+int launch_timestep_embedding(const float* t, const float* freqs, float* out, int B, int half, hipStream_t s) {
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((B * half + 255) / 256), dim3(256), 0, s, t, freqs, out, B, half);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+int launch_linear_smallm(const LinearSmallParams& p, int wdtype, hipStream_t s) {
+  if (p.M > 8) return k22_set_error(K22_EINVAL, "linear_smallm: M must be <= 8");
+  const int epc = wdtype == K22_BF16 ? 8 : 4;
+  if (p.K % epc) return k22_set_error(K22_EINVAL, "linear_smallm: K alignment");
+  dim3 grid((p.N + 3) / 4);
+  if (wdtype == K22_BF16) hipLaunchKernelGGL(linear_smallm_kernel<bf16_t>, grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(linear_smallm_kernel<float>, grid, dim3(256), 0, s, p);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+int launch_layernorm_f32(const float* x, const float* g, const float* b, float* y, int rows, int D, float eps, hipStream_t s) {
+  hipLaunchKernelGGL(layernorm_f32_kernel, dim3(rows), dim3(256), 0, s, x, g, b, y, D, eps);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+int launch_cast_rows(const float* x, void* y, int rows, int cols, int64_t ldx, int64_t ldy, int dtype, hipStream_t s) {
+  const int nb = grid_for((int64_t)rows * cols, 256, 4096);
+  if (dtype == K22_BF16) hipLaunchKernelGGL(cast_rows_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, x, y, rows, cols, ldx, ldy);
+  else hipLaunchKernelGGL(cast_rows_kernel<float>, dim3(nb), dim3(256), 0, s, x, y, rows, cols, ldx, ldy);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+int launch_kv_pack(const KvPackParams& p, int dtype, hipStream_t s) {
+  if (p.Tkp % 64) return k22_set_error(K22_EINVAL, "kv_pack: Tkp % 64");
+  dim3 grid(p.Tkp / 64, p.H, p.B);
+  if (dtype == K22_BF16) hipLaunchKernelGGL(kv_pack_kernel<bf16_t>, grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(kv_pack_kernel<float>, grid, dim3(256), 0, s, p);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}

@@ -1,0 +1,536 @@
+// k22 — UNet engine: builds the launch list of one Text2ImUNet forward from the reference's
+// hyper-parameters and replays it (eagerly or as a captured hipGraph) on a caller-owned workspace.
+//
+// Structure mirrors UNetModel.__init__/forward (kandinsky2/model/unet.py:371-611) and
+// Text2ImUNet.forward/get_text_emb (kandinsky2/model/text2im_model2_1.py:57-103):
+//   emb = time_embed(timestep_embedding(t)) + xf_proj ; 16 input blocks ; middle ; 16 output blocks
+//   (skip concat) ; out = GN+SiLU+conv3x3.
+// MI355X mapping: activations live as NHWC in the workspace; every 3x3 conv input is written by the
+// GroupNorm-apply kernel with a zero border; skip concats are never materialised (GroupNorm and the
+// 1x1 skip GEMM take two base pointers); all 36 emb_layers run as ONE skinny GEMV per step;
+// encoder_kv is hoisted into set_condition (its input, the cached xf_out, is step-invariant).
+#include "kernels.h"
+#include "elementwise.h"
+#include "../../include/k22.h"
+
+#include <deque>
+#include <functional>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+int launch_step_advance(int* step, int delta, hipStream_t s);
+
+namespace {
+
+struct Slot { size_t bytes = 0, off = 0; };
+
+struct Act {  // unpadded NHWC activation, optionally a virtual channel concat of two tensors
+  Slot* s0 = nullptr; int C0 = 0;
+  Slot* s1 = nullptr; int C1 = 0;
+  int H = 0, W = 0;
+  int C() const { return C0 + C1; }
+};
+
+}  // namespace
+
+struct K22UNet {
+  K22UNetConfig cfg;
+  int dtype; size_t esz;
+  std::unordered_map<std::string, const void*> w;
+
+  // ---- plan state ----
+  int B = 0, H = 0, W = 0;
+  std::deque<Slot> slots;
+  std::vector<std::function<int(hipStream_t)>> ops;       // one UNet forward
+  std::vector<std::function<int(hipStream_t)>> cond_ops;  // conditioning head
+  size_t ws_bytes = 0;
+  char* ws = nullptr;
+  bool cond_set = false;
+  hipGraphExec_t graph_exec = nullptr;
+  std::string err;
+
+  // persistent slots
+  Slot *s_xin, *s_img, *s_mask, *s_t, *s_out;
+  Slot *s_temb, *s_e1, *s_emb, *s_film, *s_xfproj, *s_ctx;
+  Slot *s_full, *s_pool, *s_imgemb, *s_tmpf, *s_tmpf2, *s_fullT;
+  Slot *s_part, *s_coeff, *s_P1, *s_U1, *s_P2, *s_S, *s_N, *s_QKV, *s_KALL, *s_VT, *s_ATT, *s_splitk;
+  Slot* s_h[3];
+  std::vector<Slot*> s_ctxkv;  // one per attention block
+  int n_attn = 0;
+  int64_t film_total = 0;
+
+  Slot* new_slot(size_t bytes = 0) { slots.emplace_back(); slots.back().bytes = bytes; return &slots.back(); }
+  static void need(Slot* s, size_t bytes) { if (bytes > s->bytes) s->bytes = bytes; }
+  template <typename T = char> T* ptr(const Slot* s) const { return reinterpret_cast<T*>(ws + s->off); }
+
+  const void* W_(const std::string& name) {
+    auto it = w.find(name);
+    if (it == w.end()) { if (err.empty()) err = "missing weight: " + name; return nullptr; }
+    return it->second;
+  }
+  const float* Wf(const std::string& name) { return reinterpret_cast<const float*>(W_(name)); }
+
+  ~K22UNet() { if (graph_exec) (void)hipGraphExecDestroy(graph_exec); }
+
+  // ------------------------------------------------------------------------------------------
+  void op_gn(std::vector<std::function<int(hipStream_t)>>& L, const Act& in, const std::string& pfx, int64_t film_off,
+             int act, int mode, int pad, Slot* dst) {
+    const int Bn = B, C = in.C(), HW = in.H * in.W;
+    const int nsplit = gn_nsplit(Bn, HW);
+    need(s_part, (size_t)Bn * nsplit * 64 * sizeof(float));
+    need(s_coeff, (size_t)Bn * C * 2 * sizeof(float));
+    const int Ho = mode == 1 ? in.H / 2 : (mode == 2 ? in.H * 2 : in.H);
+    const int Wo = mode == 1 ? in.W / 2 : (mode == 2 ? in.W * 2 : in.W);
+    need(dst, (size_t)Bn * (Ho + 2 * pad) * (Wo + 2 * pad) * C * esz);
+    const float* gamma = Wf(pfx + ".weight");
+    const float* beta = Wf(pfx + ".bias");
+    const Act a = in;
+    const int dt = dtype;
+    L.push_back([=](hipStream_t st) {
+      GnStatsParams sp;
+      sp.x0 = ptr(a.s0); sp.x1 = a.s1 ? ptr(a.s1) : nullptr; sp.C0 = a.C0; sp.C1 = a.C1;
+      sp.HW = HW; sp.B = Bn; sp.groups = 32; sp.nsplit = nsplit; sp.partial = ptr<float>(s_part);
+      int rc = launch_gn_stats(sp, dt, st);
+      if (rc) return rc;
+      GnCoeffParams cp;
+      cp.partial = ptr<float>(s_part); cp.nsplit = nsplit; cp.HW = HW; cp.C = C; cp.groups = 32; cp.eps = 1e-5f;
+      cp.gamma = gamma; cp.beta = beta;
+      cp.film = film_off >= 0 ? ptr<float>(s_film) + film_off : nullptr; cp.film_ld = film_total;
+      cp.coeff = ptr<float>(s_coeff);
+      rc = launch_gn_coeff(cp, Bn, st);
+      if (rc) return rc;
+      GnApplyParams ap;
+      ap.x0 = sp.x0; ap.x1 = sp.x1; ap.C0 = a.C0; ap.C1 = a.C1; ap.B = Bn; ap.H = a.H; ap.W = a.W;
+      ap.mode = mode; ap.pad = pad; ap.act = act; ap.coeff = ptr<float>(s_coeff); ap.out = ptr(dst);
+      return launch_gn_apply(ap, dt, st);
+    });
+  }
+
+  // conv3x3 over a zero-bordered slot `src` [B][Hc+2][Wc+2][Cin]
+  void op_conv(std::vector<std::function<int(hipStream_t)>>& L, Slot* src, int Hc, int Wc, int Cin, int Cout,
+               const std::string& pfx, const Act* residual, Slot* dst, int out_mode) {
+    IgemmParams p = {};
+    p.M = B * Hc * Wc; p.N = Cout; p.Npad = (Cout + 63) / 64 * 64; p.Kc = Cin; p.K0 = Cin; p.taps = 9;
+    p.H = Hc; p.W = Wc; p.ldo = Cout; p.ldr = Cout; p.out_mode = out_mode; p.act = K22_ACT_NONE;
+    p.Wp = W_(pfx + ".weight"); p.bias = Wf(pfx + ".bias");
+    p.splitk = igemm_choose_splitk(p, dtype);
+    if (p.splitk > 1) need(s_splitk, (size_t)p.splitk * p.M * p.N * sizeof(float));
+    need(dst, out_mode == IG_OUT_ROWMAJOR ? (size_t)p.M * Cout * esz : (size_t)p.M * Cout * sizeof(float));
+    Slot* rs = residual ? residual->s0 : nullptr;
+    const int dt = dtype;
+    L.push_back([=](hipStream_t st) {
+      IgemmParams q = p;
+      q.A0 = ptr(src); q.residual = rs ? ptr(rs) : nullptr; q.out = ptr(dst); q.partial = ptr<float>(s_splitk);
+      return launch_igemm(q, dt, st);
+    });
+  }
+
+  // GEMM over unpadded rows (1x1 conv / linear); `in` may be a virtual concat.
+  void op_gemm(std::vector<std::function<int(hipStream_t)>>& L, const Act& in, int M, int N, const std::string& pfx,
+               const Act* residual, Slot* dst, int ldo = 0) {
+    IgemmParams p = {};
+    p.M = M; p.N = N; p.Npad = (N + 63) / 64 * 64; p.Kc = in.C(); p.K0 = in.C0; p.taps = 1;
+    p.lda0 = in.C0; p.lda1 = in.C1; p.ldo = ldo ? ldo : N; p.ldr = N; p.out_mode = IG_OUT_ROWMAJOR;
+    p.act = K22_ACT_NONE;
+    p.Wp = W_(pfx + ".weight"); p.bias = Wf(pfx + ".bias");
+    p.splitk = igemm_choose_splitk(p, dtype);
+    if (p.splitk > 1) need(s_splitk, (size_t)p.splitk * p.M * p.N * sizeof(float));
+    need(dst, (size_t)M * p.ldo * esz);
+    const Act a = in;
+    Slot* rs = residual ? residual->s0 : nullptr;
+    const int dt = dtype;
+    L.push_back([=](hipStream_t st) {
+      IgemmParams q = p;
+      q.A0 = ptr(a.s0); q.A1 = a.s1 ? ptr(a.s1) : nullptr;
+      q.residual = rs ? ptr(rs) : nullptr; q.out = ptr(dst); q.partial = ptr<float>(s_splitk);
+      return launch_igemm(q, dt, st);
+    });
+  }
+
+  // ResBlock (unet.py:110-220) with use_scale_shift_norm=True; updown: 0 none, 1 down, 2 up.
+  Act resblock(const std::string& pfx, const Act& in, int Cout, int updown, int64_t& film_cursor, Slot* dst) {
+    const int Cin = in.C();
+    const int Ho = updown == 1 ? in.H / 2 : (updown == 2 ? in.H * 2 : in.H);
+    const int Wo = updown == 1 ? in.W / 2 : (updown == 2 ? in.W * 2 : in.W);
+    // in_layers: GN + SiLU (+ resample) -> conv3x3
+    op_gn(ops, in, pfx + ".in_layers.0", -1, K22_ACT_SILU, updown, 1, s_P1);
+    op_conv(ops, s_P1, Ho, Wo, Cin, Cout, pfx + ".in_layers.2", nullptr, s_U1, IG_OUT_ROWMAJOR);
+    // out_layers: GN * (1+scale) + shift -> SiLU -> conv3x3 (+ skip)
+    Act u1; u1.s0 = s_U1; u1.C0 = Cout; u1.H = Ho; u1.W = Wo;
+    const int64_t film_off = film_cursor;
+    film_cursor += 2 * Cout;
+    op_gn(ops, u1, pfx + ".out_layers.0", film_off, K22_ACT_SILU, 0, 1, s_P2);
+    Act skip;
+    skip.H = Ho; skip.W = Wo; skip.C0 = Cout;
+    if (updown) {
+      if (Cin != Cout || in.s1) { if (err.empty()) err = "updown ResBlock with channel change is not supported"; }
+      need(s_S, (size_t)B * Ho * Wo * Cin * esz);
+      const Act a = in; const int Bn = B, dt = dtype;
+      ops.push_back([=](hipStream_t st) { return launch_resample(ptr(a.s0), ptr(s_S), Bn, a.H, a.W, Cin, updown, dt, st); });
+      skip.s0 = s_S;
+    } else if (Cin != Cout) {
+      op_gemm(ops, in, B * Ho * Wo, Cout, pfx + ".skip_connection", nullptr, s_S);
+      skip.s0 = s_S;
+    } else {
+      if (in.s1) { if (err.empty()) err = "identity skip over a concat input"; }
+      skip.s0 = in.s0;
+    }
+    op_conv(ops, s_P2, Ho, Wo, Cout, Cout, pfx + ".out_layers.3", &skip, dst, IG_OUT_ROWMAJOR);
+    Act out; out.s0 = dst; out.C0 = Cout; out.H = Ho; out.W = Wo;
+    return out;
+  }
+
+  // AttentionBlock (unet.py:223-269) + QKVAttention (:272-340)
+  Act attnblock(const std::string& pfx, const Act& in, Slot* dst) {
+    const int C = in.C0, T = in.H * in.W, Hh = C / 64, S = cfg.ctx_len;
+    const int Tk = S + T, Tkp = (Tk + 63) / 64 * 64;
+    const int idx = n_attn++;
+    op_gn(ops, in, pfx + ".norm", -1, K22_ACT_NONE, 0, 0, s_N);
+    Act n; n.s0 = s_N; n.C0 = C; n.H = in.H; n.W = in.W;
+    op_gemm(ops, n, B * T, 3 * C, pfx + ".qkv", nullptr, s_QKV);
+    // encoder_kv (step-invariant) -> cond_ops
+    Slot* ckv = new_slot((size_t)B * S * 2 * C * esz);
+    s_ctxkv.push_back(ckv);
+    {
+      Act c; c.s0 = s_ctx; c.C0 = cfg.ctx_dim; c.H = 1; c.W = S;
+      op_gemm(cond_ops, c, B * S, 2 * C, pfx + ".encoder_kv", nullptr, ckv);
+    }
+    need(s_KALL, (size_t)B * Hh * Tkp * 64 * esz);
+    need(s_VT, (size_t)B * Hh * Tkp * 64 * esz);
+    need(s_ATT, (size_t)B * T * C * esz);
+    const int Bn = B, dt = dtype;
+    ops.push_back([=](hipStream_t st) {
+      KvPackParams kp;
+      kp.qkv = ptr(s_QKV); kp.ctxkv = ptr(ckv); kp.kall = ptr(s_KALL); kp.vtall = ptr(s_VT);
+      kp.B = Bn; kp.H = Hh; kp.T = T; kp.S = S; kp.Tkp = Tkp;
+      int rc = launch_kv_pack(kp, dt, st);
+      if (rc) return rc;
+      AttentionParams ap;
+      ap.q = ptr(s_QKV); ap.ldq = 3 * C; ap.kall = ptr(s_KALL); ap.vtall = ptr(s_VT); ap.out = ptr(s_ATT); ap.ldo = C;
+      ap.B = Bn; ap.H = Hh; ap.T = T; ap.Tk = Tk; ap.Tkp = Tkp; ap.scale = 0.125f;
+      return launch_attention(ap, dt, st);
+    });
+    Act a; a.s0 = s_ATT; a.C0 = C; a.H = in.H; a.W = in.W;
+    op_gemm(ops, a, B * T, C, pfx + ".proj_out", &in, dst);
+    Act out; out.s0 = dst; out.C0 = C; out.H = in.H; out.W = in.W;
+    return out;
+  }
+
+  bool has_attn(int ds) const {
+    for (int i = 0; i < cfg.n_attention_ds; ++i) if (cfg.attention_ds[i] == ds) return true;
+    return false;
+  }
+
+  int plan(int nB, int nH, int nW) {
+    B = nB; H = nH; W = nW;
+    slots.clear(); ops.clear(); cond_ops.clear(); s_ctxkv.clear(); n_attn = 0; err.clear();
+    ws = nullptr; cond_set = false;
+    if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+    const int mc = cfg.model_channels, ted = 4 * mc;
+    const int n_down = cfg.n_levels - 1;
+    if (H % (1 << n_down) || W % (1 << n_down)) return k22_set_error(K22_EINVAL, "unet: H, W must be divisible by 2^(levels-1)");
+    if (B > 8) return k22_set_error(K22_EINVAL, "unet: batch (2*bs) must be <= 8 per engine call");
+
+    // total FiLM width = sum over ResBlocks of 2*Cout, in module order
+    film_total = 0;
+    {
+      int ch = mc * cfg.channel_mult[0];
+      for (int l = 0; l < cfg.n_levels; ++l) {
+        for (int i = 0; i < cfg.num_res_blocks; ++i) { ch = mc * cfg.channel_mult[l]; film_total += 2 * ch; }
+        if (l != cfg.n_levels - 1) film_total += 2 * ch;
+      }
+      film_total += 2 * 2 * ch;  // middle
+      for (int l = cfg.n_levels - 1; l >= 0; --l)
+        for (int i = 0; i <= cfg.num_res_blocks; ++i) {
+          ch = mc * cfg.channel_mult[l];
+          film_total += 2 * ch;
+          if (l && i == cfg.num_res_blocks) film_total += 2 * ch;
+        }
+    }
+
+    s_xin = new_slot((size_t)B * 4 * H * W * 4); s_img = new_slot((size_t)B * 4 * H * W * 4);
+    s_mask = new_slot((size_t)B * H * W * 4); s_t = new_slot((size_t)B * 4 + 64);
+    s_out = new_slot((size_t)B * cfg.out_channels * H * W * 4);
+    s_temb = new_slot((size_t)B * mc * 4); s_e1 = new_slot((size_t)B * ted * 4); s_emb = new_slot((size_t)B * ted * 4);
+    s_film = new_slot((size_t)B * film_total * 4); s_xfproj = new_slot((size_t)B * ted * 4);
+    s_ctx = new_slot((size_t)B * cfg.ctx_len * cfg.ctx_dim * esz);
+    s_full = new_slot((size_t)B * 77 * cfg.text_dim1 * 4); s_pool = new_slot((size_t)B * cfg.text_dim2 * 4);
+    s_imgemb = new_slot((size_t)B * cfg.image_dim * 4);
+    s_tmpf = new_slot((size_t)B * cfg.n_image_embs * cfg.ctx_dim * 4 + (size_t)B * ted * 4);
+    s_tmpf2 = new_slot((size_t)B * ted * 4);
+    s_fullT = new_slot((size_t)B * 77 * cfg.text_dim1 * esz);
+    s_part = new_slot(); s_coeff = new_slot(); s_P1 = new_slot(); s_U1 = new_slot(); s_P2 = new_slot(); s_S = new_slot();
+    s_N = new_slot(); s_QKV = new_slot(); s_KALL = new_slot(); s_VT = new_slot(); s_ATT = new_slot();
+    s_splitk = new_slot(256);
+    for (int i = 0; i < 3; ++i) s_h[i] = new_slot();
+    int hrot = 0;
+    auto next_h = [&]() { Slot* s = s_h[hrot]; hrot = (hrot + 1) % 3; return s; };
+
+    build_cond_ops();
+
+    // ---- time embedding + all FiLM vectors -------------------------------------------------
+    {
+      const float* freqs = Wf("time_freqs");
+      const float* w0 = Wf("time_embed.0.weight"); const float* b0 = Wf("time_embed.0.bias");
+      const float* w2 = Wf("time_embed.2.weight"); const float* b2 = Wf("time_embed.2.bias");
+      const void* we = W_("emb_layers.weight"); const float* be = Wf("emb_layers.bias");
+      const int Bn = B, dt = dtype; const int64_t ft = film_total;
+      ops.push_back([=](hipStream_t st) {
+        int rc = launch_timestep_embedding(ptr<float>(s_t), freqs, ptr<float>(s_temb), Bn, mc / 2, st);
+        if (rc) return rc;
+        LinearSmallParams lp = {};
+        lp.x = ptr<float>(s_temb); lp.ldx = mc; lp.W = w0; lp.bias = b0; lp.out = ptr<float>(s_e1); lp.ldo = ted;
+        lp.M = Bn; lp.N = ted; lp.K = mc; lp.act_in = K22_ACT_NONE; lp.act_out = K22_ACT_SILU;
+        rc = launch_linear_smallm(lp, K22_F32, st);
+        if (rc) return rc;
+        lp.x = ptr<float>(s_e1); lp.ldx = ted; lp.W = w2; lp.bias = b2; lp.add = ptr<float>(s_xfproj); lp.ld_add = ted;
+        lp.out = ptr<float>(s_emb); lp.K = ted; lp.act_out = K22_ACT_NONE;
+        rc = launch_linear_smallm(lp, K22_F32, st);
+        if (rc) return rc;
+        LinearSmallParams le = {};
+        le.x = ptr<float>(s_emb); le.ldx = ted; le.W = we; le.bias = be; le.out = ptr<float>(s_film); le.ldo = ft;
+        le.M = Bn; le.N = (int)ft; le.K = ted; le.act_in = K22_ACT_SILU; le.act_out = K22_ACT_NONE;
+        return launch_linear_smallm(le, dt, st);
+      });
+    }
+
+    // ---- input blocks ------------------------------------------------------------------------
+    int64_t film_cursor = 0;
+    std::vector<Act> hs;
+    int ch = mc * cfg.channel_mult[0];
+    {
+      Slot* d = new_slot((size_t)B * H * W * ch * esz);
+      ConvInParams cp = {};
+      cp.w = Wf("input_blocks.0.0.weight"); cp.bias = Wf("input_blocks.0.0.bias");
+      cp.B = B; cp.H = H; cp.W = W; cp.Cin = cfg.in_channels; cp.Cout = ch;
+      const int dt = dtype; const bool inpaint = cfg.in_channels == 9;
+      ops.push_back([=](hipStream_t st) {
+        ConvInParams q = cp;
+        q.x = ptr<float>(s_xin); q.img = inpaint ? ptr<float>(s_img) : nullptr; q.mask = inpaint ? ptr<float>(s_mask) : nullptr;
+        q.out = ptr(d);
+        return launch_conv_in(q, dt, st);
+      });
+      Act a; a.s0 = d; a.C0 = ch; a.H = H; a.W = W;
+      hs.push_back(a);
+    }
+    Act h = hs.back();
+    int ds = 1, blk = 1;
+    for (int l = 0; l < cfg.n_levels; ++l) {
+      for (int i = 0; i < cfg.num_res_blocks; ++i) {
+        const int co = mc * cfg.channel_mult[l];
+        const std::string pfx = "input_blocks." + std::to_string(blk);
+        Slot* d = new_slot();
+        if (has_attn(ds)) {
+          Act r = resblock(pfx + ".0", h, co, 0, film_cursor, next_h());
+          h = attnblock(pfx + ".1", r, d);
+        } else {
+          h = resblock(pfx + ".0", h, co, 0, film_cursor, d);
+        }
+        ch = co; hs.push_back(h); ++blk;
+      }
+      if (l != cfg.n_levels - 1) {
+        const std::string pfx = "input_blocks." + std::to_string(blk);
+        Slot* d = new_slot();
+        h = resblock(pfx + ".0", h, ch, 1, film_cursor, d);
+        hs.push_back(h); ++blk; ds *= 2;
+      }
+    }
+    // ---- middle ------------------------------------------------------------------------------
+    {
+      Act r = resblock("middle_block.0", h, ch, 0, film_cursor, next_h());
+      Act a = attnblock("middle_block.1", r, next_h());
+      h = resblock("middle_block.2", a, ch, 0, film_cursor, next_h());
+    }
+    // ---- output blocks ---------------------------------------------------------------------
+    blk = 0;
+    for (int l = cfg.n_levels - 1; l >= 0; --l) {
+      for (int i = 0; i <= cfg.num_res_blocks; ++i) {
+        const Act skip = hs.back(); hs.pop_back();
+        Act cat; cat.s0 = h.s0; cat.C0 = h.C0; cat.s1 = skip.s0; cat.C1 = skip.C0; cat.H = h.H; cat.W = h.W;
+        if (skip.H != h.H || skip.W != h.W) return k22_set_error(K22_EINVAL, "unet: skip shape mismatch");
+        const int co = mc * cfg.channel_mult[l];
+        const std::string pfx = "output_blocks." + std::to_string(blk);
+        h = resblock(pfx + ".0", cat, co, 0, film_cursor, next_h());
+        int sub = 1;
+        if (has_attn(ds)) { h = attnblock(pfx + "." + std::to_string(sub), h, next_h()); ++sub; }
+        if (l && i == cfg.num_res_blocks) {
+          h = resblock(pfx + "." + std::to_string(sub), h, co, 2, film_cursor, next_h());
+          ds /= 2;
+        }
+        ch = co; ++blk;
+      }
+    }
+    if (film_cursor != film_total) return k22_set_error(K22_EINVAL, "unet: internal FiLM width mismatch");
+    // ---- out: GN + SiLU + conv3x3 -> fp32 NCHW ---------------------------------------------------
+    op_gn(ops, h, "out.0", -1, K22_ACT_SILU, 0, 1, s_P1);
+    op_conv(ops, s_P1, H, W, ch, cfg.out_channels, "out.2", nullptr, s_out, IG_OUT_NCHW_F32);
+
+    if (!err.empty()) return k22_set_error(K22_EINVAL, err.c_str());
+    // ---- lay the slots out -----------------------------------------------------------------------
+    size_t off = 0;
+    for (auto& s : slots) { s.off = off; off += (s.bytes + 255) / 256 * 256; }
+    ws_bytes = off + 256;
+    return K22_OK;
+  }
+
+  // Text2ImUNet.get_text_emb (text2im_model2_1.py:57-80), pooling_type == "from_model".
+  void build_cond_ops() {
+    const int mc = cfg.model_channels, ted = 4 * mc, Bn = B, dt = dtype;
+    const int nie = cfg.n_image_embs, cd = cfg.ctx_dim, S = cfg.ctx_len, ntext = S - nie;
+    const float* w_cs = Wf("clip_to_seq.weight"); const float* b_cs = Wf("clip_to_seq.bias");
+    const float* w_pn = Wf("proj_n.weight"); const float* b_pn = Wf("proj_n.bias");
+    const float* g_ln = Wf("ln_model_n.weight"); const float* b_ln = Wf("ln_model_n.bias");
+    const float* w_il = Wf("img_layer.weight"); const float* b_il = Wf("img_layer.bias");
+    const int d1 = cfg.text_dim1, d2 = cfg.text_dim2, di = cfg.image_dim;
+    cond_ops.push_back([=](hipStream_t st) {
+      float* clipseq = ptr<float>(s_tmpf);                  // [B][nie*cd]
+      float* proj = ptr<float>(s_tmpf) + (size_t)Bn * nie * cd;  // [B][ted]
+      LinearSmallParams lp = {};
+      lp.x = ptr<float>(s_imgemb); lp.ldx = di; lp.W = w_cs; lp.bias = b_cs; lp.out = clipseq; lp.ldo = nie * cd;
+      lp.M = Bn; lp.N = nie * cd; lp.K = di;
+      int rc = launch_linear_smallm(lp, K22_F32, st);
+      if (rc) return rc;
+      // ctx[b][0:nie] = clip_seq
+      for (int b = 0; b < Bn; ++b) {
+        rc = launch_cast_rows(clipseq + (size_t)b * nie * cd, ptr(s_ctx) + (size_t)b * S * cd * esz, nie, cd, cd, cd, dt, st);
+        if (rc) return rc;
+      }
+      // xf_proj = LN(proj_n(pooled)) + img_layer(image_emb)
+      lp.x = ptr<float>(s_pool); lp.ldx = d2; lp.W = w_pn; lp.bias = b_pn; lp.out = proj; lp.ldo = ted; lp.N = ted; lp.K = d2;
+      rc = launch_linear_smallm(lp, K22_F32, st);
+      if (rc) return rc;
+      rc = launch_layernorm_f32(proj, g_ln, b_ln, ptr<float>(s_tmpf2), Bn, ted, 1e-5f, st);
+      if (rc) return rc;
+      lp.x = ptr<float>(s_imgemb); lp.ldx = di; lp.W = w_il; lp.bias = b_il; lp.add = ptr<float>(s_tmpf2); lp.ld_add = ted;
+      lp.out = ptr<float>(s_xfproj); lp.ldo = ted; lp.N = ted; lp.K = di;
+      rc = launch_linear_smallm(lp, K22_F32, st);
+      if (rc) return rc;
+      // full_emb -> T
+      return launch_cast_rows(ptr<float>(s_full), ptr(s_fullT), Bn * ntext, d1, d1, d1, dt, st);
+    });
+    // ctx[b][nie:S] = to_model_dim_n(full_emb[b])   (one GEMM per batch element: rows re-strided)
+    {
+      IgemmParams p = {};
+      p.M = ntext; p.N = cd; p.Npad = (cd + 63) / 64 * 64; p.Kc = d1; p.K0 = d1; p.taps = 1; p.lda0 = d1; p.ldo = cd;
+      p.out_mode = IG_OUT_ROWMAJOR; p.splitk = 1;
+      p.Wp = W_("to_model_dim_n.weight"); p.bias = Wf("to_model_dim_n.bias");
+      const size_t es = esz;
+      cond_ops.push_back([=](hipStream_t st) {
+        for (int b = 0; b < Bn; ++b) {
+          IgemmParams q = p;
+          q.A0 = ptr(s_fullT) + (size_t)b * ntext * d1 * es;
+          q.out = ptr(s_ctx) + ((size_t)b * S + nie) * cd * es;
+          int rc = launch_igemm(q, dt, st);
+          if (rc) return rc;
+        }
+        return K22_OK;
+      });
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int k22_unet_create(const K22UNetConfig* cfg, const K22Weight* weights, int n_weights, K22UNet** out) {
+  if (!cfg || !out) return k22_set_error(K22_EINVAL, "unet_create: null argument");
+  if (cfg->dtype != K22_BF16 && cfg->dtype != K22_F32) return k22_set_error(K22_EINVAL, "unet_create: dtype");
+  if (cfg->num_head_channels != 64) return k22_set_error(K22_EINVAL, "unet_create: only num_head_channels == 64");
+  if (cfg->model_channels % 128) return k22_set_error(K22_EINVAL, "unet_create: model_channels % 128");
+  if (cfg->n_levels < 1 || cfg->n_levels > 8) return k22_set_error(K22_EINVAL, "unet_create: n_levels");
+  if (cfg->in_channels != 4 && cfg->in_channels != 9) return k22_set_error(K22_EINVAL, "unet_create: in_channels must be 4 or 9");
+  K22UNet* u = new K22UNet();
+  u->cfg = *cfg; u->dtype = cfg->dtype; u->esz = cfg->dtype == K22_BF16 ? 2 : 4;
+  for (int i = 0; i < n_weights; ++i) u->w[weights[i].name] = weights[i].ptr;
+  *out = u;
+  return K22_OK;
+}
+
+void k22_unet_destroy(K22UNet* u) { delete u; }
+
+int k22_unet_plan(K22UNet* u, int B, int H, int W, size_t* workspace_bytes) {
+  if (!u || !workspace_bytes) return k22_set_error(K22_EINVAL, "unet_plan: null argument");
+  int rc = u->plan(B, H, W);
+  if (rc) return rc;
+  *workspace_bytes = u->ws_bytes;
+  return K22_OK;
+}
+
+int k22_unet_bind(K22UNet* u, void* workspace, size_t workspace_bytes) {
+  if (!u || !workspace) return k22_set_error(K22_EINVAL, "unet_bind: null argument");
+  if (u->ops.empty()) return k22_set_error(K22_EINVAL, "unet_bind: plan first");
+  if (workspace_bytes < u->ws_bytes) return k22_set_error(K22_ENOMEM, "unet_bind: workspace too small");
+  if ((uintptr_t)workspace % 256) return k22_set_error(K22_EINVAL, "unet_bind: workspace must be 256-byte aligned");
+  u->ws = reinterpret_cast<char*>(workspace);
+  u->cond_set = false;
+  if (u->graph_exec) { (void)hipGraphExecDestroy(u->graph_exec); u->graph_exec = nullptr; }
+  return K22_OK;
+}
+
+int k22_unet_set_condition(K22UNet* u, const float* full_emb, const float* pooled_emb, const float* image_emb, void* stream) {
+  if (!u || !u->ws) return k22_set_error(K22_EINVAL, "unet_set_condition: bind a workspace first");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const K22UNetConfig& c = u->cfg;
+  const int ntext = c.ctx_len - c.n_image_embs;
+  hipError_t e;
+  e = hipMemcpyAsync(u->ptr(u->s_full), full_emb, (size_t)u->B * ntext * c.text_dim1 * 4, hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+  e = hipMemcpyAsync(u->ptr(u->s_pool), pooled_emb, (size_t)u->B * c.text_dim2 * 4, hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+  e = hipMemcpyAsync(u->ptr(u->s_imgemb), image_emb, (size_t)u->B * c.image_dim * 4, hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+  for (auto& op : u->cond_ops) { int rc = op(st); if (rc) return rc; }
+  u->cond_set = true;
+  return K22_OK;
+}
+
+int k22_unet_forward(K22UNet* u, const float* x, const float* timesteps, const float* inpaint_image,
+                     const float* inpaint_mask, float* out, int use_graph, void* stream) {
+  if (!u || !u->ws) return k22_set_error(K22_EINVAL, "unet_forward: bind a workspace first");
+  if (!u->cond_set) return k22_set_error(K22_EINVAL, "unet_forward: call k22_unet_set_condition first");
+  if (u->cfg.in_channels == 9 && (!inpaint_image || !inpaint_mask)) return k22_set_error(K22_EINVAL, "unet_forward: inpainting UNet needs inpaint_image and inpaint_mask");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const size_t hw = (size_t)u->H * u->W;
+  hipError_t e;
+#define K22_CPY(dst, src, bytes)                                                   \
+  e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);                \
+  if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+  K22_CPY(u->ptr(u->s_xin), x, (size_t)u->B * 4 * hw * 4);
+  K22_CPY(u->ptr(u->s_t), timesteps, (size_t)u->B * 4);
+  if (u->cfg.in_channels == 9) {
+    K22_CPY(u->ptr(u->s_img), inpaint_image, (size_t)u->B * 4 * hw * 4);
+    K22_CPY(u->ptr(u->s_mask), inpaint_mask, (size_t)u->B * hw * 4);
+  }
+  if (use_graph) {
+    if (!u->graph_exec) {
+      // warm-up eagerly once (sets function attributes), then capture
+      for (auto& op : u->ops) { int rc = op(st); if (rc) return rc; }
+      hipGraph_t g = nullptr;
+      e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+      if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+      int rc = K22_OK;
+      for (auto& op : u->ops) { rc = op(st); if (rc) break; }
+      e = hipStreamEndCapture(st, &g);
+      if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+      if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+      e = hipGraphInstantiate(&u->graph_exec, g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g);
+      if (e != hipSuccess) { u->graph_exec = nullptr; return k22_set_error_hip(e, __FILE__, __LINE__); }
+    }
+    e = hipGraphLaunch(u->graph_exec, st);
+    if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+  } else {
+    for (auto& op : u->ops) { int rc = op(st); if (rc) return rc; }
+  }
+  K22_CPY(out, u->ptr(u->s_out), (size_t)u->B * u->cfg.out_channels * hw * 4);
+#undef K22_CPY
+  return K22_OK;
+}
+
+int k22_unet_num_ops(const K22UNet* u) { return u ? (int)u->ops.size() : 0; }
+
+}  // extern "C"
