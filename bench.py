@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""bench.py — UNet denoise steps/sec of the MI355X-native Kandinsky sampling engine.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 768] [--bs 1] [--dtype bf16]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one denoise step of the reference's p_sampler on the BASELINE.json workload (configs[1]):
+Kandinsky 2.x text2img 768x768, bs=1 => one classifier-free-guided UNet forward on the CFG batch
+[2,4,96,96] (1.23 B-param Kandinsky-2.1-architecture UNet, random-init seeded weights, synthetic
+conditioning) + the fused sampler update (CFG combine, learned-range variance, dynamic-threshold
+percentile, posterior mean, ancestral noise).  Inputs are resident in HBM before the timed region.
+Multi-GPU: every rank denoises its own image (weak scaling), weights arrive by ONE RCCL broadcast of the
+packed arena before the timed region; value = images-steps per second over all ranks.
+
+Extra objects on the JSON line: "roofline" (dominant kernel = implicit-GEMM conv3x3, MFMA-bound; measured
+with HIP events around every engine op on the launch stream) and "cpu_baseline" (the CPU oracle, i.e. the
+restated reference algorithm in PyTorch fp32, timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import kandinsky2_amd as k22  # noqa: E402
+from kandinsky2_amd import _lib  # noqa: E402
+from kandinsky2_amd.parallel import broadcast_arena  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3     # fp32-input MFMA
+PEAK_HBM_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=768, help="image side in pixels (latent = size/8)")
+    ap.add_argument("--bs", type=int, default=1, help="images per GPU (CFG batch = 2*bs)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--sched-steps", type=int, default=50, help="decoder_steps of the schedule being sampled")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-size", type=int, default=0, help="image side for the CPU sample (0 = same as --size)")
+    ap.add_argument("--tiny", action="store_true", help="1/3-width UNet (debug only; not a valid bench config)")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if a.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    mcfg = k22.tiny_model_config() if a.tiny else k22.MODEL_CONFIG_2_1
+    arch = k22.make_arch(mcfg)
+    tdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    lat = a.size // 8
+    B = 2 * a.bs
+
+    # ---- weights: rank 0 draws + packs, everyone else receives the arena over RCCL -----------------
+    t0 = time.time()
+    sd = None
+    if rank == 0:
+        sd = k22.init_unet_state_dict(arch, seed=0)
+        m = k22.Text2ImUNetHIP(arch, backend_dtype=tdt, use_graph=not a.no_graph)
+        m.load_state_dict(sd)
+        m = m.to(dev)
+        m.prepare(free_params=True)
+        arena = m._arena
+    else:
+        m = k22.Text2ImUNetHIP(arch, backend_dtype=tdt, use_graph=not a.no_graph, meta_params=True)
+        arena = None
+    if world > 1:
+        arena = broadcast_arena(arena, m.arena_bytes() if rank else arena.numel(), dev, src=0)
+        if rank != 0:
+            m.prepare(arena=arena)
+    t_load = time.time() - t0
+
+    full, pooled, image = k22.make_conditioning(arch, B, seed=2 + rank)
+    kw = dict(full_emb=full.to(dev), pooled_emb=pooled.to(dev), image_emb=image.to(dev))
+    d = k22.create_gaussian_diffusion(**dict(k22.DIFFUSION_CONFIG_2_1, timestep_respacing=str(a.sched_steps)))
+    T = d.num_timesteps
+    table = torch.from_numpy(d.step_table()).to(dev)
+    ts_rows = torch.from_numpy(d.model_timesteps()).to(dev)[:, None].expand(-1, B).contiguous()
+    L = _lib.lib()
+    HW = lat * lat
+    g = torch.Generator(device="cpu").manual_seed(42 + rank)
+    x = torch.randn(B, 4, lat, lat, generator=g).to(dev)
+    x_next = torch.empty_like(x)
+    noise = torch.randn(a.steps + a.warmup + 1, B, 4, lat, lat, generator=g).to(dev)  # resident before timing
+    scratch = torch.empty(L.k22_sampler_scratch_bytes(B, HW), dtype=torch.uint8, device=dev)
+    lo, gamma = k22.percentile_index(4 * HW)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(k, x, x_next):
+        i = T - 1 - (k % T)
+        half = x[: a.bs]
+        out = m(torch.cat([half, half], 0), ts_rows[i], **kw)
+        _lib.check(L.k22_sampler_step(x.data_ptr(), out.data_ptr(), noise[k].data_ptr(), None, None, table.data_ptr(), i,
+                                      4.0, 1, -2.0, 2.0, lo, gamma, scratch.data_ptr(), x_next.data_ptr(), None, B, HW, stream))
+        return x_next, x
+
+    k = 0
+    for _ in range(a.warmup):
+        x, x_next = step(k, x, x_next)
+        k += 1
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        x, x_next = step(k, x, x_next)
+        k += 1
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = tt.item()
+    finite = bool(torch.isfinite(x).all().item())
+
+    if rank == 0:
+        prof = m.profile(reps=3)
+        conv = prof["conv3x3"]
+        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        conv_tf = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+        tot_ms = sum(v["ms"] for v in prof.values())
+        tot_fl = sum(v["flops"] for v in prof.values())
+        gn = prof["groupnorm"]
+        roofline = {
+            "kernel": "igemm_kernel (implicit-GEMM conv3x3)", "bound": "mfma",
+            "achieved": round(conv_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(conv_tf / peak, 4),
+            "traffic": None,
+            "launches_per_step": conv["launches"], "avg_launch_ms": round(conv["ms"] / max(1, conv["launches"]), 5),
+            "flops_per_step": conv["flops"],
+            "by_class_ms": {kk: round(v["ms"], 4) for kk, v in prof.items()},
+            "unet_flops_per_step": tot_fl, "unet_tflops_events": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2) if tot_ms else 0.0,
+            "groupnorm_gbs": round(gn["bytes"] / (gn["ms"] * 1e-3) / 1e9, 1) if gn["ms"] else 0.0,
+            "groupnorm_frac_hbm": round(gn["bytes"] / (gn["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if gn["ms"] else 0.0,
+        }
+        cpu = None
+        if not a.no_cpu_baseline:
+            cpu = cpu_baseline(arch, sd, a, B)
+        value = world * a.steps / el
+        line = {
+            "metric": "UNet denoise steps/sec @ 768x768 bs=1, 50 steps" if (a.size == 768 and a.bs == 1) else
+                      f"UNet denoise steps/sec @ {a.size}x{a.size} bs={a.bs}",
+            "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(el / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic (seeded random-init weights + N(0,1) conditioning/noise)",
+            "config": {"workload": f"Kandinsky-2.x text2img {a.size}x{a.size}, decoder_steps={a.sched_steps}, bs={a.bs}/GPU "
+                                   f"(CFG batch {B}x4x{lat}x{lat}), 2.1-architecture UNet ({'tiny' if a.tiny else '1.23B'}) p_sampler step",
+                       "images_per_gpu": a.bs, "parallelism": f"prompt-sharded x{world}, weights by one RCCL broadcast",
+                       "graph": not a.no_graph},
+            "images_per_sec": round(world * a.bs * a.steps / el / a.sched_steps, 4),
+            "finite": finite, "load_s": round(t_load, 1),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(arch, sd, a, B):
+    """The CPU oracle (PyTorch fp32 restatement of the reference's UNet + p_sampler step) on this box's cores."""
+    from oracle import diffusion_ref, unet_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    size = a.cpu_baseline_size or a.size
+    lat = size // 8
+    full, pooled, image = k22.make_conditioning(arch, B, seed=2)
+    g = torch.Generator().manual_seed(42)
+    x = torch.randn(B, 4, lat, lat, generator=g)
+    nz = torch.randn(B, 4, lat, lat, generator=g)
+    od = diffusion_ref.RefDiffusion(a.sched_steps)
+    i = od.T - 1
+    n = 1
+    t0 = time.perf_counter()
+    for _ in range(n):
+        half = x[: B // 2]
+        out = unet_ref.unet_forward(sd, arch, torch.cat([half, half], 0), torch.full((B,), od.model_t(i)), full, pooled, image)
+        x, _ = od.p_sample(out, x, i, nz, 4.0)
+    el = time.perf_counter() - t0
+    return {"value": round(n / el, 4), "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} denoise step (UNet fwd CFG batch {B}x4x{lat}x{lat} + p_sample) of the same workload, fp32, "
+                      f"{cores} threads, no warm-up"}
+
+
+if __name__ == "__main__":
+    main()

@@ -91,8 +91,14 @@ int k22_unet_set_condition(K22UNet* u, const float* full_emb, const float* poole
 int k22_unet_forward(K22UNet* u, const float* x, const float* timesteps, const float* inpaint_image,
                      const float* inpaint_mask, float* out, int use_graph, void* stream);
 
-/* Number of kernel launches in one planned forward (diagnostics). */
+/* Number of engine ops in one planned forward (diagnostics). */
 int k22_unet_num_ops(const K22UNet* u);
+
+/* Measurement aid for bench.py: replays the planned forward EAGERLY `reps` times on `stream` with a HIP
+ * event pair around every op, and reports per op class k (0 conv3x3, 1 GEMM, 2 GroupNorm, 3 attention,
+ * 4 other): ms[k] = average summed device time per forward, flops[k]/bytes[k] = algorithmic work per
+ * forward, launches[k] = kernel launches per forward.  Synchronises the stream (not a hot-path call). */
+int k22_unet_profile(K22UNet* u, int reps, double* ms, double* flops, double* bytes, int* launches, void* stream);
 
 /* ---- sampler step ---------------------------------------------------------------------------
  * Replaces one iteration of GaussianDiffusion.p_sample_loop_progressive

@@ -1,0 +1,16 @@
+"""kandinsky-2_amd — MI355X-native Kandinsky-2 sampling engine (import as `kandinsky2_amd`).
+
+Hot path only: the classifier-free-guided latent UNet denoise loop of Kandinsky 2.1/2.2
+as hand-written gfx950 HIP kernels behind the C ABI in include/k22.h, plus the Python mirror of the
+reference's module / sampler interface for that path.
+"""
+from .arch import MODEL_CONFIG_2_1, DIFFUSION_CONFIG_2_1, UNetArch, make_arch, param_shapes, tiny_model_config
+from .unet import Text2ImUNetHIP, create_model
+from .diffusion import SpacedDiffusionHIP, create_gaussian_diffusion, space_timesteps, percentile_index
+from .weights import init_unet_state_dict, make_conditioning
+
+__all__ = [
+    "MODEL_CONFIG_2_1", "DIFFUSION_CONFIG_2_1", "UNetArch", "make_arch", "param_shapes", "tiny_model_config",
+    "Text2ImUNetHIP", "create_model", "SpacedDiffusionHIP", "create_gaussian_diffusion", "space_timesteps",
+    "percentile_index", "init_unet_state_dict", "make_conditioning",
+]

@@ -1,0 +1,92 @@
+"""ctypes binding of libk22hip.so (the C ABI declared in include/k22.h).
+
+The product path has no CPU fallback: if the HIP library is missing or an entry point fails, these
+helpers raise.  Build the library with `python __graft_entry__.py` / `make -C kandinsky-2_amd/csrc`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libk22hip.so")
+
+K22_BF16, K22_F32 = 0, 1
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+OUT_ROWMAJOR, OUT_ROWMAJOR_F32, OUT_NCHW_F32 = 0, 1, 2
+
+
+class K22UNetConfig(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int), ("in_channels", C.c_int), ("model_channels", C.c_int), ("out_channels", C.c_int),
+        ("num_res_blocks", C.c_int), ("n_levels", C.c_int), ("channel_mult", C.c_int * 8),
+        ("n_attention_ds", C.c_int), ("attention_ds", C.c_int * 8), ("num_head_channels", C.c_int),
+        ("ctx_dim", C.c_int), ("ctx_len", C.c_int), ("n_image_embs", C.c_int), ("text_dim1", C.c_int),
+        ("text_dim2", C.c_int), ("image_dim", C.c_int),
+    ]
+
+
+class K22Weight(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("ptr", C.c_void_p)]
+
+
+_P, _I, _L, _F, _D, _Z = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); every symbol here is declared in include/k22.h
+SIGNATURES = {
+    "k22_version": (_I, []),
+    "k22_last_error": (C.c_char_p, []),
+    "k22_unet_create": (_I, [C.POINTER(K22UNetConfig), C.POINTER(K22Weight), _I, C.POINTER(_P)]),
+    "k22_unet_destroy": (None, [_P]),
+    "k22_unet_plan": (_I, [_P, _I, _I, _I, C.POINTER(_Z)]),
+    "k22_unet_bind": (_I, [_P, _P, _Z]),
+    "k22_unet_set_condition": (_I, [_P, _P, _P, _P, _P]),
+    "k22_unet_forward": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
+    "k22_unet_num_ops": (_I, [_P]),
+    "k22_unet_profile": (_I, [_P, _I, C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), C.POINTER(_I), _P]),
+    "k22_sampler_scratch_bytes": (_Z, [_I, _I]),
+    "k22_sampler_step": (_I, [_P, _P, _P, _P, _P, _P, _I, _F, _I, _F, _F, _I, _D, _P, _P, _P, _I, _I, _P]),
+    "k22_gemm": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "k22_conv3x3": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "k22_groupnorm": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _L, _F, _I, _I, _I, _P, _P, _I, _P]),
+    "k22_groupnorm_scratch_bytes": (_Z, [_I, _I]),
+    "k22_attention": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "k22_linear_smallm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is the only compute path (no CPU fallback). "
+                "Build it with `python -c 'import __graft_entry__ as g; g.build()'`.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = lib().k22_last_error()
+        raise RuntimeError(f"k22 error {rc}: {msg.decode() if msg else ''}")
+
+
+def ptr(t) -> int:
+    """data pointer of a (contiguous) torch tensor, or NULL for None."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "k22: tensors crossing the C ABI must be contiguous"
+    return t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -26,6 +26,20 @@ namespace {
 
 struct Slot { size_t bytes = 0, off = 0; };
 
+enum OpKind { OP_CONV3 = 0, OP_GEMM = 1, OP_GN = 2, OP_ATTN = 3, OP_MISC = 4, OP_NKINDS = 5 };
+
+struct Op {
+  std::function<int(hipStream_t)> fn;
+  int kind = OP_MISC;
+  double flops = 0.0;   // algorithmic FLOPs (2*M*N*K) for MFMA ops
+  double bytes = 0.0;   // algorithmic HBM bytes (read + write) for HBM-bound ops
+  int kernels = 1;      // kernel launches issued by fn
+  Op() {}
+  template <typename F> Op(F f, int k = OP_MISC, double fl = 0.0, double by = 0.0, int nk = 1) : fn(f), kind(k), flops(fl), bytes(by), kernels(nk) {}
+  int operator()(hipStream_t st) const { return fn(st); }
+};
+typedef std::vector<Op> OpList;
+
 struct Act {  // unpadded NHWC activation, optionally a virtual channel concat of two tensors
   Slot* s0 = nullptr; int C0 = 0;
   Slot* s1 = nullptr; int C1 = 0;
@@ -43,12 +57,13 @@ struct K22UNet {
   // ---- plan state ----
   int B = 0, H = 0, W = 0;
   std::deque<Slot> slots;
-  std::vector<std::function<int(hipStream_t)>> ops;       // one UNet forward
-  std::vector<std::function<int(hipStream_t)>> cond_ops;  // conditioning head
+  OpList ops;       // one UNet forward
+  OpList cond_ops;  // conditioning head
   size_t ws_bytes = 0;
   char* ws = nullptr;
   bool cond_set = false;
   hipGraphExec_t graph_exec = nullptr;
+  hipStream_t cap_stream = nullptr;  // private stream used only to CAPTURE (the caller's may be the legacy default stream)
   std::string err;
 
   // persistent slots
@@ -72,10 +87,13 @@ struct K22UNet {
   }
   const float* Wf(const std::string& name) { return reinterpret_cast<const float*>(W_(name)); }
 
-  ~K22UNet() { if (graph_exec) (void)hipGraphExecDestroy(graph_exec); }
+  ~K22UNet() {
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    if (cap_stream) (void)hipStreamDestroy(cap_stream);
+  }
 
   // ------------------------------------------------------------------------------------------
-  void op_gn(std::vector<std::function<int(hipStream_t)>>& L, const Act& in, const std::string& pfx, int64_t film_off,
+  void op_gn(OpList& L, const Act& in, const std::string& pfx, int64_t film_off,
              int act, int mode, int pad, Slot* dst) {
     const int Bn = B, C = in.C(), HW = in.H * in.W;
     const int nsplit = gn_nsplit(Bn, HW);
@@ -88,7 +106,8 @@ struct K22UNet {
     const float* beta = Wf(pfx + ".bias");
     const Act a = in;
     const int dt = dtype;
-    L.push_back([=](hipStream_t st) {
+    const double gn_bytes = (double)Bn * HW * C * esz * 2.0 + (double)Bn * (Ho + 2 * pad) * (Wo + 2 * pad) * C * esz;
+    L.push_back(Op([=](hipStream_t st) {
       GnStatsParams sp;
       sp.x0 = ptr(a.s0); sp.x1 = a.s1 ? ptr(a.s1) : nullptr; sp.C0 = a.C0; sp.C1 = a.C1;
       sp.HW = HW; sp.B = Bn; sp.groups = 32; sp.nsplit = nsplit; sp.partial = ptr<float>(s_part);
@@ -105,11 +124,11 @@ struct K22UNet {
       ap.x0 = sp.x0; ap.x1 = sp.x1; ap.C0 = a.C0; ap.C1 = a.C1; ap.B = Bn; ap.H = a.H; ap.W = a.W;
       ap.mode = mode; ap.pad = pad; ap.act = act; ap.coeff = ptr<float>(s_coeff); ap.out = ptr(dst);
       return launch_gn_apply(ap, dt, st);
-    });
+    }, OP_GN, 0.0, gn_bytes, 3));
   }
 
   // conv3x3 over a zero-bordered slot `src` [B][Hc+2][Wc+2][Cin]
-  void op_conv(std::vector<std::function<int(hipStream_t)>>& L, Slot* src, int Hc, int Wc, int Cin, int Cout,
+  void op_conv(OpList& L, Slot* src, int Hc, int Wc, int Cin, int Cout,
                const std::string& pfx, const Act* residual, Slot* dst, int out_mode) {
     IgemmParams p = {};
     p.M = B * Hc * Wc; p.N = Cout; p.Npad = (Cout + 63) / 64 * 64; p.Kc = Cin; p.K0 = Cin; p.taps = 9;
@@ -120,15 +139,15 @@ struct K22UNet {
     need(dst, out_mode == IG_OUT_ROWMAJOR ? (size_t)p.M * Cout * esz : (size_t)p.M * Cout * sizeof(float));
     Slot* rs = residual ? residual->s0 : nullptr;
     const int dt = dtype;
-    L.push_back([=](hipStream_t st) {
+    L.push_back(Op([=](hipStream_t st) {
       IgemmParams q = p;
       q.A0 = ptr(src); q.residual = rs ? ptr(rs) : nullptr; q.out = ptr(dst); q.partial = ptr<float>(s_splitk);
       return launch_igemm(q, dt, st);
-    });
+    }, OP_CONV3, 2.0 * p.M * (double)p.N * 9.0 * p.Kc, 0.0, p.splitk > 1 ? 2 : 1));
   }
 
   // GEMM over unpadded rows (1x1 conv / linear); `in` may be a virtual concat.
-  void op_gemm(std::vector<std::function<int(hipStream_t)>>& L, const Act& in, int M, int N, const std::string& pfx,
+  void op_gemm(OpList& L, const Act& in, int M, int N, const std::string& pfx,
                const Act* residual, Slot* dst, int ldo = 0) {
     IgemmParams p = {};
     p.M = M; p.N = N; p.Npad = (N + 63) / 64 * 64; p.Kc = in.C(); p.K0 = in.C0; p.taps = 1;
@@ -141,12 +160,12 @@ struct K22UNet {
     const Act a = in;
     Slot* rs = residual ? residual->s0 : nullptr;
     const int dt = dtype;
-    L.push_back([=](hipStream_t st) {
+    L.push_back(Op([=](hipStream_t st) {
       IgemmParams q = p;
       q.A0 = ptr(a.s0); q.A1 = a.s1 ? ptr(a.s1) : nullptr;
       q.residual = rs ? ptr(rs) : nullptr; q.out = ptr(dst); q.partial = ptr<float>(s_splitk);
       return launch_igemm(q, dt, st);
-    });
+    }, OP_GEMM, 2.0 * p.M * (double)p.N * p.Kc, 0.0, p.splitk > 1 ? 2 : 1));
   }
 
   // ResBlock (unet.py:110-220) with use_scale_shift_norm=True; updown: 0 none, 1 down, 2 up.
@@ -201,7 +220,7 @@ struct K22UNet {
     need(s_VT, (size_t)B * Hh * Tkp * 64 * esz);
     need(s_ATT, (size_t)B * T * C * esz);
     const int Bn = B, dt = dtype;
-    ops.push_back([=](hipStream_t st) {
+    ops.push_back(Op([=](hipStream_t st) {
       KvPackParams kp;
       kp.qkv = ptr(s_QKV); kp.ctxkv = ptr(ckv); kp.kall = ptr(s_KALL); kp.vtall = ptr(s_VT);
       kp.B = Bn; kp.H = Hh; kp.T = T; kp.S = S; kp.Tkp = Tkp;
@@ -211,7 +230,7 @@ struct K22UNet {
       ap.q = ptr(s_QKV); ap.ldq = 3 * C; ap.kall = ptr(s_KALL); ap.vtall = ptr(s_VT); ap.out = ptr(s_ATT); ap.ldo = C;
       ap.B = Bn; ap.H = Hh; ap.T = T; ap.Tk = Tk; ap.Tkp = Tkp; ap.scale = 0.125f;
       return launch_attention(ap, dt, st);
-    });
+    }, OP_ATTN, 4.0 * Bn * Hh * (double)T * Tk * 64.0, 0.0, 2));
     Act a; a.s0 = s_ATT; a.C0 = C; a.H = in.H; a.W = in.W;
     op_gemm(ops, a, B * T, C, pfx + ".proj_out", &in, dst);
     Act out; out.s0 = dst; out.C0 = C; out.H = in.H; out.W = in.W;
@@ -510,11 +529,15 @@ int k22_unet_forward(K22UNet* u, const float* x, const float* timesteps, const f
       // warm-up eagerly once (sets function attributes), then capture
       for (auto& op : u->ops) { int rc = op(st); if (rc) return rc; }
       hipGraph_t g = nullptr;
-      e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+      if (!u->cap_stream) {
+        e = hipStreamCreateWithFlags(&u->cap_stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+      }
+      e = hipStreamBeginCapture(u->cap_stream, hipStreamCaptureModeThreadLocal);
       if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
       int rc = K22_OK;
-      for (auto& op : u->ops) { rc = op(st); if (rc) break; }
-      e = hipStreamEndCapture(st, &g);
+      for (auto& op : u->ops) { rc = op(u->cap_stream); if (rc) break; }
+      e = hipStreamEndCapture(u->cap_stream, &g);
       if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
       if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
       e = hipGraphInstantiate(&u->graph_exec, g, nullptr, nullptr, 0);
@@ -532,5 +555,38 @@ int k22_unet_forward(K22UNet* u, const float* x, const float* timesteps, const f
 }
 
 int k22_unet_num_ops(const K22UNet* u) { return u ? (int)u->ops.size() : 0; }
+
+int k22_unet_profile(K22UNet* u, int reps, double* ms, double* flops, double* bytes, int* launches, void* stream) {
+  if (!u || !u->ws || !u->cond_set) return k22_set_error(K22_EINVAL, "unet_profile: run k22_unet_forward once first");
+  if (reps < 1) reps = 1;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const size_t n = u->ops.size();
+  std::vector<hipEvent_t> ev(2 * n);
+  for (auto& e : ev) { hipError_t r = hipEventCreate(&e); if (r != hipSuccess) return k22_set_error_hip(r, __FILE__, __LINE__); }
+  for (int k = 0; k < OP_NKINDS; ++k) { ms[k] = 0.0; flops[k] = 0.0; bytes[k] = 0.0; launches[k] = 0; }
+  for (size_t i = 0; i < n; ++i) {
+    flops[u->ops[i].kind] += u->ops[i].flops;
+    bytes[u->ops[i].kind] += u->ops[i].bytes;
+    launches[u->ops[i].kind] += u->ops[i].kernels;
+  }
+  int rc = K22_OK;
+  for (int r = 0; r < reps && rc == K22_OK; ++r) {
+    for (size_t i = 0; i < n; ++i) {
+      (void)hipEventRecord(ev[2 * i], st);
+      rc = u->ops[i](st);
+      (void)hipEventRecord(ev[2 * i + 1], st);
+      if (rc) break;
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { rc = k22_set_error_hip(e, __FILE__, __LINE__); break; }
+    for (size_t i = 0; i < n; ++i) {
+      float t = 0.f;
+      (void)hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]);
+      ms[u->ops[i].kind] += (double)t / reps;
+    }
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return rc;
+}
 
 }  // extern "C"

@@ -1,0 +1,237 @@
+"""Drop-in replacement of the reference's Text2ImUNet / InpaintText2ImUNet backed by the HIP engine.
+
+Same constructor hyper-parameters (through create_model), same state_dict keys and shapes (reference
+checkpoints load with load_state_dict), same call surface as the reference driver uses
+(kandinsky2/kandinsky2_1_model.py:90-104, 208-225, 246-257):
+    model(x, timesteps, full_emb=, pooled_emb=, image_emb= [, inpaint_image=, inpaint_mask=]) -> [B,8,h,w]
+    model.del_cache(), model.convert_to_fp16(), model.eval(), model.to(device), model.dtype
+Everything inside forward() runs in libk22hip.so; there is no PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .arch import UNetArch, make_arch, param_shapes
+from .pack import pack_arena
+
+
+def _register(root: nn.Module, dotted: str, param: nn.Parameter) -> None:
+    parts = dotted.split(".")
+    m = root
+    for p in parts[:-1]:
+        if p not in m._modules:
+            m.add_module(p, nn.Module())
+        m = m._modules[p]
+    m.register_parameter(parts[-1], param)
+
+
+class Text2ImUNetHIP(nn.Module):
+    """MI355X-native Text2ImUNet (kandinsky2/model/text2im_model2_1.py:13-103).
+
+    backend_dtype: torch.bfloat16 (product path, bf16 MFMA) or torch.float32 (parity path, fp32 MFMA).
+    use_graph: replay each forward as one captured hipGraph.
+    """
+
+    def __init__(self, arch: UNetArch, backend_dtype: torch.dtype = torch.bfloat16, use_graph: bool = True,
+                 cache_text_emb: bool = True, meta_params: bool = False):
+        super().__init__()
+        if backend_dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError("backend_dtype must be torch.bfloat16 or torch.float32")
+        self.arch = arch
+        self.backend_dtype = backend_dtype
+        self.use_graph = use_graph
+        self.cache_text_emb = cache_text_emb
+        self.dtype = torch.float32  # public tensors are fp32, like the reference's x / output
+        self.model_channels = arch.model_channels
+        for name, shape in param_shapes(arch).items():
+            t = torch.empty(shape, device="meta") if meta_params else torch.zeros(shape)
+            _register(self, name, nn.Parameter(t, requires_grad=False))
+        self._handle: Optional[C.c_void_p] = None
+        self._arena = None
+        self._weights_keepalive = None
+        self._ws = None
+        self._plan_key = None
+        self._cond_key = None
+        self.cache = None  # mirrors the reference attribute; holds the key of the cached conditioning
+
+    # ---- reference-compatible no-ops -------------------------------------------------------------
+    def convert_to_fp16(self):
+        """The reference casts conv weights to fp16 here (unet.py:566-572); precision of the HIP engine is
+        chosen by backend_dtype instead."""
+        return self
+
+    def convert_to_fp32(self):
+        return self
+
+    def del_cache(self):
+        self.cache = None
+        self._cond_key = None
+
+    # ---- engine management -------------------------------------------------------------------------
+    def _release(self):
+        if self._handle is not None:
+            _lib.lib().k22_unet_destroy(self._handle)
+            self._handle = None
+        self._arena = None
+        self._ws = None
+        self._plan_key = None
+        self._cond_key = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def load_state_dict(self, *args, **kwargs):
+        r = super().load_state_dict(*args, **kwargs)
+        self._release()  # weights changed: re-pack lazily
+        return r
+
+    def _apply(self, fn, *args, **kwargs):
+        r = super()._apply(fn, *args, **kwargs)
+        self._release()  # device move: re-pack lazily
+        return r
+
+    def arena_table(self):
+        """name -> (byte offset, byte size) of the packed arena, derived from shapes only."""
+        meta_sd = {k: torch.empty(v, device="meta") for k, v in param_shapes(self.arch).items()}
+        return pack_arena(self.arch, meta_sd, self.backend_dtype, "meta")[1]
+
+    def arena_bytes(self) -> int:
+        t = self.arena_table()
+        last_off, last_n = list(t.values())[-1]
+        return (last_off + (last_n + 255) // 256 * 256) + 256
+
+    def prepare(self, arena: Optional[torch.Tensor] = None, free_params: bool = False):
+        """Packs the weights (or adopts a broadcast arena) and creates the native engine."""
+        dev = arena.device if arena is not None else next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("Text2ImUNetHIP runs on the GPU only (no CPU fallback): move it with .to('cuda')")
+        L = _lib.lib()
+        self._release()
+        if arena is None:
+            arena, table = pack_arena(self.arch, self.state_dict(), self.backend_dtype, dev)
+        else:
+            table = self.arena_table()
+            if arena.numel() < self.arena_bytes() or arena.dtype != torch.uint8:
+                raise ValueError("arena does not match this architecture/dtype")
+        self._arena = arena
+        a = self.arch
+        cfg = _lib.K22UNetConfig()
+        cfg.dtype = _lib.K22_BF16 if self.backend_dtype == torch.bfloat16 else _lib.K22_F32
+        cfg.in_channels = a.in_channels
+        cfg.model_channels = a.model_channels
+        cfg.out_channels = a.out_channels
+        cfg.num_res_blocks = a.num_res_blocks
+        cfg.n_levels = len(a.channel_mult)
+        for i, v in enumerate(a.channel_mult):
+            cfg.channel_mult[i] = v
+        cfg.n_attention_ds = len(a.attention_ds)
+        for i, v in enumerate(a.attention_ds):
+            cfg.attention_ds[i] = v
+        cfg.num_head_channels = a.num_head_channels
+        cfg.ctx_dim = a.model_dim
+        cfg.ctx_len = a.ctx_len
+        cfg.n_image_embs = a.num_image_embs
+        cfg.text_dim1 = a.text_dim1
+        cfg.text_dim2 = a.text_dim2
+        cfg.image_dim = a.image_dim
+        base = arena.data_ptr()
+        arr = (_lib.K22Weight * len(table))()
+        names = []
+        for i, (name, (off, _n)) in enumerate(table.items()):
+            nb = name.encode()
+            names.append(nb)
+            arr[i].name = nb
+            arr[i].ptr = base + off
+        h = C.c_void_p()
+        _lib.check(L.k22_unet_create(C.byref(cfg), arr, len(table), C.byref(h)))
+        self._handle = h
+        if free_params:
+            for p in self.parameters():
+                p.data = torch.empty(0, device=dev)
+        self._adopted = True
+        return self
+
+    def _ensure_plan(self, B: int, H: int, W: int):
+        if self._handle is None:
+            self.prepare()
+        key = (B, H, W)
+        if self._plan_key != key:
+            L = _lib.lib()
+            nbytes = C.c_size_t()
+            _lib.check(L.k22_unet_plan(self._handle, B, H, W, C.byref(nbytes)))
+            self._ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=self._arena.device)
+            p = self._ws.data_ptr()
+            al = (p + 255) // 256 * 256
+            _lib.check(L.k22_unet_bind(self._handle, al, nbytes.value))
+            self._plan_key = key
+            self._cond_key = None
+
+    def num_ops(self) -> int:
+        return _lib.lib().k22_unet_num_ops(self._handle) if self._handle is not None else 0
+
+    def profile(self, reps: int = 3):
+        """Per-op-class device time of one forward (HIP events around every op, eager replay)."""
+        ms, fl, by = (C.c_double * 5)(), (C.c_double * 5)(), (C.c_double * 5)()
+        ln = (C.c_int * 5)()
+        _lib.check(_lib.lib().k22_unet_profile(self._handle, reps, ms, fl, by, ln, _lib.current_stream()))
+        kinds = ["conv3x3", "gemm", "groupnorm", "attention", "other"]
+        return {k: dict(ms=ms[i], flops=fl[i], bytes=by[i], launches=ln[i]) for i, k in enumerate(kinds)}
+
+    def workspace_bytes(self) -> int:
+        return 0 if self._ws is None else self._ws.numel()
+
+    def set_condition(self, full_emb, pooled_emb, image_emb):
+        """Text2ImUNet.get_text_emb (text2im_model2_1.py:57-80) + hoisted encoder_kv projections."""
+        L = _lib.lib()
+        f = full_emb.detach().float().contiguous()
+        p = pooled_emb.detach().float().contiguous()
+        i = image_emb.detach().float().contiguous()
+        _lib.check(L.k22_unet_set_condition(self._handle, f.data_ptr(), p.data_ptr(), i.data_ptr(), _lib.current_stream()))
+        return self
+
+    @torch.no_grad()
+    def forward(self, x, timesteps, full_emb=None, pooled_emb=None, image_emb=None, inpaint_image=None, inpaint_mask=None):
+        if x.device.type != "cuda":
+            raise RuntimeError("Text2ImUNetHIP.forward: input must be on the GPU (no CPU fallback)")
+        B, Cx, H, W = x.shape
+        if Cx != 4:
+            raise ValueError("expected a 4-channel latent")
+        self._ensure_plan(B, H, W)
+        # the reference caches the conditioning after the first call until del_cache() (text2im_model2_1.py:58-59, 82-83)
+        if self._cond_key is None or not self.cache_text_emb:
+            if full_emb is None or pooled_emb is None or image_emb is None:
+                raise ValueError("full_emb, pooled_emb and image_emb are required")
+            self.set_condition(full_emb, pooled_emb, image_emb)
+            self._cond_key = True
+            self.cache = {"cached": True}
+        xf = x.detach().float().contiguous()
+        tf = timesteps.detach().float().contiguous()
+        img = msk = None
+        if self.arch.inpainting:
+            # InpaintText2ImUNet.forward defaults (text2im_model2_1.py:146-150)
+            img = torch.zeros_like(xf) if inpaint_image is None else inpaint_image.detach().float().contiguous()
+            msk = torch.zeros_like(xf[:, :1]) if inpaint_mask is None else inpaint_mask.detach().float().contiguous()
+        out = torch.empty(B, self.arch.out_channels, H, W, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().k22_unet_forward(
+            self._handle, xf.data_ptr(), tf.data_ptr(), _lib.ptr(img), _lib.ptr(msk), out.data_ptr(),
+            1 if self.use_graph else 0, _lib.current_stream()))
+        return out
+
+
+def create_model(backend_dtype: torch.dtype = torch.bfloat16, use_graph: bool = True, inpainting: bool = False,
+                 up: bool = False, **model_config) -> Text2ImUNetHIP:
+    """Same keyword schema as the reference's create_model (kandinsky2/model/model_creation.py:9-83);
+    version must be "2.1"."""
+    if model_config.get("version", "2.1") != "2.1":
+        raise NotImplementedError("only the 2.1 UNet is implemented")
+    arch = make_arch(model_config, inpainting=inpainting)
+    return Text2ImUNetHIP(arch, backend_dtype=backend_dtype, use_graph=use_graph,
+                          cache_text_emb=model_config.get("cache_text_emb", True))

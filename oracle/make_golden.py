@@ -1,0 +1,163 @@
+"""Generates tests/golden/* by running the REFERENCE's own modules (imported from /root/reference) on
+seeded weights/inputs, and checks the oracle restatement against them.  Build-container only.
+
+    python oracle/make_golden.py            # tiny + table fixtures (about a minute)
+    python oracle/make_golden.py --full     # also the full-size (1.23 B param) C1 fixtures (minutes, ~12 GB RAM)
+
+Fixtures hold seeds + expected outputs only; the weights are re-drawn from kandinsky2_amd.weights
+(deterministic CPU generator), so the files stay small.
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import kandinsky2_amd as k22  # noqa: E402
+from oracle import diffusion_ref, ref_loader, unet_ref  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def ref_model(model_config, inpainting):
+    mc = ref_loader.ref("model.model_creation")
+    cfg = dict(copy.deepcopy(model_config), up=False, inpainting=inpainting, use_fp16=False)
+    return mc.create_model(**cfg).eval()
+
+
+def ref_diffusion(num_steps):
+    mc = ref_loader.ref("model.model_creation")
+    return mc.create_gaussian_diffusion(**dict(k22.DIFFUSION_CONFIG_2_1, timestep_respacing=str(num_steps)))
+
+
+def inputs(arch, B, h, w, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 4, h, w, generator=g)
+    img = torch.randn(B, 4, h, w, generator=g)
+    mask = (torch.rand(B, 1, h, w, generator=g) > 0.5).float()
+    return x, img, mask
+
+
+def ref_p_sample_loop(model, diffusion, x_T, noise_seq, kwargs, guidance, init_img=None, img_mask=None):
+    """Kandinsky2_1.generate_img's p_sampler branch (kandinsky2_1_model.py:222-257), with the per-step
+    th.randn_like replaced by the injected noise sequence."""
+    gd = ref_loader.ref("model.gaussian_diffusion")
+
+    def model_fn(x_t, ts, **kw):  # verbatim logic of kandinsky2_1_model.py:222-233, sampler == 'p_sampler'
+        half = x_t[: len(x_t) // 2]
+        combined = torch.cat([half, half], dim=0)
+        model_out = model(combined, ts, **kw)
+        eps, rest = model_out[:, :4], model_out[:, 4:]
+        cond_eps, uncond_eps = torch.split(eps, len(eps) // 2, dim=0)
+        half_eps = uncond_eps + guidance * (cond_eps - uncond_eps)
+        eps = torch.cat([half_eps, half_eps], dim=0)
+        return torch.cat([eps, rest], dim=1)
+
+    if img_mask is not None:
+        def denoised_fun(x_start):
+            x_start = x_start.clamp(-2, 2)
+            return x_start * (1 - img_mask) + init_img * img_mask
+    else:
+        def denoised_fun(x):
+            return x.clamp(-2, 2)
+
+    it = iter(noise_seq)
+    orig = gd.th.randn_like
+    gd.th.randn_like = lambda t: next(it).to(t)
+    try:
+        model.del_cache()
+        out = diffusion.p_sample_loop(model_fn, tuple(x_T.shape), device="cpu", noise=x_T.clone(), progress=False,
+                                      model_kwargs=kwargs, init_step=None, denoised_fn=denoised_fun)
+        model.del_cache()
+    finally:
+        gd.th.randn_like = orig
+    return out
+
+
+def run_case(name, model_config, inpainting, B, h, w, steps, guidance=4.0, seed_w=0):
+    arch = k22.make_arch(model_config, inpainting=inpainting)
+    sd = k22.init_unet_state_dict(arch, seed=seed_w)
+    model = ref_model(model_config, inpainting)
+    missing = model.load_state_dict(sd, strict=True)
+    print(name, "load_state_dict:", missing)
+    full, pooled, image = k22.make_conditioning(arch, B, seed=2)
+    x, img, mask = inputs(arch, B, h, w)
+    t = torch.tensor([37.0, 999.0] * (B // 2))
+    kw = dict(full_emb=full, pooled_emb=pooled, image_emb=image)
+    if inpainting:
+        kw.update(inpaint_image=img * mask, inpaint_mask=mask)
+    with torch.no_grad():
+        model.del_cache()
+        ref_out = model(x, t, **kw)
+        model.del_cache()
+    ora = unet_ref.unet_forward(sd, arch, x, t, full, pooled, image, kw.get("inpaint_image"), kw.get("inpaint_mask"))
+    print(f"  forward: ref absmax {ref_out.abs().max():.4f} std {ref_out.std():.4f}  oracle-vs-ref max|d| {(ora - ref_out).abs().max():.3e}")
+    assert (ora - ref_out).abs().max() < 2e-4 * max(1.0, ref_out.abs().max().item())
+    fix = dict(name=name, model_config=model_config, inpainting=inpainting, B=B, h=h, w=w, steps=steps, guidance=guidance,
+               seed_w=seed_w, t=t, forward_out=ref_out.clone())
+    if steps:
+        g = torch.Generator().manual_seed(42)
+        x_T = torch.randn(B, 4, h, w, generator=g)
+        noise_seq = torch.randn(steps, B, 4, h, w, generator=g)
+        diff = ref_diffusion(steps)
+        kw2 = dict(full_emb=full, pooled_emb=pooled, image_emb=image)
+        ii = mm = None
+        if inpainting:
+            ii, mm = img, mask
+            kw2.update(inpaint_image=img * mask, inpaint_mask=mask)
+        ref_final = ref_p_sample_loop(model, diff, x_T, list(noise_seq), kw2, guidance, ii, mm)
+        od = diffusion_ref.RefDiffusion(steps)
+        ora_final = od.p_sample_loop(
+            lambda xc, tt: unet_ref.unet_forward(sd, arch, xc, tt, full, pooled, image, kw2.get("inpaint_image"), kw2.get("inpaint_mask")),
+            x_T, noise_seq, guidance, ii, mm)
+        d = (ora_final - ref_final).abs().max().item()
+        print(f"  {steps}-step p_sampler: ref absmax {ref_final.abs().max():.4f}  oracle-vs-ref max|d| {d:.3e}")
+        assert d < 1e-3
+        fix.update(final=ref_final.clone())
+    torch.save(fix, os.path.join(GOLD, name + ".pt"))
+
+
+def table_fixtures():
+    out = {}
+    for steps in (10, 50, 100):
+        d = ref_diffusion(steps)
+        out[str(steps)] = dict(
+            timestep_map=list(map(int, d.timestep_map)),
+            betas=d.betas.tolist(),
+            sqrt_recip_alphas_cumprod=d.sqrt_recip_alphas_cumprod.tolist(),
+            sqrt_recipm1_alphas_cumprod=d.sqrt_recipm1_alphas_cumprod.tolist(),
+            posterior_log_variance_clipped=d.posterior_log_variance_clipped.tolist(),
+            posterior_mean_coef1=d.posterior_mean_coef1.tolist(),
+            posterior_mean_coef2=d.posterior_mean_coef2.tolist(),
+        )
+    with open(os.path.join(GOLD, "ref_diffusion_tables.json"), "w") as f:
+        json.dump(out, f)
+    keys = {}
+    for nm, inp in (("text2img", False), ("inpainting", True)):
+        cfg = dict(copy.deepcopy(k22.MODEL_CONFIG_2_1), up=False, inpainting=inp, use_fp16=False)
+        with torch.device("meta"):
+            m = ref_loader.ref("model.model_creation").create_model(**cfg)
+        keys[nm] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    with open(os.path.join(GOLD, "ref_unet_keys.json"), "w") as f:
+        json.dump(keys, f)
+    print("tables + keys written;", len(keys["text2img"]), "keys")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true")
+    a = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.manual_seed(0)
+    table_fixtures()
+    tiny = k22.tiny_model_config()
+    run_case("tiny_text2img", tiny, False, B=2, h=16, w=16, steps=6)
+    run_case("tiny_inpaint", tiny, True, B=4, h=16, w=24, steps=4)
+    if a.full:
+        run_case("full_c1_text2img", k22.MODEL_CONFIG_2_1, False, B=2, h=32, w=32, steps=10)

@@ -1,0 +1,144 @@
+"""CPU suite (-m "not gpu"): oracle vs golden fixtures made from the reference, host-side logic of the
+product (architecture walk, schedule tables, percentile index), and the C-ABI library surface."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import kandinsky2_amd as k22
+from kandinsky2_amd import _lib
+from oracle import diffusion_ref, unet_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(golden_dir, name):
+    return torch.load(os.path.join(golden_dir, name + ".pt"), weights_only=False)
+
+
+@pytest.mark.parametrize("name", ["tiny_text2img", "tiny_inpaint"])
+def test_oracle_forward_matches_reference_golden(golden_dir, name):
+    fx = _load(golden_dir, name)
+    arch = k22.make_arch(fx["model_config"], inpainting=fx["inpainting"])
+    sd = k22.init_unet_state_dict(arch, seed=fx["seed_w"])
+    full, pooled, image = k22.make_conditioning(arch, fx["B"], seed=2)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(fx["B"], 4, fx["h"], fx["w"], generator=g)
+    img = torch.randn(fx["B"], 4, fx["h"], fx["w"], generator=g)
+    mask = (torch.rand(fx["B"], 1, fx["h"], fx["w"], generator=g) > 0.5).float()
+    ii, mm = (img * mask, mask) if fx["inpainting"] else (None, None)
+    out = unet_ref.unet_forward(sd, arch, x, fx["t"], full, pooled, image, ii, mm)
+    assert out.abs().max() > 0.1  # not the vacuous all-zero output of zero_module()
+    assert (out - fx["forward_out"]).abs().max().item() <= 1e-5
+
+
+def test_oracle_sampler_loop_matches_reference_golden(golden_dir):
+    fx = _load(golden_dir, "tiny_text2img")
+    arch = k22.make_arch(fx["model_config"])
+    sd = k22.init_unet_state_dict(arch, seed=fx["seed_w"])
+    full, pooled, image = k22.make_conditioning(arch, fx["B"], seed=2)
+    g = torch.Generator().manual_seed(42)
+    x_T = torch.randn(fx["B"], 4, fx["h"], fx["w"], generator=g)
+    noise_seq = torch.randn(fx["steps"], fx["B"], 4, fx["h"], fx["w"], generator=g)
+    od = diffusion_ref.RefDiffusion(fx["steps"])
+    final = od.p_sample_loop(lambda xc, tt: unet_ref.unet_forward(sd, arch, xc, tt, full, pooled, image), x_T, noise_seq, fx["guidance"])
+    assert (final - fx["final"]).abs().max().item() <= 1e-4
+
+
+def test_param_shapes_equal_reference_state_dict(golden_dir):
+    with open(os.path.join(golden_dir, "ref_unet_keys.json")) as f:
+        keys = json.load(f)
+    for nm, inp in (("text2img", False), ("inpainting", True)):
+        mine = {k: list(v) for k, v in k22.param_shapes(k22.make_arch(k22.MODEL_CONFIG_2_1, inpainting=inp)).items()}
+        assert mine == keys[nm]
+
+
+@pytest.mark.parametrize("steps", [10, 50, 100])
+def test_schedule_tables_equal_reference(golden_dir, steps):
+    with open(os.path.join(golden_dir, "ref_diffusion_tables.json")) as f:
+        ref = json.load(f)[str(steps)]
+    d = k22.create_gaussian_diffusion(**dict(k22.DIFFUSION_CONFIG_2_1, timestep_respacing=str(steps)))
+    o = diffusion_ref.RefDiffusion(steps)
+    assert d.timestep_map == ref["timestep_map"] == o.timestep_map
+    for mine, theirs, key in [
+        (d.betas, o.betas, "betas"),
+        (d.sqrt_recip_alphas_cumprod, o.sqrt_recip, "sqrt_recip_alphas_cumprod"),
+        (d.sqrt_recipm1_alphas_cumprod, o.sqrt_recipm1, "sqrt_recipm1_alphas_cumprod"),
+        (d.posterior_log_variance_clipped, o.post_logvar, "posterior_log_variance_clipped"),
+        (d.posterior_mean_coef1, o.c1, "posterior_mean_coef1"),
+        (d.posterior_mean_coef2, o.c2, "posterior_mean_coef2"),
+    ]:
+        assert np.array_equal(mine, np.array(ref[key])), key   # bit-exact fp64
+        assert np.array_equal(theirs, np.array(ref[key])), key
+    tab = d.step_table()
+    assert tab.shape == (steps, 8) and tab[0, 6] == 0 and (tab[1:, 6] == 1).all()
+    assert np.array_equal(tab[:, 7], np.array([o.model_t(i) for i in range(steps)], dtype=np.float32))
+
+
+def test_space_timesteps_ddim_and_sections():
+    assert k22.space_timesteps(1000, "10") == [0, 111, 222, 333, 444, 555, 666, 777, 888, 999]
+    assert k22.space_timesteps(300, [10, 15, 20])[:3] == [0, 11, 22]
+    assert k22.space_timesteps(1000, "ddim50")[:3] == [1, 21, 41]
+    with pytest.raises(ValueError):
+        k22.space_timesteps(10, "20")
+
+
+@pytest.mark.parametrize("n", [4 * 8 * 8, 4 * 16 * 16, 4 * 32 * 32, 4 * 96 * 96, 4 * 128 * 128, 7, 1])
+def test_percentile_index_reproduces_numpy(n):
+    rng = np.random.default_rng(n)
+    a = np.abs(rng.standard_normal(n).astype(np.float32))
+    lo, gamma = k22.percentile_index(n)
+    s = np.sort(a)
+    hi = min(lo + 1, n - 1)
+    d = np.float32(s[hi] - s[lo])
+    t = np.float32(gamma)
+    r = np.float32(s[lo] + np.float32(d * t))
+    if t >= 0.5:
+        r = np.float32(s[hi] - np.float32(d * np.float32(np.float32(1) - t)))
+    assert r == np.percentile(a, 99.5)
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "k22.h")).read()
+    declared = set(re.findall(r"\b(k22_[a-z0-9_]+)\s*\(", hdr))
+    declared.discard("k22_sampler_table_columns")
+    assert declared, "no declarations parsed"
+    assert os.path.exists(_lib.LIB_PATH), "libk22hip.so not built: run __graft_entry__.build()"
+    L = _lib.lib()
+    for sym in sorted(declared):
+        assert hasattr(L, sym), sym
+        assert sym in _lib.SIGNATURES, f"{sym} has no ctypes signature"
+    assert L.k22_version() >= 100
+
+
+def test_product_fails_loudly_without_gpu():
+    arch = k22.make_arch(k22.tiny_model_config())
+    m = k22.Text2ImUNetHIP(arch)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(2, 4, 8, 8), torch.zeros(2), full_emb=torch.zeros(2, 77, 1024), pooled_emb=torch.zeros(2, 768),
+          image_emb=torch.zeros(2, 768))
+
+
+def test_pack_layouts():
+    from kandinsky2_amd.pack import pack_arena, packed_entries
+    arch = k22.make_arch(k22.tiny_model_config())
+    sd = k22.init_unet_state_dict(arch, seed=1)
+    ent = packed_entries(arch, sd, torch.float32, "cpu")
+    w = sd["input_blocks.1.0.in_layers.2.weight"]
+    p = ent["input_blocks.1.0.in_layers.2.weight"]
+    assert p.shape == (128, 9 * 128)
+    assert torch.equal(p[5].view(3, 3, 128)[1, 2], w[5, :, 1, 2])
+    # qkv rows: head*192 + part*64 + d  ->  part*C + head*64 + d
+    pfx = "input_blocks.5.1"
+    wq, pq = sd[pfx + ".qkv.weight"][:, :, 0], ent[pfx + ".qkv.weight"]
+    C = wq.shape[1]
+    assert torch.equal(pq[1 * C + 2 * 64 + 7], wq[2 * 192 + 1 * 64 + 7])
+    tot = sum(2 * b[3] for b in arch.blocks if b[0] == "res")
+    assert ent["emb_layers.weight"].shape == (tot, arch.time_embed_dim)
+    arena, table = pack_arena(arch, sd, torch.bfloat16, "cpu")
+    meta = {k: torch.empty(v, device="meta") for k, v in k22.param_shapes(arch).items()}
+    _, table2 = pack_arena(arch, meta, torch.bfloat16, "meta")
+    assert table == table2 and all(o % 256 == 0 for o, _ in table.values())

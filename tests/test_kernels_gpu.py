@@ -1,0 +1,154 @@
+"""GPU parity of the individual HIP kernels, called through the C ABI, against plain PyTorch fp32
+references of the same floating-point op on the same (dtype-rounded) operands.
+
+Tolerances: bf16 path = inputs identical (pre-rounded), fp32 accumulation, one bf16 output rounding
+(2^-8 relative) -> rtol 1e-2 / atol 1e-2*scale; fp32 path (exact-fp32 MFMA) -> 2e-4 relative to the output
+scale (accumulation order differs from rocBLAS/MIOpen).
+"""
+import numpy as np
+import pytest
+import torch
+
+import helpers as hp
+from kandinsky2_amd import _lib
+from oracle import diffusion_ref
+import kandinsky2_amd as k22
+
+pytestmark = pytest.mark.gpu
+DT = [_lib.K22_BF16, _lib.K22_F32]
+
+
+def close(out, ref, dtype, what=""):
+    scale = ref.abs().max().item() + 1e-6
+    err = (out - ref).abs().max().item()
+    tol = (1.2e-2 if dtype == _lib.K22_BF16 else 2e-4) * scale
+    assert np.isfinite(err) and err <= tol, f"{what}: max|d|={err:.4e} tol={tol:.4e} scale={scale:.3f}"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K,bm,bn,splitk", [
+    (256, 256, 128, 128, 128, 1), (300, 192, 192, 128, 64, 1), (77, 768, 1024, 64, 64, 1), (128, 128, 64, 64, 128, 1),
+    (512, 384, 256, 256, 128, 1), (288, 320, 1152, 128, 64, 4), (2, 1536, 384, 64, 64, 2), (1000, 8, 384, 128, 64, 1),
+    (333, 200, 320, 0, 0, 0),
+])
+def test_gemm(dtype, M, N, K, bm, bn, splitk):
+    A, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    out, a, w, r = hp.gemm(A, W, bias, res, dtype=dtype, splitk=splitk, bm=bm, bn=bn)
+    close(out, a @ w.T + bias + r, dtype, f"gemm {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_virtual_concat_and_f32_out(dtype):
+    A0, A1, W = rnd(200, 128, seed=1), rnd(200, 192, seed=2), rnd(256, 320, seed=3, scale=0.05)
+    out, a, w, _ = hp.gemm(A0, W, A1=A1, dtype=dtype, out_f32=True)
+    scale = (a @ w.T).abs().max().item()
+    assert (out - a @ w.T).abs().max().item() <= 2e-4 * scale  # fp32 store: no output rounding in either dtype
+
+
+def test_gemm_asymmetric_layout():
+    """A = I (padded) with an asymmetric W detects any row/column transposition of the MFMA output map."""
+    K = 128
+    A = torch.eye(K).cuda()
+    W = (torch.arange(64 * K, dtype=torch.float32).reshape(64, K) % 251 - 125).cuda() / 16
+    out, a, w, _ = hp.gemm(A, W, dtype=_lib.K22_F32)
+    assert torch.equal(out, w.T.contiguous())
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,Cin,Cout,H,W,bm,bn,splitk", [
+    (2, 128, 128, 16, 16, 128, 128, 1), (1, 64, 192, 9, 13, 128, 64, 1), (2, 256, 128, 8, 8, 64, 64, 3),
+    (2, 128, 8, 12, 12, 128, 64, 1), (3, 192, 256, 6, 10, 0, 0, 0), (2, 384, 384, 24, 24, 0, 0, 0),
+])
+def test_conv3x3(dtype, B, Cin, Cout, H, W, bm, bn, splitk):
+    x, w = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
+    bias, res = rnd(Cout, seed=3), rnd(B, Cout, H, W, seed=4)
+    out, ref = hp.conv3x3(x, w, bias, res, dtype=dtype, splitk=splitk, bm=bm, bn=bn)
+    close(out, ref, dtype, f"conv {B}x{Cin}->{Cout}@{H}x{W}")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_conv3x3_nchw_f32_output(dtype):
+    x, w, bias = rnd(2, 128, 16, 16, seed=1), rnd(8, 128, 3, 3, seed=2, scale=0.03), rnd(8, seed=3)
+    out, ref = hp.conv3x3(x, w, bias, None, dtype=dtype, out_mode=_lib.OUT_NCHW_F32)
+    scale = ref.abs().max().item()
+    assert (out - ref).abs().max().item() <= 2e-4 * scale
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("C0,C1,H,W,act,mode,pad,film", [
+    (128, 0, 16, 16, 1, 0, 1, False), (256, 128, 8, 8, 1, 0, 1, False), (384, 0, 12, 12, 1, 0, 1, True),
+    (128, 0, 16, 16, 1, 1, 1, False), (128, 0, 8, 8, 1, 2, 1, False), (512, 0, 6, 6, 0, 0, 0, False),
+    (1536, 1536, 4, 4, 1, 0, 1, True), (384, 0, 96, 96, 1, 0, 1, False),
+])
+def test_groupnorm(dtype, C0, C1, H, W, act, mode, pad, film):
+    B, C = 2, C0 + C1
+    x0 = rnd(B, C0, H, W, seed=1) * 1.7 + 0.3
+    x1 = (rnd(B, C1, H, W, seed=2) * 0.6 - 0.2) if C1 else None
+    gamma, beta = 1 + 0.1 * rnd(C, seed=3), 0.1 * rnd(C, seed=4)
+    fl = 0.3 * rnd(B, 2 * C + 64, seed=5) if film else None
+    out, ref = hp.groupnorm(x0, gamma, beta, x1, None if fl is None else fl[:, : 2 * C].contiguous(), act, mode, pad, dtype)
+    close(out, ref, dtype, "groupnorm")
+    if pad:
+        assert (out[:, :, 0] == 0).all() and (out[:, :, -1] == 0).all() and (out[..., 0] == 0).all() and (out[..., -1] == 0).all()
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,H,T,S", [(2, 2, 64, 87), (1, 3, 144, 87), (2, 4, 576, 87), (2, 1, 100, 5), (1, 12, 2304, 87)])
+def test_attention(dtype, B, H, T, S):
+    C = 64 * H
+    qkv, ctx = rnd(B * T, 3 * C, seed=1) * 1.5, rnd(B * S, 2 * C, seed=2) * 1.5
+    out, ref = hp.attention(qkv, ctx, B, H, T, S, dtype)
+    close(out, ref, dtype, f"attention B{B} H{H} T{T}")
+
+
+def test_attention_online_softmax_rescale_branch():
+    """A late key with a huge logit forces the running-max rescale of already accumulated tiles (fp64 ref)."""
+    B, H, T, S = 1, 1, 200, 87
+    qkv, ctx = rnd(B * T, 192, seed=1), rnd(B * S, 128, seed=2)
+    qkv[180, 64:128] = qkv[3, 0:64] * 40.0  # key 180 (3rd tile incl. ctx) spikes against query 3
+    out, _ = hp.attention(qkv, ctx, B, H, T, S, _lib.K22_F32)
+    q = qkv[:, :64].double(); k = torch.cat([ctx[:, :64], qkv[:, 64:128]]).double(); v = torch.cat([ctx[:, 64:], qkv[:, 128:]]).double()
+    ref = torch.softmax(q @ k.T * 0.125, -1) @ v
+    assert (out.double() - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("wdtype", DT)
+def test_linear_smallm(wdtype):
+    M, N, K = 4, 1000, 1536
+    x, W, b, add = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
+    Wt = W.to(hp.tdt(wdtype)).contiguous()
+    out = torch.empty(M, N, device="cuda")
+    _lib.check(_lib.lib().k22_linear_smallm(x.data_ptr(), Wt.data_ptr(), b.data_ptr(), add.data_ptr(), out.data_ptr(),
+                                            M, N, K, 1, 0, wdtype, hp.stream()))
+    ref = torch.nn.functional.silu(x) @ Wt.float().T + b + add
+    assert (out - ref).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("N,H,W,inpaint,step", [(2, 16, 16, False, 3), (4, 8, 12, True, 0), (2, 96, 96, False, 49), (8, 32, 32, True, 7)])
+def test_sampler_step_matches_oracle(N, H, W, inpaint, step):
+    steps = 50
+    d = k22.create_gaussian_diffusion(**dict(k22.DIFFUSION_CONFIG_2_1, timestep_respacing=str(steps)))
+    od = diffusion_ref.RefDiffusion(steps)
+    g = torch.Generator().manual_seed(step)
+    x, mo, nz = torch.randn(N, 4, H, W, generator=g), torch.randn(N, 8, H, W, generator=g), torch.randn(N, 4, H, W, generator=g)
+    init = torch.randn(N, 4, H, W, generator=g) if inpaint else None
+    mask = (torch.rand(N, 1, H, W, generator=g) > 0.5).float() if inpaint else None
+    ref, ref_x0 = od.p_sample(mo, x, step, nz, 4.0, init, mask)
+    L = _lib.lib()
+    table = torch.from_numpy(d.step_table()).cuda()
+    scratch = torch.empty(L.k22_sampler_scratch_bytes(N, H * W), dtype=torch.uint8, device="cuda")
+    lo, gamma = k22.percentile_index(4 * H * W)
+    xo, x0o = torch.empty(N, 4, H, W, device="cuda"), torch.empty(N, 4, H, W, device="cuda")
+    xc, moc, nzc = x.cuda(), mo.cuda(), nz.cuda()
+    ic, mc = (init.cuda(), mask.cuda()) if inpaint else (None, None)
+    _lib.check(L.k22_sampler_step(xc.data_ptr(), moc.data_ptr(), nzc.data_ptr(), _lib.ptr(ic), _lib.ptr(mc), table.data_ptr(),
+                                  step, 4.0, 1, -2.0, 2.0, lo, gamma, scratch.data_ptr(), xo.data_ptr(), x0o.data_ptr(),
+                                  N, H * W, hp.stream()))
+    assert (x0o.cpu() - ref_x0).abs().max().item() <= 2e-6
+    assert (xo.cpu() - ref).abs().max().item() <= 1e-5
