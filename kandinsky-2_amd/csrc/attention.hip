@@ -17,9 +17,10 @@
 // V^T fragment whose K (= key) order matches the S^T accumulator registers:
 // element j<4 -> key 16a + 4h + j ; j>=4 -> key 16a + 8 + 4h + (j-4).
 __device__ __forceinline__ void ld_frag_split(Frag<bf16_t>& f, const char* tile, int r, int a, int h) {
-  const uint2 lo = *reinterpret_cast<const uint2*>(tile + lds_chunk_off(r, 2 * a) + 8 * h);
-  const uint2 hi = *reinterpret_cast<const uint2*>(tile + lds_chunk_off(r, 2 * a + 1) + 8 * h);
-  f.v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+  const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(tile + lds_chunk_off(r, 2 * a) + 8 * h);
+  const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(tile + lds_chunk_off(r, 2 * a + 1) + 8 * h);
+  f.v = u32x4_t{lo.x, lo.y, hi.x, hi.y};
 }
 __device__ __forceinline__ void ld_frag_split(Frag<float>& f, const char* tile, int r, int a, int h) {
   const char* sub = tile + (a >> 1) * 8192;
@@ -30,16 +31,16 @@ __device__ __forceinline__ void ld_frag_split(Frag<float>& f, const char* tile, 
   f.v[4] = hi.x; f.v[5] = hi.y; f.v[6] = hi.z; f.v[7] = hi.w;
 }
 __device__ __forceinline__ void make_pfrag(Frag<bf16_t>& f, const float* p) {
-  f.v.x = (uint32_t)f32_to_bf16(p[0]) | ((uint32_t)f32_to_bf16(p[1]) << 16);
-  f.v.y = (uint32_t)f32_to_bf16(p[2]) | ((uint32_t)f32_to_bf16(p[3]) << 16);
-  f.v.z = (uint32_t)f32_to_bf16(p[4]) | ((uint32_t)f32_to_bf16(p[5]) << 16);
-  f.v.w = (uint32_t)f32_to_bf16(p[6]) | ((uint32_t)f32_to_bf16(p[7]) << 16);
+  f.v = u32x4_t{(uint32_t)f32_to_bf16(p[0]) | ((uint32_t)f32_to_bf16(p[1]) << 16),
+                (uint32_t)f32_to_bf16(p[2]) | ((uint32_t)f32_to_bf16(p[3]) << 16),
+                (uint32_t)f32_to_bf16(p[4]) | ((uint32_t)f32_to_bf16(p[5]) << 16),
+                (uint32_t)f32_to_bf16(p[6]) | ((uint32_t)f32_to_bf16(p[7]) << 16)};
 }
 __device__ __forceinline__ void make_pfrag(Frag<float>& f, const float* p) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) f.v[j] = p[j];
 }
-__device__ __forceinline__ void ld_qfrag(Frag<bf16_t>& f, const bf16_t* p) { f.v = *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void ld_qfrag(Frag<bf16_t>& f, const bf16_t* p) { f.v = *reinterpret_cast<const u32x4_t*>(p); }
 __device__ __forceinline__ void ld_qfrag(Frag<float>& f, const float* p) {
   const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
   f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
@@ -75,36 +76,38 @@ __global__ __launch_bounds__(256) void attention_kernel(AttentionParams p) {
   const T* Vg = reinterpret_cast<const T*>(p.vtall) + (int64_t)(b * p.H + hd) * 64 * p.Tkp;
   const int nkt = (p.Tk + 63) / 64;
 
-  uint4 kreg[LCH], vreg[LCH];
-  auto gload = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < LCH; ++i) {
-      const int q = tid + i * 256, row = q / CPR, cc = q - row * CPR;
-      kreg[i] = *reinterpret_cast<const uint4*>(Kg + (int64_t)(kt * 64 + row) * 64 + cc * EPC);
-      vreg[i] = *reinterpret_cast<const uint4*>(Vg + (int64_t)row * p.Tkp + kt * 64 + cc * EPC);
-    }
-  };
-  auto lstore = [&]() {
-#pragma unroll
-    for (int i = 0; i < LCH; ++i) {
-      const int q = tid + i * 256, row = q / CPR, cc = q - row * CPR;
-      const int off = (cc >> 3) * 8192 + lds_chunk_off(row, cc & 7);
-      *reinterpret_cast<uint4*>(Ks + off) = kreg[i];
-      *reinterpret_cast<uint4*>(Vs + off) = vreg[i];
-    }
-  };
+  // unconditional, native-vector staging (conditional staging ends up in scratch memory)
+  u32x4_t kreg[LCH], vreg[LCH];
+#define K22_ATT_GLOAD(KT)                                                                                \
+  {                                                                                                      \
+    const int kt_ = (KT);                                                                                \
+    _Pragma("unroll") for (int i = 0; i < LCH; ++i) {                                                    \
+      const int q = tid + i * 256, row = q / CPR, cc = q - row * CPR;                                    \
+      kreg[i] = *reinterpret_cast<const u32x4_t*>(Kg + (int64_t)(kt_ * 64 + row) * 64 + cc * EPC);       \
+      vreg[i] = *reinterpret_cast<const u32x4_t*>(Vg + (int64_t)row * p.Tkp + kt_ * 64 + cc * EPC);      \
+    }                                                                                                    \
+  }
+#define K22_ATT_LSTORE()                                                                                 \
+  {                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < LCH; ++i) {                                                    \
+      const int q = tid + i * 256, row = q / CPR, cc = q - row * CPR;                                    \
+      const int off = (cc >> 3) * 8192 + lds_chunk_off(row, cc & 7);                                     \
+      *reinterpret_cast<u32x4_t*>(Ks + off) = kreg[i];                                                   \
+      *reinterpret_cast<u32x4_t*>(Vs + off) = vreg[i];                                                   \
+    }                                                                                                    \
+  }
 
   f32x16_t o[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
   float m_run = -1e30f, l_run = 0.f;
 
-  gload(0);
+  K22_ATT_GLOAD(0);
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();  // every wave finished reading the previous tile
-    lstore();
+    K22_ATT_LSTORE();
     __syncthreads();
-    if (kt + 1 < nkt) gload(kt + 1);
+    K22_ATT_GLOAD(kt + 1 < nkt ? kt + 1 : nkt - 1);
 
     f32x16_t s[2];
 #pragma unroll

@@ -13,6 +13,7 @@ typedef unsigned short bf16_t;  // bf16 storage type
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 enum K22DType { K22_BF16 = 0, K22_F32 = 1 };
 enum K22Act { K22_ACT_NONE = 0, K22_ACT_SILU = 1, K22_ACT_GELU = 2 };
@@ -53,7 +54,7 @@ template <> struct TT<float> {
 
 // A/B fragment of one 32x32x16 atom: 8 consecutive K elements of one row.
 template <typename T> struct Frag;
-template <> struct Frag<bf16_t> { uint4 v; };
+template <> struct Frag<bf16_t> { u32x4_t v; };
 template <> struct Frag<float> { float v[8]; };
 
 // Swizzled LDS tile: row r (128 B), logical chunk c (16 B) lives at physical chunk c ^ (r & 7).
@@ -62,7 +63,7 @@ __device__ __forceinline__ int lds_chunk_off(int r, int c) { return r * 128 + ((
 
 // lane-half h (= lane>>5) reads K elements [16*ks + 8*h, +8) of row r.
 __device__ __forceinline__ void ld_frag(Frag<bf16_t>& f, const char* tile, int r, int ks, int h) {
-  f.v = *reinterpret_cast<const uint4*>(tile + lds_chunk_off(r, 2 * ks + h));
+  f.v = *reinterpret_cast<const u32x4_t*>(tile + lds_chunk_off(r, 2 * ks + h));
 }
 __device__ __forceinline__ void ld_frag(Frag<float>& f, const char* tile, int r, int ks, int h) {
   const float4 a = *reinterpret_cast<const float4*>(tile + lds_chunk_off(r, 4 * ks + 2 * h));

@@ -29,10 +29,8 @@ __device__ __forceinline__ void load4(const float* p, float* f) {
 // pixels of the block's range are walked with every wave reading whole contiguous NHWC rows.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(GnStatsParams p) {
-  __shared__ float ls[64];
+  __shared__ float red[2][768];
   const int tid = threadIdx.x, b = blockIdx.y, s = blockIdx.x;
-  if (tid < 64) ls[tid] = 0.f;
-  __syncthreads();
   const int C = p.C0 + p.C1, cg = C / p.groups, VP = C / 4;
   const int per = (p.HW + p.nsplit - 1) / p.nsplit;
   const int pix0 = s * per, pix1 = min(p.HW, pix0 + per);
@@ -47,42 +45,65 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnStatsParams p) {
     int v = (VP >= 256) ? tid + 256 * j : ((j == 0 && pl < PL) ? tid - pl * VP : VP);
     vj[j] = v < VP ? v : -1;
   }
-  for (int pix = pix0 + pl; pix < pix1; pix += PL) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      if (vj[j] >= 0) {
-        const int c = vj[j] * 4;
+  for (int j = 0; j < 3; ++j) {
+    if (vj[j] >= 0) {
+      const int c = vj[j] * 4;
+      const T* src = c < p.C0 ? x0 + c : x1 + (c - p.C0);
+      const int64_t ld = c < p.C0 ? p.C0 : p.C1;
+      int pix = pix0 + pl;
+      // 4 independent loads in flight per thread (latency-bound otherwise)
+      for (; pix + 3 * PL < pix1; pix += 4 * PL) {
+        float f0[4], f1[4], f2[4], f3[4];
+        load4(src + (int64_t)pix * ld, f0);
+        load4(src + (int64_t)(pix + PL) * ld, f1);
+        load4(src + (int64_t)(pix + 2 * PL) * ld, f2);
+        load4(src + (int64_t)(pix + 3 * PL) * ld, f3);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          sum[j] += (f0[k] + f1[k]) + (f2[k] + f3[k]);
+          sq[j] += (f0[k] * f0[k] + f1[k] * f1[k]) + (f2[k] * f2[k] + f3[k] * f3[k]);
+        }
+      }
+      for (; pix < pix1; pix += PL) {
         float f[4];
-        if (c < p.C0) load4(x0 + (int64_t)pix * p.C0 + c, f);
-        else load4(x1 + (int64_t)pix * p.C1 + (c - p.C0), f);
+        load4(src + (int64_t)pix * ld, f);
         sum[j] += (f[0] + f[1]) + (f[2] + f[3]);
         sq[j] += (f[0] * f[0] + f[1] * f[1]) + (f[2] * f[2] + f[3] * f[3]);
       }
     }
   }
+  // deterministic block reduction: slot (pl, v) -> red[.][pl*VP + v]; group g owns a contiguous v range
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    if (vj[j] >= 0) {
-      const int g = (vj[j] * 4) / cg;
-      atomicAdd(&ls[2 * g], sum[j]);
-      atomicAdd(&ls[2 * g + 1], sq[j]);
-    }
-  }
+  for (int j = 0; j < 3; ++j)
+    if (vj[j] >= 0) { red[0][pl * VP + vj[j]] = sum[j]; red[1][pl * VP + vj[j]] = sq[j]; }
   __syncthreads();
-  if (tid < 2 * p.groups) p.partial[((int64_t)b * p.nsplit + s) * 64 + tid] = ls[tid];
+  if (tid < 2 * p.groups) {
+    const int g = tid >> 1, which = tid & 1, vpg = cg / 4;
+    float a = 0.f;
+    for (int q = 0; q < PL; ++q)
+      for (int v = g * vpg; v < (g + 1) * vpg; ++v) a += red[which][q * VP + v];
+    p.partial[((int64_t)b * p.nsplit + s) * 64 + tid] = a;
+  }
 }
 
 // ---- GroupNorm pass 2: fold mean/rstd, gamma/beta and FiLM into y = x*A[c] + Bc[c] -------------
 // grid (B), 256 threads.  coeff[b][c] = (A, Bc).
 __global__ __launch_bounds__(256) void gn_coeff_kernel(GnCoeffParams p) {
+  __shared__ double part[4][64];
   __shared__ float mean_s[32], rstd_s[32];
   const int tid = threadIdx.x, b = blockIdx.x;
+  {
+    // 64 (sum, sumsq) columns x 4 row-interleaved partial sums, fixed order => deterministic
+    const int col = tid & 63, q = tid >> 6;
+    double a = 0.0;
+    for (int i = q; i < p.nsplit; i += 4) a += (double)p.partial[((int64_t)b * p.nsplit + i) * 64 + col];
+    part[q][col] = a;
+  }
+  __syncthreads();
   if (tid < p.groups) {
-    double s = 0.0, q = 0.0;
-    for (int i = 0; i < p.nsplit; ++i) {
-      s += (double)p.partial[((int64_t)b * p.nsplit + i) * 64 + 2 * tid];
-      q += (double)p.partial[((int64_t)b * p.nsplit + i) * 64 + 2 * tid + 1];
-    }
+    const double s = (part[0][2 * tid] + part[1][2 * tid]) + (part[2][2 * tid] + part[3][2 * tid]);
+    const double q = (part[0][2 * tid + 1] + part[1][2 * tid + 1]) + (part[2][2 * tid + 1] + part[3][2 * tid + 1]);
     const double n = (double)p.HW * (double)(p.C / p.groups);
     const double mean = s / n;
     double var = q / n - mean * mean;

@@ -69,36 +69,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     kt1 = kt0 + per < nkt ? kt0 + per : nkt;
   }
 
-  uint4 areg[A_CH], breg[B_CH];
-  auto gload = [&](int kt) {
-    const int tap = kt / kt_per_tap;
-    const int k0 = (kt - tap * kt_per_tap) * BK;
-    if (conv) {
-      const int ty = tap / 3, tx = tap - ty * 3;
-      const int64_t add = (int64_t)(ty * (p.W + 2) + tx) * p.Kc + k0 + lchunk * EPC;
-#pragma unroll
-      for (int i = 0; i < A_CH; ++i) areg[i] = *reinterpret_cast<const uint4*>(A0 + aoff0[i] + add);
-    } else {
-      const bool second = (k0 >= p.K0);
-      const T* src = second ? A1 : A0;
-      const int64_t add = (second ? k0 - p.K0 : k0) + lchunk * EPC;
-#pragma unroll
-      for (int i = 0; i < A_CH; ++i)
-        areg[i] = *reinterpret_cast<const uint4*>(src + (second ? aoff1[i] : aoff0[i]) + add);
-    }
-    const int64_t badd = (int64_t)tap * p.Kc + k0 + lchunk * EPC;
-#pragma unroll
-    for (int i = 0; i < B_CH; ++i) breg[i] = *reinterpret_cast<const uint4*>(Wp + boff[i] + badd);
-  };
-  auto lstore = [&](int buf) {
-    char* As = smem + buf * BUF;
-    char* Bs = As + A_BYTES;
-#pragma unroll
-    for (int i = 0; i < A_CH; ++i) *reinterpret_cast<uint4*>(As + (lrow + 32 * i) * 128 + lpos * 16) = areg[i];
-#pragma unroll
-    for (int i = 0; i < B_CH; ++i) *reinterpret_cast<uint4*>(Bs + (lrow + 32 * i) * 128 + lpos * 16) = breg[i];
-  };
-
+  // Staging registers are native vectors and every load below is unconditional (the prefetch of the
+  // last iteration re-reads the last tile): conditional staging made hipcc keep them in scratch memory.
+  u32x4_t areg[A_CH], breg[B_CH];
   f32x16_t acc[MI][NI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -108,37 +81,64 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
   const int h = lane >> 5, l31 = lane & 31;
-  auto compute = [&](int buf) {
-    const char* As = smem + buf * BUF;
-    const char* Bs = As + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      Frag<T> a[MI], b[NI];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) ld_frag(a[mi], As, wm * (BM / 2) + mi * 32 + l31, ks, h);
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) ld_frag(b[ni], Bs, wn * (BN / 2) + ni * 32 + l31, ks, h);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], a[mi], b[ni]);
-    }
-  };
+  const int64_t lck = lchunk * EPC;
+
+#define K22_GLOAD(KT)                                                                                   \
+  {                                                                                                     \
+    const int kt_ = (KT);                                                                               \
+    const int tap_ = kt_ / kt_per_tap;                                                                  \
+    const int k0_ = (kt_ - tap_ * kt_per_tap) * BK;                                                     \
+    const bool second_ = (!conv) && (k0_ >= p.K0);                                                      \
+    const T* src_ = second_ ? A1 : A0;                                                                  \
+    const int ty_ = tap_ / 3, tx_ = tap_ - ty_ * 3;                                                     \
+    const int64_t add_ = (conv ? (int64_t)(ty_ * (p.W + 2) + tx_) * p.Kc + k0_ : (int64_t)(second_ ? k0_ - p.K0 : k0_)) + lck; \
+    _Pragma("unroll") for (int i = 0; i < A_CH; ++i)                                                    \
+        areg[i] = *reinterpret_cast<const u32x4_t*>(src_ + (second_ ? aoff1[i] : aoff0[i]) + add_);     \
+    const int64_t badd_ = (int64_t)tap_ * p.Kc + k0_ + lck;                                             \
+    _Pragma("unroll") for (int i = 0; i < B_CH; ++i)                                                    \
+        breg[i] = *reinterpret_cast<const u32x4_t*>(Wp + boff[i] + badd_);                              \
+  }
+#define K22_LSTORE(BUFI)                                                                                \
+  {                                                                                                     \
+    char* As_ = smem + (BUFI) * BUF;                                                                    \
+    char* Bs_ = As_ + A_BYTES;                                                                          \
+    _Pragma("unroll") for (int i = 0; i < A_CH; ++i)                                                    \
+        *reinterpret_cast<u32x4_t*>(As_ + (lrow + 32 * i) * 128 + lpos * 16) = areg[i];                 \
+    _Pragma("unroll") for (int i = 0; i < B_CH; ++i)                                                    \
+        *reinterpret_cast<u32x4_t*>(Bs_ + (lrow + 32 * i) * 128 + lpos * 16) = breg[i];                 \
+  }
 
   if (kt0 < kt1) {
-    gload(kt0);
-    lstore(0);
+    K22_GLOAD(kt0);
+    K22_LSTORE(0);
     __syncthreads();
     int cur = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
-      const bool more = (kt + 1 < kt1);
-      if (more) gload(kt + 1);
-      compute(cur);
-      if (more) lstore(cur ^ 1);
+      const int nxt = kt + 1 < kt1 ? kt + 1 : kt1 - 1;
+      K22_GLOAD(nxt);
+      {
+        const char* As = smem + cur * BUF;
+        const char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          Frag<T> a[MI], b[NI];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) ld_frag(a[mi], As, wm * (BM / 2) + mi * 32 + l31, ks, h);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) ld_frag(b[ni], Bs, wn * (BN / 2) + ni * 32 + l31, ks, h);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], a[mi], b[ni]);
+        }
+      }
+      K22_LSTORE(cur ^ 1);
       __syncthreads();
       cur ^= 1;
     }
   }
+#undef K22_GLOAD
+#undef K22_LSTORE
 
   // ---- epilogue ------------------------------------------------------------------------
   const int mbase = m0 + wm * (BM / 2), nbase = n0 + wn * (BN / 2);

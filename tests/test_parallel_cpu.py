@@ -1,0 +1,62 @@
+"""World-size-2 gloo tests of the multi-GPU plumbing (runs on CPU): arena broadcast + prompt sharding."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from kandinsky2_amd.parallel import broadcast_arena, gather_outputs, shard_range
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 3 * 1024 * 1024 + 17
+        g = torch.Generator().manual_seed(7)
+        full = torch.randint(0, 256, (n,), dtype=torch.uint8, generator=g)
+        arena = broadcast_arena(full.clone() if rank == 0 else None, n, "cpu", src=0, chunk_bytes=1 << 20)
+        ok = torch.equal(arena, full)
+        lo, hi = shard_range(7, rank, world)
+        local = torch.arange(lo, hi, dtype=torch.float32)[:, None].repeat(1, 3)
+        got = gather_outputs(local, dst=0)
+        if rank == 0:
+            cat = torch.cat(got, 0)
+            ok = ok and torch.equal(cat[:, 0], torch.arange(7, dtype=torch.float32))
+        q.put((rank, ok, (lo, hi)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_range_partitions():
+    for n in (1, 7, 8, 32, 33):
+        for world in (1, 2, 4, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_arena_broadcast_and_gather_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok, _ in res), res
+    assert sorted(span for _, _, span in res) == [(0, 4), (4, 7)]

@@ -1,0 +1,91 @@
+#!/usr/bin/env python
+"""Per-shape micro-benchmark of the implicit-GEMM conv / GEMM kernels on the real layer shapes of one UNet
+step (C2: B=2, latent 96x96).  Used to pick tile configurations; prints TFLOP/s per shape and the summed time.
+
+    python tools/bench_kernels.py [--lat 96] [--B 2] [--dtype bf16] [--configs auto,128x128,128x64,256x128]
+"""
+import argparse
+import os
+import sys
+from collections import OrderedDict
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import kandinsky2_amd as k22  # noqa: E402
+from kandinsky2_amd import _lib  # noqa: E402
+
+
+def conv_shapes(arch, B, lat):
+    """(Cin, Cout, H) -> count, for every 3x3 conv of one forward."""
+    shapes = OrderedDict()
+    res = {}
+    h = lat
+    # spatial size per block follows the walk: down blocks halve, up blocks double
+    for b in arch.blocks:
+        if b[0] != "res":
+            continue
+        _, pfx, cin, cout, ud = b
+        ho = h // 2 if ud == 1 else (h * 2 if ud == 2 else h)
+        for (ci, co) in ((cin, cout), (cout, cout)):
+            key = (ci, co, ho)
+            shapes[key] = shapes.get(key, 0) + 1
+        h = ho
+    return shapes
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lat", type=int, default=96)
+    ap.add_argument("--B", type=int, default=2)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--configs", default="auto")
+    ap.add_argument("--reps", type=int, default=5)
+    a = ap.parse_args()
+    arch = k22.make_arch(k22.MODEL_CONFIG_2_1)
+    dt = _lib.K22_BF16 if a.dtype == "bf16" else _lib.K22_F32
+    T = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    L = _lib.lib()
+    shapes = conv_shapes(arch, a.B, a.lat)
+    cfgs = []
+    for c in a.configs.split(","):
+        if c == "auto":
+            cfgs.append((0, 0, 0))
+        else:
+            parts = c.split("x")
+            cfgs.append((int(parts[0]), int(parts[1]), int(parts[2]) if len(parts) > 2 else 1))
+    st = torch.cuda.current_stream().cuda_stream
+    tot = {c: 0.0 for c in cfgs}
+    totfl = 0.0
+    print(f"{'Cin':>5} {'Cout':>5} {'H':>3} {'cnt':>3} {'GFLOP':>8} | " + " | ".join(f"{c[0]}x{c[1]}k{c[2]} TF/s" for c in cfgs))
+    for (ci, co, h), cnt in shapes.items():
+        x = torch.randn(a.B, h + 2, h + 2, ci, device="cuda").to(T)
+        w = (torch.randn((co + 63) // 64 * 64, 9 * ci, device="cuda") * (9 * ci) ** -0.5).to(T)
+        bias = torch.randn(co, device="cuda")
+        out = torch.empty(a.B, h, h, co, device="cuda", dtype=T)
+        part = torch.empty(16 * a.B * h * h * co + 64, device="cuda")
+        fl = 2.0 * a.B * h * h * co * 9 * ci
+        totfl += fl * cnt
+        row = []
+        for c in cfgs:
+            def run():
+                _lib.check(L.k22_conv3x3(x.data_ptr(), w.data_ptr(), bias.data_ptr(), None, out.data_ptr(), part.data_ptr(),
+                                         a.B, h, h, ci, co, w.shape[0], 0, 0, c[2], c[0], c[1], dt, st))
+            run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.reps):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / a.reps
+            tot[c] += ms * cnt
+            row.append(f"{fl / ms / 1e9:10.1f}")
+        print(f"{ci:5d} {co:5d} {h:3d} {cnt:3d} {fl / 1e9:8.1f} | " + " | ".join(row))
+    for c in cfgs:
+        print(f"config {c}: conv total {tot[c]:.3f} ms/step -> {totfl / tot[c] / 1e9:.1f} TFLOP/s over {totfl / 1e9:.0f} GFLOP")
+
+
+if __name__ == "__main__":
+    main()
