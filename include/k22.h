@@ -32,6 +32,8 @@ extern "C" {
 
 int k22_version(void);
 const char* k22_last_error(void);
+/* Tuning knobs (process-wide): "igemm_stages" = 0 register-staged, 2..4 LDS-DMA pipeline depth, -1 default. */
+int k22_set_option(const char* name, int value);
 
 /* ---- UNet engine --------------------------------------------------------------------------
  * Replaces Text2ImUNet.forward / InpaintText2ImUNet.forward (kandinsky2/model/text2im_model2_1.py:

@@ -36,6 +36,7 @@ _P, _I, _L, _F, _D, _Z = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C
 SIGNATURES = {
     "k22_version": (_I, []),
     "k22_last_error": (C.c_char_p, []),
+    "k22_set_option": (_I, [C.c_char_p, _I]),
     "k22_unet_create": (_I, [C.POINTER(K22UNetConfig), C.POINTER(K22Weight), _I, C.POINTER(_P)]),
     "k22_unet_destroy": (None, [_P]),
     "k22_unet_plan": (_I, [_P, _I, _I, _I, C.POINTER(_Z)]),

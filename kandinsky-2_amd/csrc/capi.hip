@@ -19,12 +19,18 @@ int k22_set_error_hip(hipError_t e, const char* file, int line) {
 extern "C" {
 
 int k22_version(void) { return 100; }
+
+int k22_set_option(const char* name, int value) {
+  if (name && !strcmp(name, "igemm_stages")) { igemm_set_default_stages(value); return K22_OK; }
+  return k22_set_error(K22_EINVAL, "k22_set_option: unknown option");
+}
 const char* k22_last_error(void) { return g_err; }
 
 int k22_gemm(const void* A0, const void* A1, const void* Wp, const float* bias, const void* residual, void* out,
              void* partial, int M, int N, int Npad, int K0, int K1, long lda0, long lda1, int ldo, int ldr,
              int out_f32, int act, int splitk, int bm, int bn, int dtype, void* stream) {
   IgemmParams p = {};
+    p.stages = -1;
   p.A0 = A0; p.A1 = A1; p.Wp = Wp; p.bias = bias; p.residual = residual; p.out = out;
   p.partial = reinterpret_cast<float*>(partial);
   p.M = M; p.N = N; p.Npad = Npad; p.Kc = K0 + K1; p.K0 = K0; p.taps = 1; p.lda0 = lda0; p.lda1 = lda1;
@@ -38,6 +44,7 @@ int k22_conv3x3(const void* x_padded, const void* Wp, const float* bias, const v
                 void* partial, int B, int H, int W, int Cin, int Cout, int Npad, int out_mode, int act, int splitk,
                 int bm, int bn, int dtype, void* stream) {
   IgemmParams p = {};
+    p.stages = -1;
   p.A0 = x_padded; p.Wp = Wp; p.bias = bias; p.residual = residual; p.out = out;
   p.partial = reinterpret_cast<float*>(partial);
   p.M = B * H * W; p.N = Cout; p.Npad = Npad; p.Kc = Cin; p.K0 = Cin; p.taps = 9; p.H = H; p.W = W;

@@ -131,6 +131,7 @@ struct K22UNet {
   void op_conv(OpList& L, Slot* src, int Hc, int Wc, int Cin, int Cout,
                const std::string& pfx, const Act* residual, Slot* dst, int out_mode) {
     IgemmParams p = {};
+    p.stages = -1;
     p.M = B * Hc * Wc; p.N = Cout; p.Npad = (Cout + 63) / 64 * 64; p.Kc = Cin; p.K0 = Cin; p.taps = 9;
     p.H = Hc; p.W = Wc; p.ldo = Cout; p.ldr = Cout; p.out_mode = out_mode; p.act = K22_ACT_NONE;
     p.Wp = W_(pfx + ".weight"); p.bias = Wf(pfx + ".bias");
@@ -150,6 +151,7 @@ struct K22UNet {
   void op_gemm(OpList& L, const Act& in, int M, int N, const std::string& pfx,
                const Act* residual, Slot* dst, int ldo = 0) {
     IgemmParams p = {};
+    p.stages = -1;
     p.M = M; p.N = N; p.Npad = (N + 63) / 64 * 64; p.Kc = in.C(); p.K0 = in.C0; p.taps = 1;
     p.lda0 = in.C0; p.lda1 = in.C1; p.ldo = ldo ? ldo : N; p.ldr = N; p.out_mode = IG_OUT_ROWMAJOR;
     p.act = K22_ACT_NONE;
@@ -432,6 +434,7 @@ struct K22UNet {
     // ctx[b][nie:S] = to_model_dim_n(full_emb[b])   (one GEMM per batch element: rows re-strided)
     {
       IgemmParams p = {};
+    p.stages = -1;
       p.M = ntext; p.N = cd; p.Npad = (cd + 63) / 64 * 64; p.Kc = d1; p.K0 = d1; p.taps = 1; p.lda0 = d1; p.ldo = cd;
       p.out_mode = IG_OUT_ROWMAJOR; p.splitk = 1;
       p.Wp = W_("to_model_dim_n.weight"); p.bias = Wf("to_model_dim_n.bias");

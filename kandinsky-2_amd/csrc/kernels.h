@@ -39,7 +39,9 @@ struct IgemmParams {
   int act;               // K22Act applied after bias+residual
   int splitk;            // >= 1 (0 = let the launcher choose)
   int force_bm, force_bn;  // 0 = heuristic
+  int stages;            // -1 = default (env K22_IGEMM_STAGES), 0 = register staging, 2..4 = LDS-DMA pipeline depth
 };
 
 int launch_igemm(const IgemmParams& p, int dtype, hipStream_t stream);
+void igemm_set_default_stages(int v);  // tuning knob: 0 register staging, 2..4 LDS-DMA stages, -1 env/default
 int igemm_choose_splitk(const IgemmParams& p, int dtype);  // split-K factor the heuristic picks (scratch = splitk*M*N*4 B)

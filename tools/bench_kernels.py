@@ -41,11 +41,14 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--configs", default="auto")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--stages", type=int, default=-1, help="igemm_stages option (0 reg-staged, 2..4 LDS-DMA)")
     a = ap.parse_args()
     arch = k22.make_arch(k22.MODEL_CONFIG_2_1)
     dt = _lib.K22_BF16 if a.dtype == "bf16" else _lib.K22_F32
     T = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     L = _lib.lib()
+    _lib.check(L.k22_set_option(b"igemm_stages", a.stages))
+    print("igemm_stages =", a.stages)
     shapes = conv_shapes(arch, a.B, a.lat)
     cfgs = []
     for c in a.configs.split(","):
