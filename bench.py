@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-size", type=int, default=0, help="image side for the CPU sample (0 = same as --size)")
+    ap.add_argument("--tuning-report", default="", help="write the chosen conv/GEMM tile configurations to this file")
     ap.add_argument("--tiny", action="store_true", help="1/3-width UNet (debug only; not a valid bench config)")
     a = ap.parse_args()
 
@@ -139,6 +140,9 @@ def main():
     finite = bool(torch.isfinite(x).all().item())
 
     if rank == 0:
+        if a.tuning_report:
+            with open(a.tuning_report, "w") as f:
+                f.write(m.tuning_report())
         prof = m.profile(reps=3)
         conv = prof["conv3x3"]
         peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS

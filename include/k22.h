@@ -32,7 +32,9 @@ extern "C" {
 
 int k22_version(void);
 const char* k22_last_error(void);
-/* Tuning knobs (process-wide): "igemm_stages" = 0 register-staged, 2..4 LDS-DMA pipeline depth, -1 default. */
+/* Tuning knobs (process-wide): "igemm_stages" = 2..4 LDS-DMA pipeline depth (-1 default);
+ * "igemm_xcd_remap" = 0/1 XCD-aware workgroup renumbering; "conv_algo" = 0 auto, 1 generic implicit GEMM,
+ * 2 LDS-resident halo kernel for the 3x3 convolutions. */
 int k22_set_option(const char* name, int value);
 
 /* ---- UNet engine --------------------------------------------------------------------------
@@ -95,6 +97,11 @@ int k22_unet_forward(K22UNet* u, const float* x, const float* timesteps, const f
 
 /* Number of engine ops in one planned forward (diagnostics). */
 int k22_unet_num_ops(const K22UNet* u);
+/* Tile configurations of the convolutions / GEMMs are chosen by measurement during the first k22_unet_forward
+ * after k22_unet_plan (default on; env K22_AUTOTUNE=0 or k22_unet_set_autotune(u, 0) before planning = heuristics).
+ * k22_unet_tuning_report writes a text table of the choices into buf. */
+int k22_unet_set_autotune(K22UNet* u, int on);
+int k22_unet_tuning_report(const K22UNet* u, char* buf, size_t cap);
 
 /* Measurement aid for bench.py: replays the planned forward EAGERLY `reps` times on `stream` with a HIP
  * event pair around every op, and reports per op class k (0 conv3x3, 1 GEMM, 2 GroupNorm, 3 attention,
@@ -129,6 +136,13 @@ int k22_gemm(const void* A0, const void* A1, const void* Wp, const float* bias, 
 int k22_conv3x3(const void* x_padded, const void* Wp, const float* bias, const void* residual, void* out,
                 void* partial, int B, int H, int W, int Cin, int Cout, int Npad, int out_mode, int act, int splitk,
                 int bm, int bn, int dtype, void* stream);
+/* Same convolution (row-major T output, no activation) that also emits the per-channel partial sums the next
+ * GroupNorm needs (ResBlock: conv -> GroupNorm32, unet.py:157-164/212-216), so the tensor is not re-read:
+ * stats[row][c] = (sum, sum of squares) of the STORED outputs, image b owning rows [b*rpi, (b+1)*rpi);
+ * *rows_per_image receives rpi.  Fails (K22_EINVAL) for configurations that cannot produce them. */
+int k22_conv3x3_gnstats(const void* x_padded, const void* Wp, const float* bias, const void* residual, void* out,
+                        void* partial, int B, int H, int W, int Cin, int Cout, int Npad, int splitk, int bm, int bn,
+                        float* stats, int stats_capacity_rows, int* rows_per_image, int dtype, void* stream);
 int k22_groupnorm(const void* x0, const void* x1, int C0, int C1, int B, int H, int W, const float* gamma,
                   const float* beta, const float* film, long film_ld, float eps, int act, int mode, int pad,
                   void* scratch, void* out, int dtype, void* stream);

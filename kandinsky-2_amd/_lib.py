@@ -44,11 +44,14 @@ SIGNATURES = {
     "k22_unet_set_condition": (_I, [_P, _P, _P, _P, _P]),
     "k22_unet_forward": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "k22_unet_num_ops": (_I, [_P]),
+    "k22_unet_set_autotune": (_I, [_P, _I]),
+    "k22_unet_tuning_report": (_I, [_P, C.c_char_p, _Z]),
     "k22_unet_profile": (_I, [_P, _I, C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), C.POINTER(_I), _P]),
     "k22_sampler_scratch_bytes": (_Z, [_I, _I]),
     "k22_sampler_step": (_I, [_P, _P, _P, _P, _P, _P, _I, _F, _I, _F, _F, _I, _D, _P, _P, _P, _I, _I, _P]),
     "k22_gemm": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "k22_conv3x3": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "k22_conv3x3_gnstats": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, C.POINTER(_I), _I, _P]),
     "k22_groupnorm": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _L, _F, _I, _I, _I, _P, _P, _I, _P]),
     "k22_groupnorm_scratch_bytes": (_Z, [_I, _I]),
     "k22_attention": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

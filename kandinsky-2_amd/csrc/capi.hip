@@ -22,6 +22,8 @@ int k22_version(void) { return 100; }
 
 int k22_set_option(const char* name, int value) {
   if (name && !strcmp(name, "igemm_stages")) { igemm_set_default_stages(value); return K22_OK; }
+  if (name && !strcmp(name, "igemm_xcd_remap")) { igemm_set_xcd_remap(value); return K22_OK; }
+  if (name && !strcmp(name, "conv_algo")) { igemm_set_conv_algo(value); return K22_OK; }
   return k22_set_error(K22_EINVAL, "k22_set_option: unknown option");
 }
 const char* k22_last_error(void) { return g_err; }
@@ -53,8 +55,26 @@ int k22_conv3x3(const void* x_padded, const void* Wp, const float* bias, const v
   return launch_igemm(p, dtype, reinterpret_cast<hipStream_t>(stream));
 }
 
+int k22_conv3x3_gnstats(const void* x_padded, const void* Wp, const float* bias, const void* residual, void* out,
+                        void* partial, int B, int H, int W, int Cin, int Cout, int Npad, int splitk, int bm, int bn,
+                        float* stats, int stats_capacity_rows, int* rows_per_image, int dtype, void* stream) {
+  IgemmParams p = {};
+  p.stages = -1;
+  p.A0 = x_padded; p.Wp = Wp; p.bias = bias; p.residual = residual; p.out = out;
+  p.partial = reinterpret_cast<float*>(partial);
+  p.M = B * H * W; p.N = Cout; p.Npad = Npad; p.Kc = Cin; p.K0 = Cin; p.taps = 9; p.H = H; p.W = W;
+  p.ldo = Cout; p.ldr = Cout; p.out_mode = IG_OUT_ROWMAJOR; p.act = K22_ACT_NONE; p.splitk = splitk; p.force_bm = bm; p.force_bn = bn;
+  if (p.splitk == 0) p.splitk = partial ? igemm_choose_splitk(p, dtype) : 1;
+  const int rpi = igemm_stats_rows_per_image(p, dtype);
+  if (rows_per_image) *rows_per_image = rpi;
+  if (rpi <= 0) return k22_set_error(K22_EINVAL, "conv3x3_gnstats: this configuration cannot produce GroupNorm partial sums");
+  if (rpi * B > stats_capacity_rows) return k22_set_error(K22_ENOMEM, "conv3x3_gnstats: stats buffer too small");
+  p.stats = stats;
+  return launch_igemm(p, dtype, reinterpret_cast<hipStream_t>(stream));
+}
+
 size_t k22_groupnorm_scratch_bytes(int B, int C) {
-  return (size_t)B * 256 * 64 * sizeof(float) + (size_t)B * C * 2 * sizeof(float) + 512;
+  return (size_t)B * 128 * C * 2 * sizeof(float) + (size_t)B * C * 2 * sizeof(float) + 512;
 }
 
 int k22_groupnorm(const void* x0, const void* x1, int C0, int C1, int B, int H, int W, const float* gamma,
@@ -64,13 +84,14 @@ int k22_groupnorm(const void* x0, const void* x1, int C0, int C1, int B, int H, 
   const int C = C0 + C1, HW = H * W;
   const int nsplit = gn_nsplit(B, HW);
   float* partial = reinterpret_cast<float*>(scratch);
-  float* coeff = partial + (size_t)B * 256 * 64;
+  float* coeff = partial + (size_t)B * 128 * C * 2;
   GnStatsParams sp;
   sp.x0 = x0; sp.x1 = x1; sp.C0 = C0; sp.C1 = C1; sp.HW = HW; sp.B = B; sp.groups = 32; sp.nsplit = nsplit; sp.partial = partial;
   int rc = launch_gn_stats(sp, dtype, st);
   if (rc) return rc;
-  GnCoeffParams cp;
-  cp.partial = partial; cp.nsplit = nsplit; cp.HW = HW; cp.C = C; cp.groups = 32; cp.eps = eps; cp.gamma = gamma; cp.beta = beta;
+  GnCoeffParams cp = {};
+  cp.src[0].st = partial; cp.src[0].rpi = nsplit; cp.src[0].C = C; cp.src[1].st = nullptr; cp.src[1].rpi = 0; cp.src[1].C = 0;
+  cp.HW = HW; cp.C = C; cp.groups = 32; cp.eps = eps; cp.gamma = gamma; cp.beta = beta;
   cp.film = film; cp.film_ld = film_ld; cp.coeff = coeff;
   rc = launch_gn_coeff(cp, B, st);
   if (rc) return rc;

@@ -57,9 +57,12 @@ template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { u32x4_t v; };
 template <> struct Frag<float> { float v[8]; };
 
-// Swizzled LDS tile: row r (128 B), logical chunk c (16 B) lives at physical chunk c ^ (r & 7).
+// Swizzled LDS tile: row r (128 B), logical chunk c (16 B) lives at physical chunk c ^ ((r >> 1) & 7).
+// ds_read_b128 is serviced in 16-lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) over 64 banks
+// (256 B = two 128-B rows): the 16-B slot of (r, chunk) is (r & 1) * 8 + chunk, so rows of equal parity in a
+// group need distinct swizzles -> key on r >> 1 (keying on r & 7 leaves every group 2-way conflicted).
 // With this image a ds_read_b128 of "row = lane&31, chunk = const" is bank-conflict free.
-__device__ __forceinline__ int lds_chunk_off(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
+__device__ __forceinline__ int lds_chunk_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 
 // lane-half h (= lane>>5) reads K elements [16*ks + 8*h, +8) of row r.
 __device__ __forceinline__ void ld_frag(Frag<bf16_t>& f, const char* tile, int r, int ks, int h) {

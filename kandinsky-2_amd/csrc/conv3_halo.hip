@@ -1,0 +1,411 @@
+// k22 — 3x3 convolution with the input tile (+halo) RESIDENT IN LDS across the nine filter taps.
+//
+// Replaces nn.Conv2d 3x3 of the ResBlocks (kandinsky2/model/unet.py:152,180; ~83 % of the FLOPs of a
+// denoise step).  The generic implicit GEMM (igemm.hip) re-fetches the A operand for every tap: 9 x BM rows
+// per 64-channel slab, and at 128x128 tiles the L2->LDS path (~56-64 B/clk/CU) is as busy as the MFMA pipes.
+// Here the pixels are indexed in the PADDED row-major plane, v = y*(W+2) + x, so that tap (ky,kx) of output v
+// is input v + ky*(W+2) + kx: a pure 1-D shift.  A block owns BM consecutive v of one image and keeps the
+// BM + 2*(W+2) + 2 input pixels it needs (x 64 channels = one 128-byte row each) in LDS; every tap reads its A
+// fragments from the same LDS image at a different row offset.  Outputs with x >= W (two "junk" columns per
+// row, 2 % at 96x96) are computed and dropped.  Per slab a block moves (BM + 2W + 6) + 9*BN rows instead of
+// 9*(BM + BN): 188 FLOP/B at 256x128 against 64 FLOP/B before, and 3 LDS-DMA instructions per wave per tap
+// instead of 8.
+//
+//   * 8 waves (4 along M x 2 along N), BM in {256, 128}, BN = 128, K slab = 128 bytes of channels
+//   * halo buffer double-buffered across slabs (the next slab's halo trickles in, one 8-row piece per wave per
+//     tap), weight tiles in an NBST-deep ring (2..4, as many as the LDS holds next to the halo) with a COUNTED
+//     vmcnt: NBST-1 taps of weights are in flight across the ONE raw s_barrier per tap (at the low-resolution
+//     levels the weights stream from HBM, ~2 us away, and a tap is ~0.4 us of MFMA work)
+//   * LDS images are lane-linear per LDS-DMA instruction with the chunk-XOR swizzle of common.h on the source
+//     address and on the reads (rows of an atom are consecutive -> conflict-free ds_read_b128)
+//   * transposed MFMA (lane = pixel, registers = 4 consecutive channels) and an epilogue that goes through LDS:
+//     fp32 tile -> 32 B per thread row segments: bias, residual, one rounding, 16-byte stores, and the per-channel
+//     (sum, sum of squares) of the STORED values for the next GroupNorm (deterministic, no atomics)
+//   * split-K over channel slabs for the low-resolution levels (fp32 partials, finished by splitk_reduce)
+#include "kernels.h"
+
+namespace {
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ void ld_frag_at(Frag<bf16_t>& f, const char* rowp, int sw, int ks, int h) {
+  f.v = *reinterpret_cast<const u32x4_t*>(rowp + (((2 * ks + h) ^ sw) << 4));
+}
+__device__ __forceinline__ void ld_frag_at(Frag<float>& f, const char* rowp, int sw, int ks, int h) {
+  const float4 a = *reinterpret_cast<const float4*>(rowp + (((4 * ks + 2 * h) ^ sw) << 4));
+  const float4 b = *reinterpret_cast<const float4*>(rowp + (((4 * ks + 2 * h + 1) ^ sw) << 4));
+  f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
+  f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+}
+
+template <typename T> __device__ __forceinline__ void store8(T* dst, const float* v);
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* dst, const float* v) {
+  uint4 w;
+  w.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+  w.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+  w.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+  w.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+  *reinterpret_cast<uint4*>(dst) = w;
+}
+template <> __device__ __forceinline__ void store8<float>(float* dst, const float* v) {
+  *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <typename T> __device__ __forceinline__ void load8f(const T* src, float* v);
+template <> __device__ __forceinline__ void load8f<bf16_t>(const bf16_t* src, float* v) {
+  const uint4 r = *reinterpret_cast<const uint4*>(src);
+  v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+  v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+  v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
+  v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void load8f<float>(const float* src, float* v) {
+  const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+// value as it will be read back from memory (the GroupNorm statistics are those of the stored tensor)
+template <typename T> __device__ __forceinline__ float stored(float v);
+template <> __device__ __forceinline__ float stored<bf16_t>(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+template <> __device__ __forceinline__ float stored<float>(float v) { return v; }
+
+__device__ __forceinline__ int xcd_remap_h(int bid, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+constexpr int HALO_BN = 128;
+constexpr int HALO_NW = 8;        // waves per workgroup
+constexpr int HALO_MAXA = 8;      // halo LDS-DMA slots per wave per slab: taps 0 .. 9-NBST carry one each
+
+// number of halo pieces issued in the NBST-2 iterations before tap T (they sit between the weight tile this
+// tap needs and "now" in the VMEM queue); taps are unrolled, so this is a compile-time constant.
+template <int NBST> constexpr int halo_count_a(int t) {
+  int c = 0;
+  for (int k = 1; k <= NBST - 2; ++k) {
+    const int u = t - k;
+    if (u >= 0 && u <= 9 - NBST) ++c;
+  }
+  return c;
+}
+
+}  // namespace
+
+template <typename T, int BM, int NBST>
+__global__ __launch_bounds__(512) void conv3_halo_kernel(const IgemmParams p) {
+  using TR = TT<T>;
+  constexpr int BK = TR::BK, EPC = TR::EPC, KSTEPS = TR::KSTEPS;
+  constexpr int BN = HALO_BN, NW = HALO_NW, WM = 4, WN = 2;
+  constexpr int MI = BM / (WM * 32), NI = BN / (WN * 32);
+  constexpr int B_SLOTS = BN / 8 / NW;  // weight LDS-DMA instructions per wave per tap
+  constexpr int B_BYTES = BN * 128;
+  constexpr int A_SLOTS = 10 - NBST;    // taps 0 .. 9-NBST issue one halo piece per wave
+  constexpr int GM = 8;
+  constexpr int TS = BN * 4 + 16;       // epilogue tile row stride (bytes): conflict-free float4 writes
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int h = lane >> 5, l31 = lane & 31;
+
+  const int W2 = p.W + 2;
+  const int VR = p.H * W2;                     // virtual output rows per image
+  const int TPI = (VR + BM - 1) / BM;          // m-tiles per image
+  const int HRp = (BM + 2 * W2 + 2 + 7) & ~7;  // halo rows (padded to whole 8-row LDS-DMA pieces)
+  const int NP = HRp >> 3;
+  const int A_BYTES = HRp * 128;
+  const int PR_MAX = (p.H + 2) * W2 - 1;       // last pixel of one padded plane
+  const int B = p.M / (p.H * p.W);
+
+  // ---- block -> (m-tile, n-tile, k-split) ------------------------------------------------------
+  const int gx = B * TPI, gy = (p.N + BN - 1) / BN;
+  int L = p.xcd_remap ? xcd_remap_h(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int per_z = gx * gy;
+  const int bz = L / per_z;
+  L -= bz * per_z;
+  const int grp = L / (GM * gy);
+  const int first_m = grp * GM;
+  const int gsz = gx - first_m < GM ? gx - first_m : GM;
+  const int lin = L - grp * GM * gy;
+  const int bx = first_m + lin % gsz, by = lin / gsz;
+  const int img = bx / TPI, v0 = (bx - img * TPI) * BM;
+  const int n0 = by * BN;
+
+  const T* __restrict__ Aimg = reinterpret_cast<const T*>(p.A0) + (int64_t)img * (p.H + 2) * W2 * p.Kc;
+  const T* __restrict__ Wp = reinterpret_cast<const T*>(p.Wp);
+
+  // ---- loader geometry ---------------------------------------------------------------------------
+  // halo piece j (8 rows) is issued by wave j % NW in its slot j / NW; lane -> (row 8j + lane/8, position lane%8)
+  int aoff[A_SLOTS];
+#pragma unroll
+  for (int q = 0; q < A_SLOTS; ++q) {
+    int j = q * NW + wave;
+    if (j > NP - 1) j = NP - 1;  // surplus slots re-load the last piece (same bytes, same place): uniform counting
+    const int hr = 8 * j + (lane >> 3);
+    int pr = v0 + hr;
+    if (pr > PR_MAX) pr = PR_MAX;
+    const int chunk = (lane & 7) ^ ((hr >> 1) & 7);
+    aoff[q] = pr * p.Kc + chunk * EPC;
+  }
+  int boff[B_SLOTS];
+#pragma unroll
+  for (int i = 0; i < B_SLOTS; ++i) {
+    const int row = 8 * (wave + NW * i) + (lane >> 3);
+    int n = n0 + row;
+    if (n > p.Npad - 1) n = p.Npad - 1;
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    boff[i] = n * 9 * p.Kc + chunk * EPC;
+  }
+  const int nslab = p.Kc / BK;
+  int s0 = 0, s1 = nslab;
+  if (p.splitk > 1) {
+    const int per = (nslab + p.splitk - 1) / p.splitk;
+    s0 = bz * per;
+    s1 = s0 + per < nslab ? s0 + per : nslab;
+  }
+
+  f32x16_t acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  char* const Bst = smem + 2 * A_BYTES;
+  // fragment rows: A row = wm*(BM/4) + mi*32 + l31 + tap shift ; B row = wn*(BN/2) + ni*32 + l31
+  const int abase = wm * (BM / WM) + l31;
+  int brow[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) brow[ni] = (wn * (BN / WN) + ni * 32 + l31) * 128;
+  const int bsw = (l31 >> 1) & 7;  // (row >> 1) & 7 with row = multiple of 32 + l31
+
+#define K22_ISSUE_A(Q, SLAB, DST)                                                                          \
+  {                                                                                                        \
+    int j_ = (Q) * NW + wave;                                                                              \
+    if (j_ > NP - 1) j_ = NP - 1;                                                                          \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Aimg + aoff[Q] + (SLAB) * BK), \
+                                     (__attribute__((address_space(3))) void*)((DST) + j_ * 1024), 16, 0, 0); \
+  }
+#define K22_ISSUE_B(SLAB, TAP, STAGE)                                                                      \
+  {                                                                                                        \
+    const int kofs_ = (TAP) * p.Kc + (SLAB) * BK;                                                          \
+    char* dst_ = Bst + (STAGE) * B_BYTES + wave * 1024;                                                    \
+    _Pragma("unroll") for (int i = 0; i < B_SLOTS; ++i)                                                    \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wp + boff[i] + kofs_), \
+                                         (__attribute__((address_space(3))) void*)(dst_ + i * NW * 1024), 16, 0, 0); \
+  }
+
+  if (s0 < s1) {
+    // prologue: the whole halo of the first slab, then the weight tiles of taps 0 .. NBST-2
+#pragma unroll
+    for (int q = 0; q < A_SLOTS; ++q) K22_ISSUE_A(q, s0, smem);
+#pragma unroll
+    for (int t = 0; t < NBST - 1; ++t) K22_ISSUE_B(s0, t, t);
+    int cur = 0;               // ring slot of the current tap's weights
+    int fill = NBST - 1;       // ring slot the tile NBST-1 taps ahead goes into
+    for (int s = s0; s < s1; ++s) {
+      char* const Acur = smem + ((s - s0) & 1) * A_BYTES;
+      char* const Anext = smem + (((s - s0) & 1) ^ 1) * A_BYTES;
+      const int sn = s + 1 < s1 ? s + 1 : s1 - 1;  // past-the-end loads re-read the last slab (uniform counting)
+      // the nine taps are expanded with literal tap numbers: the vmcnt immediates and the (slab, tap) of the
+      // prefetched weight tile are compile-time functions of the tap
+#define K22_TAP(TAP)                                                                                       \
+      {                                                                                                    \
+        wait_vmcnt<B_SLOTS * (NBST - 2) + halo_count_a<NBST>(TAP)>();                                      \
+        __builtin_amdgcn_s_barrier();                                                                      \
+        /* one piece of the next slab's halo, then the weight tile NBST-1 taps ahead */                    \
+        if constexpr ((TAP) < A_SLOTS) K22_ISSUE_A(((TAP) < A_SLOTS ? (TAP) : 0), sn, Anext);              \
+        {                                                                                                  \
+          constexpr int ta_ = ((TAP) + NBST - 1) % 9;                                                      \
+          const int sa_ = ((TAP) + NBST - 1 >= 9) ? sn : s;                                                \
+          K22_ISSUE_B(sa_, ta_, fill);                                                                     \
+        }                                                                                                  \
+        const char* Bcur = Bst + cur * B_BYTES;                                                            \
+        const int shift = ((TAP) / 3) * W2 + ((TAP) % 3);                                                  \
+        const char* arow[MI];                                                                              \
+        int asw[MI];                                                                                       \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                \
+          const int ar = abase + mi * 32 + shift;                                                          \
+          arow[mi] = Acur + ar * 128;                                                                      \
+          asw[mi] = (ar >> 1) & 7;                                                                         \
+        }                                                                                                  \
+        _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks) {                                            \
+          Frag<T> a[MI], b[NI];                                                                            \
+          _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) ld_frag_at(a[mi], arow[mi], asw[mi], ks, h);   \
+          _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) ld_frag_at(b[ni], Bcur + brow[ni], bsw, ks, h); \
+          _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], b[ni], a[mi]);         \
+        }                                                                                                  \
+        cur = (cur + 1 == NBST) ? 0 : cur + 1;                                                             \
+        fill = (fill + 1 == NBST) ? 0 : fill + 1;                                                          \
+      }
+      K22_TAP(0) K22_TAP(1) K22_TAP(2) K22_TAP(3) K22_TAP(4) K22_TAP(5) K22_TAP(6) K22_TAP(7) K22_TAP(8)
+#undef K22_TAP
+    }
+  }
+#undef K22_ISSUE_A
+#undef K22_ISSUE_B
+  wait_vmcnt<0>();
+  __syncthreads();  // every wave is done with the operand buffers: the LDS becomes the fp32 output tile
+
+  // ---- epilogue 1: accumulators -> LDS tile [BM][BN] fp32 (lane = pixel, 4 consecutive channels per quad) ----
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int row = wm * (BM / WM) + mi * 32 + l31;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = wn * (BN / WN) + ni * 32 + 8 * j + 4 * h;
+        *reinterpret_cast<float4*>(smem + row * TS + col * 4) =
+            make_float4(acc[mi][ni][4 * j], acc[mi][ni][4 * j + 1], acc[mi][ni][4 * j + 2], acc[mi][ni][4 * j + 3]);
+      }
+  }
+  __syncthreads();
+
+  // ---- epilogue 2: thread = 8 channels x RPT consecutive rows -------------------------------------------
+  constexpr int SEGS = BN / 8;            // 16 column segments
+  constexpr int RGS = 512 / SEGS;         // 32 row groups
+  constexpr int RPT = BM / RGS;           // rows per thread
+  const int cs = tid % SEGS, rg = tid / SEGS;
+  const int n = n0 + cs * 8;
+  const bool n_ok = n < p.N;              // N % 8 == 0 (checked on the host)
+  float bias8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+  const bool finish = (p.splitk <= 1);
+  if (finish && n_ok && p.bias != nullptr) {
+    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+    bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
+    bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+  }
+  const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
+  float* part = finish ? nullptr : p.partial + (int64_t)bz * p.M * p.N;
+  float ssum[8], ssq[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    const int row = rg * RPT + k;
+    const int v = v0 + row;
+    const int y = v / W2, x = v - y * W2;
+    if (!n_ok || v >= VR || x >= p.W) continue;
+    const int64_t m = ((int64_t)img * p.H + y) * p.W + x;
+    const float4 t0 = *reinterpret_cast<const float4*>(smem + row * TS + cs * 32);
+    const float4 t1 = *reinterpret_cast<const float4*>(smem + row * TS + cs * 32 + 16);
+    float val[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+    if (!finish) {
+      *reinterpret_cast<float4*>(part + m * p.N + n) = t0;
+      *reinterpret_cast<float4*>(part + m * p.N + n + 4) = t1;
+      continue;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) val[e] += bias8[e];
+    if (res != nullptr) {
+      float rv[8];
+      load8f<T>(res + m * p.ldr + n, rv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) val[e] += rv[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) val[e] = apply_act(val[e], p.act);
+    if (p.out_mode == IG_OUT_ROWMAJOR) store8<T>(reinterpret_cast<T*>(p.out) + m * p.ldo + n, val);
+    else store8<float>(reinterpret_cast<float*>(p.out) + m * p.ldo + n, val);
+    if (p.stats != nullptr) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float sv = (p.out_mode == IG_OUT_ROWMAJOR) ? stored<T>(val[e]) : val[e];
+        ssum[e] += sv;
+        ssq[e] += sv * sv;
+      }
+    }
+  }
+  if (!finish || p.stats == nullptr) return;
+
+  // ---- epilogue 3: per-channel (sum, sumsq) of this tile's stored values, fixed-order reduction ---------
+  __syncthreads();  // tile fully consumed
+  float* red = reinterpret_cast<float*>(smem);  // [RGS][BN][2]
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    *reinterpret_cast<float2*>(red + ((rg * BN) + cs * 8 + e) * 2) = make_float2(ssum[e], ssq[e]);
+  }
+  __syncthreads();
+  if (tid < BN * 2) {
+    const int ch = tid >> 1, which = tid & 1;
+    float a = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < RGS; ++r) a += red[((r * BN) + ch) * 2 + which];
+    if (n0 + ch < p.N) p.stats[((int64_t)bx * p.N + n0 + ch) * 2 + which] = a;
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+static int halo_rows(const IgemmParams& p, int bm) { return (bm + 2 * (p.W + 2) + 2 + 7) & ~7; }
+
+static size_t halo_smem_bytes(const IgemmParams& p, int bm, int nbst) {
+  const size_t main_loop = (size_t)2 * halo_rows(p, bm) * 128 + (size_t)nbst * HALO_BN * 128;
+  const size_t epi = (size_t)bm * (HALO_BN * 4 + 16);
+  const size_t red = (size_t)32 * HALO_BN * 2 * 4;
+  size_t m = main_loop > epi ? main_loop : epi;
+  return m > red ? m : red;
+}
+
+// deepest weight ring (<= 4) that fits the LDS next to the double-buffered halo and still leaves enough
+// halo slots (taps 0 .. 9-NBST, one 8-row piece per wave each); 0 = the problem does not fit at all
+static int halo_pick_nbst(const IgemmParams& p, int bm) {
+  const int np = halo_rows(p, bm) / 8;
+  for (int nbst = 4; nbst >= 2; --nbst) {
+    if (np > (10 - nbst) * HALO_NW) continue;
+    if (halo_smem_bytes(p, bm, nbst) > 160 * 1024) continue;
+    return nbst;
+  }
+  return 0;
+}
+
+bool conv3_halo_supported(const IgemmParams& p, int dtype, int bm) {
+  const int BK = (dtype == K22_BF16) ? 64 : 32;
+  if (p.taps != 9 || (bm != 256 && bm != 128)) return false;
+  if (p.out_mode != IG_OUT_ROWMAJOR && p.out_mode != IG_OUT_ROWMAJOR_F32) return false;
+  if (p.N % 8 || p.ldo % 8 || (p.residual && p.ldr % 8) || p.Kc % BK) return false;
+  if (p.H <= 0 || p.W <= 0 || p.M % (p.H * p.W)) return false;
+  if (halo_pick_nbst(p, bm) == 0) return false;
+  if ((int64_t)(p.H + 2) * (p.W + 2) * p.Kc >= (1ll << 31) || (int64_t)p.Npad * 9 * p.Kc >= (1ll << 31)) return false;
+  return true;
+}
+
+int conv3_halo_tiles_per_image(const IgemmParams& p, int bm) { return (p.H * (p.W + 2) + bm - 1) / bm; }
+
+template <typename T, int BM, int NBST>
+static int launch_halo_cfg(const IgemmParams& p, int splitk, hipStream_t stream) {
+  const size_t smem = halo_smem_bytes(p, BM, NBST);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_kernel<T, BM, NBST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+    attr_set = true;
+  }
+  IgemmParams q = p;
+  q.splitk = splitk;
+  const int B = p.M / (p.H * p.W);
+  const int nblocks = B * conv3_halo_tiles_per_image(p, BM) * ((p.N + HALO_BN - 1) / HALO_BN) * splitk;
+  hipLaunchKernelGGL((conv3_halo_kernel<T, BM, NBST>), dim3(nblocks), dim3(512), smem, stream, q);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+
+template <typename T, int BM>
+static int launch_halo_nbst(const IgemmParams& p, int nbst, int splitk, hipStream_t stream) {
+  if (nbst == 2) return launch_halo_cfg<T, BM, 2>(p, splitk, stream);
+  if (nbst == 3) return launch_halo_cfg<T, BM, 3>(p, splitk, stream);
+  return launch_halo_cfg<T, BM, 4>(p, splitk, stream);
+}
+
+// Launches the halo kernel only (the split-K reduction, if any, is the caller's: launch_igemm).
+int launch_conv3_halo(const IgemmParams& p, int dtype, int bm, int splitk, hipStream_t stream) {
+  if (!conv3_halo_supported(p, dtype, bm)) return k22_set_error(K22_EINVAL, "conv3_halo: unsupported problem");
+  int nbst = halo_pick_nbst(p, bm);
+  if (p.stages >= 2 && p.stages < nbst) nbst = p.stages;  // tuning knob: shallower ring on request
+  if (dtype == K22_BF16) return bm == 256 ? launch_halo_nbst<bf16_t, 256>(p, nbst, splitk, stream) : launch_halo_nbst<bf16_t, 128>(p, nbst, splitk, stream);
+  return bm == 256 ? launch_halo_nbst<float, 256>(p, nbst, splitk, stream) : launch_halo_nbst<float, 128>(p, nbst, splitk, stream);
+}

@@ -6,10 +6,14 @@
 struct GnStatsParams {
   const void* x0; const void* x1;   // NHWC [B][HW][C0] (+ [B][HW][C1] virtual concat)
   int C0, C1, HW, B, groups, nsplit;
-  float* partial;                    // [B][nsplit][64] = (sum, sumsq) x 32 groups
+  float* partial;                    // [B][nsplit][C][2] = per-channel (sum, sumsq) of each pixel range
 };
+// Per-channel partial sums of one tensor: image b owns rows [b*rpi, (b+1)*rpi) of st[rows][C][2].  Written by
+// gn_stats_kernel or by the producing convolution's epilogue (conv3_halo.hip / splitk_reduce_rows_kernel).
+struct GnSrc { const float* st; int rpi, C; };
 struct GnCoeffParams {
-  const float* partial; int nsplit, HW, C, groups; float eps;
+  GnSrc src[2];                            // src[1].C == 0 when the input is not a virtual concat
+  int HW, C, groups; float eps;
   const float* gamma; const float* beta;  // [C]
   const float* film; int64_t film_ld;      // optional [B][film_ld]: scale at +c, shift at +C+c
   float* coeff;                            // [B][C][2] = (A, Bc):  y = x*A + Bc
@@ -36,6 +40,7 @@ struct LinearSmallParams {
   const float* add; int64_t ld_add;  // optional [M][N] added after the output activation
   float* out; int64_t ldo;
   int M, N, K, act_in, act_out;
+  int rows_per_wave;  // set by the launcher
 };
 struct KvPackParams {
   const void* qkv; const void* ctxkv; void* kall; void* vtall;

@@ -24,26 +24,29 @@ __device__ __forceinline__ void load4(const float* p, float* f) {
   f[0] = r.x; f[1] = r.y; f[2] = r.z; f[3] = r.w;
 }
 
-// ---- GroupNorm pass 1: per (batch, pixel-range) partial sums of x and x^2 per group ------------
-// grid (nsplit, B), 256 threads. Threads own fixed channel vectors so the sums stay in registers;
-// pixels of the block's range are walked with every wave reading whole contiguous NHWC rows.
+// ---- GroupNorm pass 1 (stand-alone form): per (batch, pixel-range) partial sums of x and x^2 per CHANNEL ----
+// grid (nsplit, B), 256 threads. Threads own fixed 4-channel vectors so the sums stay in registers; pixels of
+// the block's range are walked with every wave reading whole contiguous NHWC rows.  (Tensors produced by the
+// 3x3 convolutions arrive with these sums already computed by the conv epilogue; this kernel serves the rest.)
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(GnStatsParams p) {
-  __shared__ float red[2][768];
+  __shared__ float red[1024 * 2 * 2];  // [pl][C][2] with PL*C <= 2048
   const int tid = threadIdx.x, b = blockIdx.y, s = blockIdx.x;
-  const int C = p.C0 + p.C1, cg = C / p.groups, VP = C / 4;
+  const int C = p.C0 + p.C1, VP = C / 4;
   const int per = (p.HW + p.nsplit - 1) / p.nsplit;
   const int pix0 = s * per, pix1 = min(p.HW, pix0 + per);
   const T* x0 = reinterpret_cast<const T*>(p.x0) + (int64_t)b * p.HW * p.C0;
   const T* x1 = p.x1 ? reinterpret_cast<const T*>(p.x1) + (int64_t)b * p.HW * p.C1 : nullptr;
   int PL, pl;
   if (VP >= 256) { PL = 1; pl = 0; } else { PL = 256 / VP; pl = tid / VP; }
-  float sum[3] = {0.f, 0.f, 0.f}, sq[3] = {0.f, 0.f, 0.f};
+  float sum[3][4], sq[3][4];
   int vj[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     int v = (VP >= 256) ? tid + 256 * j : ((j == 0 && pl < PL) ? tid - pl * VP : VP);
     vj[j] = v < VP ? v : -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sum[j][k] = 0.f; sq[j][k] = 0.f; }
   }
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -61,70 +64,92 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnStatsParams p) {
         load4(src + (int64_t)(pix + 3 * PL) * ld, f3);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          sum[j] += (f0[k] + f1[k]) + (f2[k] + f3[k]);
-          sq[j] += (f0[k] * f0[k] + f1[k] * f1[k]) + (f2[k] * f2[k] + f3[k] * f3[k]);
+          sum[j][k] += (f0[k] + f1[k]) + (f2[k] + f3[k]);
+          sq[j][k] += (f0[k] * f0[k] + f1[k] * f1[k]) + (f2[k] * f2[k] + f3[k] * f3[k]);
         }
       }
       for (; pix < pix1; pix += PL) {
         float f[4];
         load4(src + (int64_t)pix * ld, f);
-        sum[j] += (f[0] + f[1]) + (f[2] + f[3]);
-        sq[j] += (f[0] * f[0] + f[1] * f[1]) + (f[2] * f[2] + f[3] * f[3]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { sum[j][k] += f[k]; sq[j][k] += f[k] * f[k]; }
       }
     }
   }
-  // deterministic block reduction: slot (pl, v) -> red[.][pl*VP + v]; group g owns a contiguous v range
+  float* out = p.partial + ((int64_t)b * p.nsplit + s) * C * 2;
+  if (PL == 1) {
 #pragma unroll
-  for (int j = 0; j < 3; ++j)
-    if (vj[j] >= 0) { red[0][pl * VP + vj[j]] = sum[j]; red[1][pl * VP + vj[j]] = sq[j]; }
+    for (int j = 0; j < 3; ++j)
+      if (vj[j] >= 0) {
+        float* o = out + (int64_t)vj[j] * 8;
+        *reinterpret_cast<float4*>(o) = make_float4(sum[j][0], sq[j][0], sum[j][1], sq[j][1]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(sum[j][2], sq[j][2], sum[j][3], sq[j][3]);
+      }
+    return;
+  }
+  // deterministic reduction over the PL pixel lanes (only slot j == 0 is in use when VP < 256)
+  if (vj[0] >= 0) {
+    float* o = red + ((int64_t)pl * C + vj[0] * 4) * 2;
+    *reinterpret_cast<float4*>(o) = make_float4(sum[0][0], sq[0][0], sum[0][1], sq[0][1]);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(sum[0][2], sq[0][2], sum[0][3], sq[0][3]);
+  }
   __syncthreads();
-  if (tid < 2 * p.groups) {
-    const int g = tid >> 1, which = tid & 1, vpg = cg / 4;
+  for (int i = tid; i < C * 2; i += 256) {
     float a = 0.f;
-    for (int q = 0; q < PL; ++q)
-      for (int v = g * vpg; v < (g + 1) * vpg; ++v) a += red[which][q * VP + v];
-    p.partial[((int64_t)b * p.nsplit + s) * 64 + tid] = a;
+    for (int q = 0; q < PL; ++q) a += red[(int64_t)q * C * 2 + i];
+    out[i] = a;
   }
 }
 
 // ---- GroupNorm pass 2: fold mean/rstd, gamma/beta and FiLM into y = x*A[c] + Bc[c] -------------
-// grid (B), 256 threads.  coeff[b][c] = (A, Bc).
-__global__ __launch_bounds__(256) void gn_coeff_kernel(GnCoeffParams p) {
-  __shared__ double part[4][64];
-  __shared__ float mean_s[32], rstd_s[32];
-  const int tid = threadIdx.x, b = blockIdx.x;
-  {
-    // 64 (sum, sumsq) columns x 4 row-interleaved partial sums, fixed order => deterministic
-    const int col = tid & 63, q = tid >> 6;
-    double a = 0.0;
-    for (int i = q; i < p.nsplit; i += 4) a += (double)p.partial[((int64_t)b * p.nsplit + i) * 64 + col];
-    part[q][col] = a;
-  }
-  __syncthreads();
-  if (tid < p.groups) {
-    const double s = (part[0][2 * tid] + part[1][2 * tid]) + (part[2][2 * tid] + part[3][2 * tid]);
-    const double q = (part[0][2 * tid + 1] + part[1][2 * tid + 1]) + (part[2][2 * tid + 1] + part[3][2 * tid + 1]);
-    const double n = (double)p.HW * (double)(p.C / p.groups);
-    const double mean = s / n;
-    double var = q / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    mean_s[tid] = (float)mean;
-    rstd_s[tid] = (float)(1.0 / sqrt(var + (double)p.eps));
-  }
-  __syncthreads();
+// grid (groups, B), one wave per (batch, group): lanes sum the per-channel partials of the group's channels
+// over all row blocks in a fixed strided order (fp64, deterministic), butterfly-reduce, then write
+// coeff[b][c] = (A, Bc).  The input may be a virtual concat of two tensors (a group may straddle them).
+__global__ __launch_bounds__(64) void gn_coeff_kernel(GnCoeffParams p) {
+  const int lane = threadIdx.x, g = blockIdx.x, b = blockIdx.y;
   const int cg = p.C / p.groups;
-  for (int c = tid; c < p.C; c += 256) {
-    const int g = c / cg;
-    float A = rstd_s[g] * p.gamma[c];
-    float Bc = p.beta[c] - mean_s[g] * A;
+  double s = 0.0, q = 0.0;
+  int off = 0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const GnSrc sr = p.src[k];
+    if (sr.C > 0) {
+      const int c_lo = max(g * cg, off), c_hi = min((g + 1) * cg, off + sr.C);
+      const int nc = c_hi - c_lo;
+      if (nc > 0) {
+        const float* base = sr.st + ((int64_t)b * sr.rpi * sr.C + (c_lo - off)) * 2;
+        const int items = sr.rpi * nc;
+        for (int i = lane; i < items; i += 64) {
+          const int r = i / nc, cc = i - r * nc;
+          const float2 v = *reinterpret_cast<const float2*>(base + ((int64_t)r * sr.C + cc) * 2);
+          s += (double)v.x;
+          q += (double)v.y;
+        }
+      }
+    }
+    off += sr.C;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    q += __shfl_xor(q, o, 64);
+  }
+  const double n = (double)p.HW * (double)cg;
+  const double mean = s / n;
+  double var = q / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float mean_f = (float)mean;
+  const float rstd_f = (float)(1.0 / sqrt(var + (double)p.eps));
+  for (int c = g * cg + lane; c < (g + 1) * cg; c += 64) {
+    float A = rstd_f * p.gamma[c];
+    float Bc = p.beta[c] - mean_f * A;
     if (p.film != nullptr) {
       const float sc = 1.f + p.film[(int64_t)b * p.film_ld + c];
       const float sh = p.film[(int64_t)b * p.film_ld + p.C + c];
       A *= sc;
       Bc = Bc * sc + sh;
     }
-    p.coeff[((int64_t)b * p.C + c) * 2] = A;
-    p.coeff[((int64_t)b * p.C + c) * 2 + 1] = Bc;
+    *reinterpret_cast<float2*>(p.coeff + ((int64_t)b * p.C + c) * 2) = make_float2(A, Bc);
   }
 }
 
@@ -280,38 +305,47 @@ __global__ void timestep_embedding_kernel(const float* t, const float* freqs, fl
 }
 
 // ---- skinny linear: out[m][n] = act_out( sum_k act_in(x[m][k]) * W[n][k] + bias[n] ) + add[m][n]
-// M <= 8 rows, one wave per output feature, weights streamed once (HBM-bound GEMV).
-template <typename TW>
+// M <= 8 rows.  HBM-bound GEMV: the weights are streamed exactly once (16 B per lane per load, one wave
+// per output feature, several features per wave); act_in(x) is staged ONCE per workgroup in LDS as fp32.
+template <typename TW, int MT>
 __global__ __launch_bounds__(256) void linear_smallm_kernel(LinearSmallParams p) {
   constexpr int EPC = 16 / sizeof(TW);
-  const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= p.N) return;
-  const TW* w = reinterpret_cast<const TW*>(p.W) + (int64_t)n * p.K;
-  float acc[8];
+  extern __shared__ __attribute__((aligned(16))) char smem_lin[];
+  float* xs = reinterpret_cast<float*>(smem_lin);  // [M][K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < MT * p.K; i += 256) {
+    const int m = i / p.K, k = i - m * p.K;
+    float xv = m < p.M ? p.x[(int64_t)m * p.ldx + k] : 0.f;  // template rows beyond p.M are zero
+    if (p.act_in == K22_ACT_SILU) xv = silu_f(xv);
+    xs[i] = xv;
+  }
+  __syncthreads();
+  const int per_wave = p.rows_per_wave;
+  const int n_begin = (blockIdx.x * 4 + wave) * per_wave;
+  for (int r = 0; r < per_wave; ++r) {
+    const int n = n_begin + r;
+    if (n >= p.N) return;
+    const TW* w = reinterpret_cast<const TW*>(p.W) + (int64_t)n * p.K;
+    float acc[MT];
 #pragma unroll
-  for (int m = 0; m < 8; ++m) acc[m] = 0.f;
-  for (int k = lane * EPC; k < p.K; k += 64 * EPC) {
-    Vec16<TW> wv;
-    wv.raw = *reinterpret_cast<const decltype(wv.raw)*>(w + k);
+    for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+    for (int k = lane * EPC; k < p.K; k += 64 * EPC) {
+      Vec16<TW> wv;
+      wv.raw = *reinterpret_cast<const decltype(wv.raw)*>(w + k);
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      if (m < p.M) {
-        const float* xr = p.x + (int64_t)m * p.ldx + k;
+      for (int m = 0; m < MT; ++m) {
+        const float* xr = xs + m * p.K + k;
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-          float xv = xr[e];
-          if (p.act_in == K22_ACT_SILU) xv = silu_f(xv);
-          acc[m] += xv * wv.get(e);
+        for (int e = 0; e < EPC; e += 4) {
+          const float4 xv = *reinterpret_cast<const float4*>(xr + e);
+          acc[m] += xv.x * wv.get(e) + xv.y * wv.get(e + 1) + xv.z * wv.get(e + 2) + xv.w * wv.get(e + 3);
         }
       }
     }
-  }
 #pragma unroll
-  for (int m = 0; m < 8; ++m) {
-    if (m < p.M) {
+    for (int m = 0; m < MT; ++m) {
       float v = wave_sum(acc[m]);
-      if (lane == 0) {
+      if (lane == 0 && m < p.M) {
         if (p.bias) v += p.bias[n];
         v = apply_act(v, p.act_out);
         if (p.add) v += p.add[(int64_t)m * p.ld_add + n];
@@ -397,9 +431,11 @@ static inline int grid_for(int64_t total, int threads, int cap) {
 }
 
 int gn_nsplit(int B, int HW) {
-  int ns = 1024 / (B > 0 ? B : 1);
-  if (ns > 256) ns = 256;
-  while (ns > 1 && HW / ns < 8) ns >>= 1;
+  // pixel ranges per image: enough workgroups to fill the chip on the big levels, but few enough that the
+  // [nsplit][C][2] partials stay small next to the tensor (>= 32 pixels per range)
+  int ns = 512 / (B > 0 ? B : 1);
+  if (ns > 128) ns = 128;
+  while (ns > 1 && HW / ns < 32) ns >>= 1;
   return ns < 1 ? 1 : ns;
 }
 
@@ -407,6 +443,7 @@ int launch_gn_stats(const GnStatsParams& p, int dtype, hipStream_t s) {
   const int C = p.C0 + p.C1;
   if (p.groups != 32 || C % 128 != 0 || p.C0 % 4 != 0) return k22_set_error(K22_EINVAL, "gn_stats: need 32 groups, C % 128 == 0");
   if (C / 4 > 768) return k22_set_error(K22_EINVAL, "gn_stats: C too large (max 3072)");
+  if (C / 4 < 256 && (256 / (C / 4)) * C > 2048) return k22_set_error(K22_EINVAL, "gn_stats: internal LDS bound");
   dim3 grid(p.nsplit, p.B);
   if (dtype == K22_BF16) hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, s, p);
@@ -414,7 +451,7 @@ int launch_gn_stats(const GnStatsParams& p, int dtype, hipStream_t s) {
   return K22_OK;
 }
 int launch_gn_coeff(const GnCoeffParams& p, int B, hipStream_t s) {
-  hipLaunchKernelGGL(gn_coeff_kernel, dim3(B), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(gn_coeff_kernel, dim3(p.groups, B), dim3(64), 0, s, p);
   K22_CHECK_LAUNCH();
   return K22_OK;
 }
@@ -459,13 +496,30 @@ int launch_timestep_embedding(const float* t, const float* freqs, float* out, in
   K22_CHECK_LAUNCH();
   return K22_OK;
 }
-int launch_linear_smallm(const LinearSmallParams& p, int wdtype, hipStream_t s) {
-  if (p.M > 8) return k22_set_error(K22_EINVAL, "linear_smallm: M must be <= 8");
+template <typename TW>
+static void launch_linear_m(const LinearSmallParams& p, int Mt, dim3 grid, size_t smem, hipStream_t s) {
+  switch (Mt) {
+    case 1: hipLaunchKernelGGL((linear_smallm_kernel<TW, 1>), grid, dim3(256), smem, s, p); break;
+    case 2: hipLaunchKernelGGL((linear_smallm_kernel<TW, 2>), grid, dim3(256), smem, s, p); break;
+    case 4: hipLaunchKernelGGL((linear_smallm_kernel<TW, 4>), grid, dim3(256), smem, s, p); break;
+    default: hipLaunchKernelGGL((linear_smallm_kernel<TW, 8>), grid, dim3(256), smem, s, p); break;
+  }
+}
+int launch_linear_smallm(const LinearSmallParams& p0, int wdtype, hipStream_t s) {
+  if (p0.M > 8 || p0.M < 1) return k22_set_error(K22_EINVAL, "linear_smallm: M must be in 1..8");
   const int epc = wdtype == K22_BF16 ? 8 : 4;
-  if (p.K % epc) return k22_set_error(K22_EINVAL, "linear_smallm: K alignment");
-  dim3 grid((p.N + 3) / 4);
-  if (wdtype == K22_BF16) hipLaunchKernelGGL(linear_smallm_kernel<bf16_t>, grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL(linear_smallm_kernel<float>, grid, dim3(256), 0, s, p);
+  if (p0.K % epc) return k22_set_error(K22_EINVAL, "linear_smallm: K alignment");
+  const int Mt = p0.M <= 2 ? p0.M : (p0.M <= 4 ? 4 : 8);  // rows the kernel is instantiated for
+  const size_t smem = (size_t)Mt * p0.K * 4;
+  if (smem > 64 * 1024) return k22_set_error(K22_EINVAL, "linear_smallm: M*K too large for the LDS stage");
+  LinearSmallParams p = p0;
+  // several features per wave when N is large (the LDS stage of x is amortised), still >= 1024 workgroups
+  int rpw = 1;
+  while (rpw < 8 && (p.N + 8 * rpw - 1) / (8 * rpw) >= 1024) rpw *= 2;
+  p.rows_per_wave = rpw;
+  dim3 grid((p.N + 4 * rpw - 1) / (4 * rpw));
+  if (wdtype == K22_BF16) launch_linear_m<bf16_t>(p, Mt, grid, smem, s);
+  else launch_linear_m<float>(p, Mt, grid, smem, s);
   K22_CHECK_LAUNCH();
   return K22_OK;
 }

@@ -15,10 +15,14 @@
 
 #include <deque>
 #include <functional>
+#include <map>
 #include <memory>
 #include <string>
+#include <tuple>
 #include <unordered_map>
 #include <vector>
+#include <stdio.h>
+#include <stdlib.h>
 
 int launch_step_advance(int* step, int delta, hipStream_t s);
 
@@ -40,10 +44,28 @@ struct Op {
 };
 typedef std::vector<Op> OpList;
 
+// One tile configuration of launch_igemm: algo 1 = generic implicit GEMM (bm x bn tile, LDS-DMA depth `stages`),
+// algo 2 = LDS-resident halo kernel for 3x3 convolutions (bm = 256 / 128); splitk >= 1.
+struct Cfg { int algo = 0, bm = 0, bn = 0, splitk = 0, stages = 0; };
+
+// A conv / GEMM launch whose configuration is chosen by measurement on the device (k22_unet_forward, first call).
+struct Tuned {
+  IgemmParams p = {};          // problem; device pointers are filled in at launch time
+  std::vector<Cfg> cands;
+  Cfg cfg;                     // current choice (heuristic until tuned)
+  bool want_stats = false;     // epilogue also emits the GroupNorm partial sums of its output
+  int rpi = 0;                 // stats rows per image under cfg
+  float best_us = 0.f;
+  std::function<int(hipStream_t)> run;
+};
+
 struct Act {  // unpadded NHWC activation, optionally a virtual channel concat of two tensors
   Slot* s0 = nullptr; int C0 = 0;
   Slot* s1 = nullptr; int C1 = 0;
   int H = 0, W = 0;
+  // GroupNorm partial sums delivered by the producing convolution (null = none: run gn_stats_kernel)
+  const Tuned* p0 = nullptr; Slot* st0 = nullptr;
+  const Tuned* p1 = nullptr; Slot* st1 = nullptr;
   int C() const { return C0 + C1; }
 };
 
@@ -59,6 +81,9 @@ struct K22UNet {
   std::deque<Slot> slots;
   OpList ops;       // one UNet forward
   OpList cond_ops;  // conditioning head
+  std::deque<Tuned> tuned;  // stable addresses: op closures and Act descriptors point into it
+  bool tuned_done = false;
+  int autotune = 1;
   size_t ws_bytes = 0;
   char* ws = nullptr;
   bool cond_set = false;
@@ -70,8 +95,10 @@ struct K22UNet {
   Slot *s_xin, *s_img, *s_mask, *s_t, *s_out;
   Slot *s_temb, *s_e1, *s_emb, *s_film, *s_xfproj, *s_ctx;
   Slot *s_full, *s_pool, *s_imgemb, *s_tmpf, *s_tmpf2, *s_fullT;
-  Slot *s_part, *s_coeff, *s_P1, *s_U1, *s_P2, *s_S, *s_N, *s_QKV, *s_KALL, *s_VT, *s_ATT, *s_splitk;
+  Slot *s_part, *s_coeff, *s_P1, *s_U1, *s_P2, *s_S, *s_N, *s_QKV, *s_KALL, *s_VT, *s_ATT, *s_splitk, *s_flush;
+  Slot *s_U1st;
   Slot* s_h[3];
+  Slot* s_hst[3];
   std::vector<Slot*> s_ctxkv;  // one per attention block
   int n_attn = 0;
   int64_t film_total = 0;
@@ -97,7 +124,9 @@ struct K22UNet {
              int act, int mode, int pad, Slot* dst) {
     const int Bn = B, C = in.C(), HW = in.H * in.W;
     const int nsplit = gn_nsplit(Bn, HW);
-    need(s_part, (size_t)Bn * nsplit * 64 * sizeof(float));
+    // producer-side partial sums for every part of the input?  Otherwise the stand-alone stats pass.
+    const bool fused = in.st0 != nullptr && (in.s1 == nullptr || in.st1 != nullptr);
+    if (!fused) need(s_part, (size_t)Bn * nsplit * C * 2 * sizeof(float));
     need(s_coeff, (size_t)Bn * C * 2 * sizeof(float));
     const int Ho = mode == 1 ? in.H / 2 : (mode == 2 ? in.H * 2 : in.H);
     const int Wo = mode == 1 ? in.W / 2 : (mode == 2 ? in.W * 2 : in.W);
@@ -106,80 +135,224 @@ struct K22UNet {
     const float* beta = Wf(pfx + ".bias");
     const Act a = in;
     const int dt = dtype;
-    const double gn_bytes = (double)Bn * HW * C * esz * 2.0 + (double)Bn * (Ho + 2 * pad) * (Wo + 2 * pad) * C * esz;
+    const double gn_bytes = (double)Bn * HW * C * esz * (fused ? 1.0 : 2.0) + (double)Bn * (Ho + 2 * pad) * (Wo + 2 * pad) * C * esz;
     L.push_back(Op([=](hipStream_t st) {
-      GnStatsParams sp;
-      sp.x0 = ptr(a.s0); sp.x1 = a.s1 ? ptr(a.s1) : nullptr; sp.C0 = a.C0; sp.C1 = a.C1;
-      sp.HW = HW; sp.B = Bn; sp.groups = 32; sp.nsplit = nsplit; sp.partial = ptr<float>(s_part);
-      int rc = launch_gn_stats(sp, dt, st);
-      if (rc) return rc;
-      GnCoeffParams cp;
-      cp.partial = ptr<float>(s_part); cp.nsplit = nsplit; cp.HW = HW; cp.C = C; cp.groups = 32; cp.eps = 1e-5f;
+      const void* x0 = ptr(a.s0);
+      const void* x1 = a.s1 ? ptr(a.s1) : nullptr;
+      GnCoeffParams cp = {};
+      if (fused) {
+        cp.src[0].st = ptr<float>(a.st0); cp.src[0].rpi = a.p0->rpi; cp.src[0].C = a.C0;
+        if (a.s1) { cp.src[1].st = ptr<float>(a.st1); cp.src[1].rpi = a.p1->rpi; cp.src[1].C = a.C1; }
+        if (cp.src[0].rpi <= 0 || (a.s1 && cp.src[1].rpi <= 0)) return k22_set_error(K22_EINVAL, "unet: producer delivered no GroupNorm partial sums");
+      } else {
+        GnStatsParams sp;
+        sp.x0 = x0; sp.x1 = x1; sp.C0 = a.C0; sp.C1 = a.C1;
+        sp.HW = HW; sp.B = Bn; sp.groups = 32; sp.nsplit = nsplit; sp.partial = ptr<float>(s_part);
+        int rc = launch_gn_stats(sp, dt, st);
+        if (rc) return rc;
+        cp.src[0].st = ptr<float>(s_part); cp.src[0].rpi = nsplit; cp.src[0].C = C;
+      }
+      cp.HW = HW; cp.C = C; cp.groups = 32; cp.eps = 1e-5f;
       cp.gamma = gamma; cp.beta = beta;
       cp.film = film_off >= 0 ? ptr<float>(s_film) + film_off : nullptr; cp.film_ld = film_total;
       cp.coeff = ptr<float>(s_coeff);
-      rc = launch_gn_coeff(cp, Bn, st);
+      int rc = launch_gn_coeff(cp, Bn, st);
       if (rc) return rc;
       GnApplyParams ap;
-      ap.x0 = sp.x0; ap.x1 = sp.x1; ap.C0 = a.C0; ap.C1 = a.C1; ap.B = Bn; ap.H = a.H; ap.W = a.W;
+      ap.x0 = x0; ap.x1 = x1; ap.C0 = a.C0; ap.C1 = a.C1; ap.B = Bn; ap.H = a.H; ap.W = a.W;
       ap.mode = mode; ap.pad = pad; ap.act = act; ap.coeff = ptr<float>(s_coeff); ap.out = ptr(dst);
       return launch_gn_apply(ap, dt, st);
-    }, OP_GN, 0.0, gn_bytes, 3));
+    }, OP_GN, 0.0, gn_bytes, fused ? 2 : 3));
   }
 
-  // conv3x3 over a zero-bordered slot `src` [B][Hc+2][Wc+2][Cin]
-  void op_conv(OpList& L, Slot* src, int Hc, int Wc, int Cin, int Cout,
-               const std::string& pfx, const Act* residual, Slot* dst, int out_mode) {
-    IgemmParams p = {};
+  // ---- tile-configuration candidates of one conv / GEMM problem ----------------------------------
+  static void apply_cfg(IgemmParams& q, const Cfg& c) {
+    q.algo = c.algo; q.force_bm = c.bm; q.force_bn = c.bn; q.splitk = c.splitk; q.stages = c.stages;
+  }
+  void make_candidates(Tuned& t) {
+    const IgemmParams& p = t.p;
+    const int BK = dtype == K22_BF16 ? 64 : 32;
+    const int nkt = p.taps * (p.Kc / BK);
+    std::vector<Cfg> all;
+    if (p.taps == 9) {
+      const int nslab = p.Kc / BK;
+      for (int bm : {256, 128}) {
+        if (!conv3_halo_supported(p, dtype, bm) || p.N < 128) continue;
+        const int nb = B * conv3_halo_tiles_per_image(p, bm) * ((p.N + 127) / 128);
+        for (int sk : {1, 2, 3, 4, 6, 8, 12}) {
+          if (sk > nslab || (sk > 1 && nb * sk > 1024) || (sk > 1 && nb >= 256)) continue;
+          Cfg c; c.algo = 2; c.bm = bm; c.bn = 0; c.splitk = sk; c.stages = 0;
+          all.push_back(c);
+        }
+      }
+    }
+    const int tiles[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+    for (auto& tl : tiles) {
+      if (tl[1] == 128 && p.N <= 64) continue;
+      if (tl[0] == 128 && p.M <= 64) continue;
+      const int nb = ((p.M + tl[0] - 1) / tl[0]) * ((p.N + tl[1] - 1) / tl[1]);
+      for (int sk : {1, 2, 4, 8, 16}) {
+        if (sk > 1 && (nkt / sk < 4 || nb * sk > 1536 || nb >= 384)) continue;
+        Cfg c; c.algo = 1; c.bm = tl[0]; c.bn = tl[1]; c.splitk = sk; c.stages = 2;
+        all.push_back(c);
+      }
+    }
+    // keep what can deliver the requested side output and whose split-K scratch stays reasonable
+    t.cands.clear();
+    for (auto& c : all) {
+      IgemmParams q = p;
+      apply_cfg(q, c);
+      if ((size_t)c.splitk * p.M * p.N * sizeof(float) > ((size_t)96 << 20) && c.splitk > 1) continue;
+      if (t.want_stats && igemm_stats_rows_per_image(q, dtype) <= 0) continue;
+      t.cands.push_back(c);
+    }
+  }
+  // heuristic starting point (also the final choice when auto-tuning is off)
+  void default_cfg(Tuned& t) {
+    IgemmParams q = t.p;
+    q.algo = 0; q.force_bm = 0; q.force_bn = 0; q.splitk = 0; q.stages = 0;
+    Cfg c; c.algo = 0; c.bm = 0; c.bn = 0; c.splitk = igemm_choose_splitk(q, dtype); c.stages = 0;
+    apply_cfg(q, c);
+    if (t.want_stats && igemm_stats_rows_per_image(q, dtype) <= 0) {
+      if (t.cands.empty()) { t.want_stats = false; }
+      else c = t.cands[0];
+    }
+    t.cfg = c;
+    finish_cfg(t);
+  }
+  void finish_cfg(Tuned& t) {
+    IgemmParams q = t.p;
+    apply_cfg(q, t.cfg);
+    t.rpi = t.want_stats ? igemm_stats_rows_per_image(q, dtype) : 0;
+  }
+  size_t max_splitk_bytes(const Tuned& t) const {
+    size_t m = 0;
+    auto upd = [&](const Cfg& c) { if (c.splitk > 1) m = std::max(m, (size_t)c.splitk * t.p.M * t.p.N * sizeof(float)); };
+    upd(t.cfg);
+    if (autotune) for (auto& c : t.cands) upd(c);
+    return m;
+  }
+  int max_rpi(const Tuned& t) const {
+    int m = t.rpi;
+    if (autotune) for (auto& c : t.cands) { IgemmParams q = t.p; apply_cfg(q, c); m = std::max(m, igemm_stats_rows_per_image(q, dtype)); }
+    return m;
+  }
+
+  // conv3x3 over a zero-bordered slot `src` [B][Hc+2][Wc+2][Cin].  `stats` (optional) receives the GroupNorm
+  // partial sums of the output; returns the launch descriptor (null when the output is not a tunable T tensor).
+  Tuned* op_conv(OpList& L, Slot* src, int Hc, int Wc, int Cin, int Cout,
+                 const std::string& pfx, const Act* residual, Slot* dst, int out_mode, Slot* stats = nullptr) {
+    tuned.emplace_back();
+    Tuned* t = &tuned.back();
+    IgemmParams& p = t->p;
     p.stages = -1;
     p.M = B * Hc * Wc; p.N = Cout; p.Npad = (Cout + 63) / 64 * 64; p.Kc = Cin; p.K0 = Cin; p.taps = 9;
     p.H = Hc; p.W = Wc; p.ldo = Cout; p.ldr = Cout; p.out_mode = out_mode; p.act = K22_ACT_NONE;
     p.Wp = W_(pfx + ".weight"); p.bias = Wf(pfx + ".bias");
-    p.splitk = igemm_choose_splitk(p, dtype);
-    if (p.splitk > 1) need(s_splitk, (size_t)p.splitk * p.M * p.N * sizeof(float));
+    t->want_stats = stats != nullptr;
+    make_candidates(*t);
+    default_cfg(*t);
+    need(s_splitk, max_splitk_bytes(*t));
+    if (t->want_stats) need(stats, (size_t)B * max_rpi(*t) * Cout * 2 * sizeof(float));
     need(dst, out_mode == IG_OUT_ROWMAJOR ? (size_t)p.M * Cout * esz : (size_t)p.M * Cout * sizeof(float));
     Slot* rs = residual ? residual->s0 : nullptr;
     const int dt = dtype;
-    L.push_back(Op([=](hipStream_t st) {
-      IgemmParams q = p;
+    t->run = [=](hipStream_t st) {
+      IgemmParams q = t->p;
+      apply_cfg(q, t->cfg);
       q.A0 = ptr(src); q.residual = rs ? ptr(rs) : nullptr; q.out = ptr(dst); q.partial = ptr<float>(s_splitk);
+      q.stats = t->want_stats ? ptr<float>(stats) : nullptr;
       return launch_igemm(q, dt, st);
-    }, OP_CONV3, 2.0 * p.M * (double)p.N * 9.0 * p.Kc, 0.0, p.splitk > 1 ? 2 : 1));
+    };
+    L.push_back(Op([=](hipStream_t st) { return t->run(st); }, OP_CONV3, 2.0 * p.M * (double)p.N * 9.0 * p.Kc, 0.0, 1));
+    return t;
   }
 
   // GEMM over unpadded rows (1x1 conv / linear); `in` may be a virtual concat.
-  void op_gemm(OpList& L, const Act& in, int M, int N, const std::string& pfx,
-               const Act* residual, Slot* dst, int ldo = 0) {
-    IgemmParams p = {};
+  Tuned* op_gemm(OpList& L, const Act& in, int M, int N, const std::string& pfx,
+                 const Act* residual, Slot* dst, int ldo = 0) {
+    tuned.emplace_back();
+    Tuned* t = &tuned.back();
+    IgemmParams& p = t->p;
     p.stages = -1;
     p.M = M; p.N = N; p.Npad = (N + 63) / 64 * 64; p.Kc = in.C(); p.K0 = in.C0; p.taps = 1;
     p.lda0 = in.C0; p.lda1 = in.C1; p.ldo = ldo ? ldo : N; p.ldr = N; p.out_mode = IG_OUT_ROWMAJOR;
     p.act = K22_ACT_NONE;
     p.Wp = W_(pfx + ".weight"); p.bias = Wf(pfx + ".bias");
-    p.splitk = igemm_choose_splitk(p, dtype);
-    if (p.splitk > 1) need(s_splitk, (size_t)p.splitk * p.M * p.N * sizeof(float));
+    make_candidates(*t);
+    default_cfg(*t);
+    need(s_splitk, max_splitk_bytes(*t));
     need(dst, (size_t)M * p.ldo * esz);
     const Act a = in;
     Slot* rs = residual ? residual->s0 : nullptr;
     const int dt = dtype;
-    L.push_back(Op([=](hipStream_t st) {
-      IgemmParams q = p;
+    t->run = [=](hipStream_t st) {
+      IgemmParams q = t->p;
+      apply_cfg(q, t->cfg);
       q.A0 = ptr(a.s0); q.A1 = a.s1 ? ptr(a.s1) : nullptr;
       q.residual = rs ? ptr(rs) : nullptr; q.out = ptr(dst); q.partial = ptr<float>(s_splitk);
       return launch_igemm(q, dt, st);
-    }, OP_GEMM, 2.0 * p.M * (double)p.N * p.Kc, 0.0, p.splitk > 1 ? 2 : 1));
+    };
+    L.push_back(Op([=](hipStream_t st) { return t->run(st); }, OP_GEMM, 2.0 * p.M * (double)p.N * p.Kc, 0.0, 1));
+    return t;
+  }
+
+  // Measures every candidate of every distinct problem on the device (weights evicted from the Infinity Cache
+  // between runs: in a real step they stream from HBM) and keeps the fastest.  Outputs written meanwhile are
+  // garbage; the caller runs the real forward afterwards.
+  int tune_all(hipStream_t st) {
+    typedef std::tuple<int, int, int, int, int, int, int, int, bool, bool> Key;
+    std::map<Key, std::pair<Cfg, float>> cache;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return k22_set_error(K22_EHIP, "tune: hipEventCreate");
+    int rc = K22_OK;
+    for (auto& t : tuned) {
+      if (!t.run || t.cands.size() < 2) continue;
+      const IgemmParams& p = t.p;
+      if (p.M < 64) continue;  // conditioning-head GEMMs: not worth it
+      const Key key(p.taps, p.M, p.N, p.Kc, p.K0, p.H, p.W, p.out_mode, t.want_stats, false);
+      auto it = cache.find(key);
+      if (it == cache.end()) {
+        Cfg best = t.cfg; float best_ms = 1e30f;
+        for (auto& c : t.cands) {
+          t.cfg = c;
+          finish_cfg(t);
+          float tmin = 1e30f;
+          for (int rep = 0; rep < 3 && rc == K22_OK; ++rep) {
+            if (s_flush->bytes) (void)hipMemsetAsync(ptr(s_flush), 0, s_flush->bytes, st);
+            (void)hipEventRecord(e0, st);
+            rc = t.run(st);
+            (void)hipEventRecord(e1, st);
+            if (hipStreamSynchronize(st) != hipSuccess) rc = k22_set_error(K22_EHIP, "tune: kernel failed");
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (rep > 0 && ms < tmin) tmin = ms;  // rep 0 = warm-up (code load, function attributes)
+          }
+          if (rc) break;
+          if (tmin < best_ms) { best_ms = tmin; best = c; }
+        }
+        if (rc) break;
+        it = cache.emplace(key, std::make_pair(best, best_ms)).first;
+      }
+      t.cfg = it->second.first;
+      t.best_us = it->second.second * 1e3f;
+      finish_cfg(t);
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return rc;
   }
 
   // ResBlock (unet.py:110-220) with use_scale_shift_norm=True; updown: 0 none, 1 down, 2 up.
-  Act resblock(const std::string& pfx, const Act& in, int Cout, int updown, int64_t& film_cursor, Slot* dst) {
+  Act resblock(const std::string& pfx, const Act& in, int Cout, int updown, int64_t& film_cursor, Slot* dst, Slot* dst_stats) {
     const int Cin = in.C();
     const int Ho = updown == 1 ? in.H / 2 : (updown == 2 ? in.H * 2 : in.H);
     const int Wo = updown == 1 ? in.W / 2 : (updown == 2 ? in.W * 2 : in.W);
     // in_layers: GN + SiLU (+ resample) -> conv3x3
     op_gn(ops, in, pfx + ".in_layers.0", -1, K22_ACT_SILU, updown, 1, s_P1);
-    op_conv(ops, s_P1, Ho, Wo, Cin, Cout, pfx + ".in_layers.2", nullptr, s_U1, IG_OUT_ROWMAJOR);
+    Tuned* t1 = op_conv(ops, s_P1, Ho, Wo, Cin, Cout, pfx + ".in_layers.2", nullptr, s_U1, IG_OUT_ROWMAJOR, s_U1st);
     // out_layers: GN * (1+scale) + shift -> SiLU -> conv3x3 (+ skip)
     Act u1; u1.s0 = s_U1; u1.C0 = Cout; u1.H = Ho; u1.W = Wo;
+    if (t1->want_stats) { u1.p0 = t1; u1.st0 = s_U1st; }
     const int64_t film_off = film_cursor;
     film_cursor += 2 * Cout;
     op_gn(ops, u1, pfx + ".out_layers.0", film_off, K22_ACT_SILU, 0, 1, s_P2);
@@ -198,8 +371,9 @@ struct K22UNet {
       if (in.s1) { if (err.empty()) err = "identity skip over a concat input"; }
       skip.s0 = in.s0;
     }
-    op_conv(ops, s_P2, Ho, Wo, Cout, Cout, pfx + ".out_layers.3", &skip, dst, IG_OUT_ROWMAJOR);
+    Tuned* t2 = op_conv(ops, s_P2, Ho, Wo, Cout, Cout, pfx + ".out_layers.3", &skip, dst, IG_OUT_ROWMAJOR, dst_stats);
     Act out; out.s0 = dst; out.C0 = Cout; out.H = Ho; out.W = Wo;
+    if (t2->want_stats) { out.p0 = t2; out.st0 = dst_stats; }
     return out;
   }
 
@@ -247,6 +421,7 @@ struct K22UNet {
   int plan(int nB, int nH, int nW) {
     B = nB; H = nH; W = nW;
     slots.clear(); ops.clear(); cond_ops.clear(); s_ctxkv.clear(); n_attn = 0; err.clear();
+    tuned.clear(); tuned_done = false;
     ws = nullptr; cond_set = false;
     if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
     const int mc = cfg.model_channels, ted = 4 * mc;
@@ -285,9 +460,12 @@ struct K22UNet {
     s_part = new_slot(); s_coeff = new_slot(); s_P1 = new_slot(); s_U1 = new_slot(); s_P2 = new_slot(); s_S = new_slot();
     s_N = new_slot(); s_QKV = new_slot(); s_KALL = new_slot(); s_VT = new_slot(); s_ATT = new_slot();
     s_splitk = new_slot(256);
-    for (int i = 0; i < 3; ++i) s_h[i] = new_slot();
-    int hrot = 0;
-    auto next_h = [&]() { Slot* s = s_h[hrot]; hrot = (hrot + 1) % 3; return s; };
+    s_U1st = new_slot();
+    s_flush = new_slot(autotune ? ((size_t)320 << 20) : 0);  // evicts the Infinity Cache between tuning runs
+    for (int i = 0; i < 3; ++i) { s_h[i] = new_slot(); s_hst[i] = new_slot(); }
+    int hrot = 0, hcur = 0;
+    auto next_h = [&]() { hcur = hrot; hrot = (hrot + 1) % 3; return s_h[hcur]; };
+    auto cur_hst = [&]() { return s_hst[hcur]; };
 
     build_cond_ops();
 
@@ -344,25 +522,28 @@ struct K22UNet {
         const std::string pfx = "input_blocks." + std::to_string(blk);
         Slot* d = new_slot();
         if (has_attn(ds)) {
-          Act r = resblock(pfx + ".0", h, co, 0, film_cursor, next_h());
+          Slot* rd = next_h();
+          Act r = resblock(pfx + ".0", h, co, 0, film_cursor, rd, cur_hst());
           h = attnblock(pfx + ".1", r, d);
         } else {
-          h = resblock(pfx + ".0", h, co, 0, film_cursor, d);
+          h = resblock(pfx + ".0", h, co, 0, film_cursor, d, new_slot());
         }
         ch = co; hs.push_back(h); ++blk;
       }
       if (l != cfg.n_levels - 1) {
         const std::string pfx = "input_blocks." + std::to_string(blk);
         Slot* d = new_slot();
-        h = resblock(pfx + ".0", h, ch, 1, film_cursor, d);
+        h = resblock(pfx + ".0", h, ch, 1, film_cursor, d, new_slot());
         hs.push_back(h); ++blk; ds *= 2;
       }
     }
     // ---- middle ------------------------------------------------------------------------------
     {
-      Act r = resblock("middle_block.0", h, ch, 0, film_cursor, next_h());
+      Slot* d0 = next_h(); Slot* st0 = cur_hst();
+      Act r = resblock("middle_block.0", h, ch, 0, film_cursor, d0, st0);
       Act a = attnblock("middle_block.1", r, next_h());
-      h = resblock("middle_block.2", a, ch, 0, film_cursor, next_h());
+      Slot* d2 = next_h(); Slot* st2 = cur_hst();
+      h = resblock("middle_block.2", a, ch, 0, film_cursor, d2, st2);
     }
     // ---- output blocks ---------------------------------------------------------------------
     blk = 0;
@@ -370,14 +551,15 @@ struct K22UNet {
       for (int i = 0; i <= cfg.num_res_blocks; ++i) {
         const Act skip = hs.back(); hs.pop_back();
         Act cat; cat.s0 = h.s0; cat.C0 = h.C0; cat.s1 = skip.s0; cat.C1 = skip.C0; cat.H = h.H; cat.W = h.W;
+        cat.p0 = h.p0; cat.st0 = h.st0; cat.p1 = skip.p0; cat.st1 = skip.st0;
         if (skip.H != h.H || skip.W != h.W) return k22_set_error(K22_EINVAL, "unet: skip shape mismatch");
         const int co = mc * cfg.channel_mult[l];
         const std::string pfx = "output_blocks." + std::to_string(blk);
-        h = resblock(pfx + ".0", cat, co, 0, film_cursor, next_h());
+        { Slot* d = next_h(); Slot* dst_st = cur_hst(); h = resblock(pfx + ".0", cat, co, 0, film_cursor, d, dst_st); }
         int sub = 1;
         if (has_attn(ds)) { h = attnblock(pfx + "." + std::to_string(sub), h, next_h()); ++sub; }
         if (l && i == cfg.num_res_blocks) {
-          h = resblock(pfx + "." + std::to_string(sub), h, co, 2, film_cursor, next_h());
+          { Slot* d = next_h(); Slot* dst_st = cur_hst(); h = resblock(pfx + "." + std::to_string(sub), h, co, 2, film_cursor, d, dst_st); }
           ds /= 2;
         }
         ch = co; ++blk;
@@ -467,6 +649,10 @@ int k22_unet_create(const K22UNetConfig* cfg, const K22Weight* weights, int n_we
   if (cfg->in_channels != 4 && cfg->in_channels != 9) return k22_set_error(K22_EINVAL, "unet_create: in_channels must be 4 or 9");
   K22UNet* u = new K22UNet();
   u->cfg = *cfg; u->dtype = cfg->dtype; u->esz = cfg->dtype == K22_BF16 ? 2 : 4;
+  {
+    const char* e = getenv("K22_AUTOTUNE");  // 0 = heuristics only (no measurement at the first forward)
+    u->autotune = e ? (atoi(e) != 0) : 1;
+  }
   for (int i = 0; i < n_weights; ++i) u->w[weights[i].name] = weights[i].ptr;
   *out = u;
   return K22_OK;
@@ -527,6 +713,12 @@ int k22_unet_forward(K22UNet* u, const float* x, const float* timesteps, const f
     K22_CPY(u->ptr(u->s_img), inpaint_image, (size_t)u->B * 4 * hw * 4);
     K22_CPY(u->ptr(u->s_mask), inpaint_mask, (size_t)u->B * hw * 4);
   }
+  if (u->autotune && !u->tuned_done) {
+    // first forward on this plan: pick every conv / GEMM tile configuration by measurement
+    int rc = u->tune_all(st);
+    if (rc) return rc;
+    u->tuned_done = true;
+  }
   if (use_graph) {
     if (!u->graph_exec) {
       // warm-up eagerly once (sets function attributes), then capture
@@ -558,6 +750,32 @@ int k22_unet_forward(K22UNet* u, const float* x, const float* timesteps, const f
 }
 
 int k22_unet_num_ops(const K22UNet* u) { return u ? (int)u->ops.size() : 0; }
+
+int k22_unet_set_autotune(K22UNet* u, int on) {
+  if (!u) return k22_set_error(K22_EINVAL, "unet_set_autotune: null handle");
+  if (!u->ops.empty() && (on != 0) != (u->autotune != 0)) return k22_set_error(K22_EINVAL, "unet_set_autotune: call before k22_unet_plan");
+  u->autotune = on ? 1 : 0;
+  return K22_OK;
+}
+
+// Text table of the chosen tile configurations (one line per distinct conv / GEMM problem of the plan).
+int k22_unet_tuning_report(const K22UNet* u, char* buf, size_t cap) {
+  if (!u || !buf || cap == 0) return k22_set_error(K22_EINVAL, "unet_tuning_report: null argument");
+  std::string out = "taps      M     N     K    H    W stats | algo  bm  bn splitk |  time_us  count\n";
+  std::map<std::string, int> seen;
+  std::vector<std::string> order;
+  for (auto& t : u->tuned) {
+    char line[256];
+    snprintf(line, sizeof line, "%4d %6d %5d %5d %4d %4d %5d | %4s %3d %3d %6d | %8.1f", t.p.taps, t.p.M, t.p.N, t.p.Kc,
+             t.p.H, t.p.W, t.want_stats ? 1 : 0, t.cfg.algo == 2 ? "halo" : (t.cfg.algo == 1 ? "gen" : "auto"), t.cfg.bm, t.cfg.bn,
+             t.cfg.splitk, t.best_us);
+    if (!seen.count(line)) order.push_back(line);
+    seen[line]++;
+  }
+  for (auto& l : order) { out += l; out += "  x" + std::to_string(seen[l]) + "\n"; }
+  snprintf(buf, cap, "%s", out.c_str());
+  return K22_OK;
+}
 
 int k22_unet_profile(K22UNet* u, int reps, double* ms, double* flops, double* bytes, int* launches, void* stream) {
   if (!u || !u->ws || !u->cond_set) return k22_set_error(K22_EINVAL, "unet_profile: run k22_unet_forward once first");

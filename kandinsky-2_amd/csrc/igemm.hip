@@ -9,26 +9,84 @@
 //     straddling a filter tap (Cin % 64 == 0), so a conv K tile is a contiguous channel slice of
 //     one shifted pixel: address = pixel_base[m] + tap_offset + c0   (no bounds checks: the
 //     producer wrote a zero border).
-//   * global -> registers (16 B/lane, issued before the MFMAs of the current tile) -> LDS
-//     double buffer (written after them), ONE barrier per K tile.
-//   * LDS image is chunk-XOR-swizzled (common.h) so fragment ds_read_b128s are conflict-free.
-//   * 32x32x16 atoms, fp32 accumulate; epilogue fuses bias, residual add and activation, or
-//     writes fp32 split-K partials that splitk_reduce_kernel finishes.
+//   * operands go HBM/L2 -> LDS directly (global_load_lds_dwordx4: no staging VGPRs, no ds_write
+//     pass), STAGES buffers deep with a COUNTED vmcnt so STAGES-2 tiles stay in flight across the
+//     single raw s_barrier of each K tile:
+//       iteration k:  s_waitcnt vmcnt((STAGES-2)*CH)  -> this wave's part of tile k has landed
+//                     s_barrier                        -> everybody's part landed; tile k-1's buffer is free
+//                     issue tile k+STAGES-1 into that buffer ; MFMAs on tile k
+//   * the LDS image of one wave-instruction is lane-linear (base + lane*16 B): 8 rows x 128 B, so
+//     the chunk-XOR swizzle (common.h) is applied to the per-lane SOURCE address and to the reads;
+//     fragment ds_read_b128s are bank-conflict free.
+//   * the MFMA is issued "transposed" (weights as the A operand, pixels as B): the 32x32 C tile then
+//     has one PIXEL per lane column and 4 consecutive OUTPUT CHANNELS in consecutive accumulator
+//     registers, so the epilogue moves 8 B (bf16) / 16 B (fp32) per store instead of one element.
+//   * workgroups are renumbered so that the blocks an XCD runs concurrently share operand panels in
+//     that XCD's L2 (hardware places block b on XCD b % 8): every weight byte is pulled from
+//     HBM/Infinity-Fabric by one XCD, pixels by the few XCDs that hold their m-tile group.
+//   * fp32 accumulate; epilogue fuses bias, residual add and activation, or writes fp32 split-K
+//     partials that splitk_reduce_kernel finishes.
 #include "kernels.h"
 #include <stdlib.h>
 
-template <typename T, int BM, int BN>
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// 4 consecutive output channels of one pixel
+template <typename T> __device__ __forceinline__ void store4(T* dst, const float* v);
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* dst, const float* v) {
+  uint2 w;
+  w.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+  w.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+  *reinterpret_cast<uint2*>(dst) = w;
+}
+template <> __device__ __forceinline__ void store4<float>(float* dst, const float* v) {
+  *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <typename T> __device__ __forceinline__ void load4f(const T* src, float* v);
+template <> __device__ __forceinline__ void load4f<bf16_t>(const bf16_t* src, float* v) {
+  const uint2 r = *reinterpret_cast<const uint2*>(src);
+  v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+  v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void load4f<float>(const float* src, float* v) {
+  const float4 r = *reinterpret_cast<const float4*>(src);
+  v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+}
+
+// Logical block index of hardware block `bid` (XCD = bid % 8): XCD x gets the contiguous range
+// [start_x, start_x + count_x) of logical indices, in dispatch order.  Bijective for any nblocks.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+template <typename T, int BM, int BN, int STAGES>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   using TR = TT<T>;
   constexpr int BK = TR::BK, EPC = TR::EPC, KSTEPS = TR::KSTEPS;
   constexpr int MI = BM / 64, NI = BN / 64;     // 32x32 atoms per wave along M / N
-  constexpr int A_CH = BM / 32, B_CH = BN / 32;  // 16-byte chunks per thread per K tile
+  constexpr int A_CH = BM / 32, B_CH = BN / 32, CH = A_CH + B_CH;  // LDS-DMA instructions per wave per K tile
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;
+  constexpr int GM = 8;                         // m-tiles per rasterisation group
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+  // ---- block -> (m-tile, n-tile, k-split): groups of GM m-tiles x all n-tiles, k-split outermost ----
+  const int gx = (p.M + BM - 1) / BM, gy = (p.N + BN - 1) / BN;
+  int L = p.xcd_remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int per_z = gx * gy;
+  const int bz = L / per_z;
+  L -= bz * per_z;
+  const int grp = L / (GM * gy);
+  const int first_m = grp * GM;
+  const int gsz = gx - first_m < GM ? gx - first_m : GM;
+  const int lin = L - grp * GM * gy;
+  const int bx = first_m + lin % gsz, by = lin / gsz;
+  const int m0 = bx * BM, n0 = by * BN;
+
   const bool conv = (p.taps == 9);
   const T* __restrict__ A0 = reinterpret_cast<const T*>(p.A0);
   const T* __restrict__ A1 = reinterpret_cast<const T*>(p.A1);
@@ -36,188 +94,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 
   // ---- loader geometry: thread -> (row = tid/8 + 32*i, physical chunk = tid%8) --------------
   const int lrow = tid >> 3, lpos = tid & 7;
-  const int lchunk = lpos ^ (lrow & 7);  // logical (source) chunk that lands at this position
-  int64_t aoff0[A_CH], aoff1[A_CH], boff[B_CH];
-  const int ldb = p.taps * p.Kc;
-#pragma unroll
-  for (int i = 0; i < A_CH; ++i) {
-    int m = m0 + lrow + 32 * i;
-    if (m > p.M - 1) m = p.M - 1;
-    if (conv) {
-      const int hw = p.H * p.W;
-      const int b = m / hw, rem = m - b * hw;
-      const int y = rem / p.W, x = rem - y * p.W;
-      aoff0[i] = ((int64_t)(b * (p.H + 2) + y) * (p.W + 2) + x) * p.Kc;
-      aoff1[i] = 0;
-    } else {
-      aoff0[i] = (int64_t)m * p.lda0;
-      aoff1[i] = (int64_t)m * p.lda1;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < B_CH; ++i) {
-    int n = n0 + lrow + 32 * i;
-    if (n > p.Npad - 1) n = p.Npad - 1;
-    boff[i] = (int64_t)n * ldb;
-  }
-
-  const int kt_per_tap = p.Kc / BK;
-  const int nkt = p.taps * kt_per_tap;
-  int kt0 = 0, kt1 = nkt;
-  if (p.splitk > 1) {
-    const int per = (nkt + p.splitk - 1) / p.splitk;
-    kt0 = blockIdx.z * per;
-    kt1 = kt0 + per < nkt ? kt0 + per : nkt;
-  }
-
-  // Staging registers are native vectors and every load below is unconditional (the prefetch of the
-  // last iteration re-reads the last tile): conditional staging made hipcc keep them in scratch memory.
-  u32x4_t areg[A_CH], breg[B_CH];
-  f32x16_t acc[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-  const int h = lane >> 5, l31 = lane & 31;
-  const int64_t lck = lchunk * EPC;
-
-#define K22_GLOAD(KT)                                                                                   \
-  {                                                                                                     \
-    const int kt_ = (KT);                                                                               \
-    const int tap_ = kt_ / kt_per_tap;                                                                  \
-    const int k0_ = (kt_ - tap_ * kt_per_tap) * BK;                                                     \
-    const bool second_ = (!conv) && (k0_ >= p.K0);                                                      \
-    const T* src_ = second_ ? A1 : A0;                                                                  \
-    const int ty_ = tap_ / 3, tx_ = tap_ - ty_ * 3;                                                     \
-    const int64_t add_ = (conv ? (int64_t)(ty_ * (p.W + 2) + tx_) * p.Kc + k0_ : (int64_t)(second_ ? k0_ - p.K0 : k0_)) + lck; \
-    _Pragma("unroll") for (int i = 0; i < A_CH; ++i)                                                    \
-        areg[i] = *reinterpret_cast<const u32x4_t*>(src_ + (second_ ? aoff1[i] : aoff0[i]) + add_);     \
-    const int64_t badd_ = (int64_t)tap_ * p.Kc + k0_ + lck;                                             \
-    _Pragma("unroll") for (int i = 0; i < B_CH; ++i)                                                    \
-        breg[i] = *reinterpret_cast<const u32x4_t*>(Wp + boff[i] + badd_);                              \
-  }
-#define K22_LSTORE(BUFI)                                                                                \
-  {                                                                                                     \
-    char* As_ = smem + (BUFI) * BUF;                                                                    \
-    char* Bs_ = As_ + A_BYTES;                                                                          \
-    _Pragma("unroll") for (int i = 0; i < A_CH; ++i)                                                    \
-        *reinterpret_cast<u32x4_t*>(As_ + (lrow + 32 * i) * 128 + lpos * 16) = areg[i];                 \
-    _Pragma("unroll") for (int i = 0; i < B_CH; ++i)                                                    \
-        *reinterpret_cast<u32x4_t*>(Bs_ + (lrow + 32 * i) * 128 + lpos * 16) = breg[i];                 \
-  }
-
-  if (kt0 < kt1) {
-    K22_GLOAD(kt0);
-    K22_LSTORE(0);
-    __syncthreads();
-    int cur = 0;
-    for (int kt = kt0; kt < kt1; ++kt) {
-      const int nxt = kt + 1 < kt1 ? kt + 1 : kt1 - 1;
-      K22_GLOAD(nxt);
-      {
-        const char* As = smem + cur * BUF;
-        const char* Bs = As + A_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-          Frag<T> a[MI], b[NI];
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) ld_frag(a[mi], As, wm * (BM / 2) + mi * 32 + l31, ks, h);
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) ld_frag(b[ni], Bs, wn * (BN / 2) + ni * 32 + l31, ks, h);
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], a[mi], b[ni]);
-        }
-      }
-      K22_LSTORE(cur ^ 1);
-      __syncthreads();
-      cur ^= 1;
-    }
-  }
-#undef K22_GLOAD
-#undef K22_LSTORE
-
-  // ---- epilogue ------------------------------------------------------------------------
-  const int mbase = m0 + wm * (BM / 2), nbase = n0 + wn * (BN / 2);
-  if (p.splitk > 1) {
-    float* part = p.partial + (int64_t)blockIdx.z * p.M * p.N;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int n = nbase + ni * 32 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mbase + mi * 32 + c_row(r, lane);
-          if (m < p.M && n < p.N) part[(int64_t)m * p.N + n] = acc[mi][ni][r];
-        }
-      }
-    return;
-  }
-  const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int n = nbase + ni * 32 + l31;
-      const float bv = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mbase + mi * 32 + c_row(r, lane);
-        if (m < p.M && n < p.N) {
-          float v = acc[mi][ni][r] + bv;
-          if (res != nullptr) v += to_f32(res[(int64_t)m * p.ldr + n]);
-          v = apply_act(v, p.act);
-          if (p.out_mode == IG_OUT_ROWMAJOR) {
-            reinterpret_cast<T*>(p.out)[(int64_t)m * p.ldo + n] = from_f32<T>(v);
-          } else if (p.out_mode == IG_OUT_ROWMAJOR_F32) {
-            reinterpret_cast<float*>(p.out)[(int64_t)m * p.ldo + n] = v;
-          } else {
-            const int hw = p.H * p.W;
-            const int b = m / hw, rem = m - b * hw;
-            reinterpret_cast<float*>(p.out)[((int64_t)b * p.N + n) * hw + rem] = v;
-          }
-        }
-      }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// LDS-DMA variant: operands go HBM/L2 -> LDS directly (global_load_lds_dwordx4, no staging VGPRs,
-// no ds_write pass), STAGES buffers deep with a COUNTED vmcnt so STAGES-2 tiles stay in flight across
-// the single raw s_barrier of each K tile.  Same tile geometry / swizzle / epilogue as igemm_kernel.
-//   iteration k:  s_waitcnt vmcnt((STAGES-2)*CH)  -> this wave's part of tile k has landed
-//                 s_barrier                        -> everybody's part landed; tile k-1's buffer is free
-//                 issue tile k+STAGES-1 into that buffer ; MFMAs on tile k
-// The LDS image of one wave-instruction is lane-linear (base + lane*16 B): 8 rows x 128 B, so the XOR
-// swizzle is applied to the per-lane SOURCE address (logical chunk = pos ^ (row & 7)) and to the reads.
-// ---------------------------------------------------------------------------------------------
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-template <typename T, int BM, int BN, int STAGES>
-__global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p) {
-  using TR = TT<T>;
-  constexpr int BK = TR::BK, EPC = TR::EPC, KSTEPS = TR::KSTEPS;
-  constexpr int MI = BM / 64, NI = BN / 64;
-  constexpr int A_CH = BM / 32, B_CH = BN / 32, CH = A_CH + B_CH;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const bool conv = (p.taps == 9);
-  const T* __restrict__ A0 = reinterpret_cast<const T*>(p.A0);
-  const T* __restrict__ A1 = reinterpret_cast<const T*>(p.A1);
-  const T* __restrict__ Wp = reinterpret_cast<const T*>(p.Wp);
-
-  const int lrow = tid >> 3, lpos = tid & 7;
-  const int lchunk = lpos ^ (lrow & 7);
+  const int lchunk = lpos ^ ((lrow >> 1) & 7);  // logical (source) chunk that lands at this position
   int64_t aoff0[A_CH], aoff1[A_CH], boff[B_CH];
   const int ldb = p.taps * p.Kc;
 #pragma unroll
@@ -246,7 +123,7 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p) {
   int kt0 = 0, kt1 = nkt;
   if (p.splitk > 1) {
     const int per = (nkt + p.splitk - 1) / p.splitk;
-    kt0 = blockIdx.z * per;
+    kt0 = bz * per;
     kt1 = kt0 + per < nkt ? kt0 + per : nkt;
   }
 
@@ -303,7 +180,7 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p) {
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], a[mi], b[ni]);
+            for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], b[ni], a[mi]);  // C^T: rows = n, cols = m
         }
       }
       cur = (cur + 1 == STAGES) ? 0 : cur + 1;
@@ -313,55 +190,124 @@ __global__ __launch_bounds__(256) void igemm_glds_kernel(const IgemmParams p) {
   }
 #undef K22_ISSUE
 
+  // ---- epilogue: lane = pixel m, registers 4j..4j+3 = channels n0 + 8j + 4h + {0..3} -----------------
   const int mbase = m0 + wm * (BM / 2), nbase = n0 + wn * (BN / 2);
-  if (p.splitk > 1) {
-    float* part = p.partial + (int64_t)blockIdx.z * p.M * p.N;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int n = nbase + ni * 32 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mbase + mi * 32 + c_row(r, lane);
-          if (m < p.M && n < p.N) part[(int64_t)m * p.N + n] = acc[mi][ni][r];
-        }
-      }
-    return;
-  }
+  const bool vec_ok = ((p.N & 3) == 0) && ((p.ldo & 3) == 0) && ((p.ldr & 3) == 0);
   const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
+  float* part = p.splitk > 1 ? p.partial + (int64_t)bz * p.M * p.N : nullptr;
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = mbase + mi * 32 + l31;
+    if (m >= p.M) continue;
+    int64_t nchw_base = 0;
+    if (p.out_mode == IG_OUT_NCHW_F32) {
+      const int hw = p.H * p.W;
+      const int b = m / hw, rem = m - b * hw;
+      nchw_base = (int64_t)b * p.N * hw + rem;
+    }
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int n = nbase + ni * 32 + l31;
-      const float bv = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mbase + mi * 32 + c_row(r, lane);
-        if (m < p.M && n < p.N) {
-          float v = acc[mi][ni][r] + bv;
-          if (res != nullptr) v += to_f32(res[(int64_t)m * p.ldr + n]);
-          v = apply_act(v, p.act);
-          if (p.out_mode == IG_OUT_ROWMAJOR) {
-            reinterpret_cast<T*>(p.out)[(int64_t)m * p.ldo + n] = from_f32<T>(v);
-          } else if (p.out_mode == IG_OUT_ROWMAJOR_F32) {
-            reinterpret_cast<float*>(p.out)[(int64_t)m * p.ldo + n] = v;
+      for (int j = 0; j < 4; ++j) {
+        const int n = nbase + ni * 32 + 8 * j + 4 * h;
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * j + e];
+        if (part != nullptr) {
+          if (vec_ok) {
+            *reinterpret_cast<float4*>(part + (int64_t)m * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
           } else {
-            const int hw = p.H * p.W;
-            const int b = m / hw, rem = m - b * hw;
-            reinterpret_cast<float*>(p.out)[((int64_t)b * p.N + n) * hw + rem] = v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n + e < p.N) part[(int64_t)m * p.N + n + e] = v[e];
+          }
+          continue;
+        }
+        if (vec_ok) {
+          if (p.bias != nullptr) {
+            const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+            v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+          }
+          if (res != nullptr) {
+            float rv[4];
+            load4f<T>(res + (int64_t)m * p.ldr + n, rv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += rv[e];
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+          if (p.out_mode == IG_OUT_ROWMAJOR) {
+            store4<T>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.ldo + n, v);
+          } else if (p.out_mode == IG_OUT_ROWMAJOR_F32) {
+            store4<float>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n, v);
+          } else {
+            const int64_t hw = (int64_t)p.H * p.W;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) reinterpret_cast<float*>(p.out)[nchw_base + (int64_t)(n + e) * hw] = v[e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (n + e >= p.N) continue;
+            float u = v[e];
+            if (p.bias != nullptr) u += p.bias[n + e];
+            if (res != nullptr) u += to_f32(res[(int64_t)m * p.ldr + n + e]);
+            u = apply_act(u, p.act);
+            if (p.out_mode == IG_OUT_ROWMAJOR) {
+              reinterpret_cast<T*>(p.out)[(int64_t)m * p.ldo + n + e] = from_f32<T>(u);
+            } else if (p.out_mode == IG_OUT_ROWMAJOR_F32) {
+              reinterpret_cast<float*>(p.out)[(int64_t)m * p.ldo + n + e] = u;
+            } else {
+              reinterpret_cast<float*>(p.out)[nchw_base + (int64_t)(n + e) * p.H * p.W] = u;
+            }
           }
         }
       }
-    }
+  }
 }
 
-// Finishes a split-K launch: out = act(sum_s partial[s] + bias + residual).
+// Finishes a split-K launch: out = act(sum_s partial[s] + bias + residual).  4 channels per thread.
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmParams p) {
   const int64_t total = (int64_t)p.M * p.N;
   const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
+  if (((p.N & 3) == 0) && ((p.ldo & 3) == 0) && ((p.ldr & 3) == 0)) {
+    const int nq = p.N >> 2;
+    const int64_t quads = total >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (int64_t)gridDim.x * blockDim.x) {
+      const int m = (int)(i / nq), n = (int)(i - (int64_t)m * nq) * 4;
+      float4 a = *reinterpret_cast<const float4*>(p.partial + i * 4);
+      for (int s = 1; s < p.splitk; ++s) {
+        const float4 b = *reinterpret_cast<const float4*>(p.partial + (int64_t)s * total + i * 4);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+      float v[4] = {a.x, a.y, a.z, a.w};
+      if (p.bias != nullptr) {
+        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+      }
+      if (res != nullptr) {
+        float rv[4];
+        load4f<T>(res + (int64_t)m * p.ldr + n, rv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += rv[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+      if (p.out_mode == IG_OUT_ROWMAJOR) {
+        store4<T>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.ldo + n, v);
+      } else if (p.out_mode == IG_OUT_ROWMAJOR_F32) {
+        store4<float>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n, v);
+      } else {
+        const int hw = p.H * p.W;
+        const int b = m / hw, rem = m - b * hw;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) reinterpret_cast<float*>(p.out)[((int64_t)b * p.N + n + e) * hw + rem] = v[e];
+      }
+    }
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int m = (int)(i / p.N), n = (int)(i - (int64_t)m * p.N);
     float v = 0.f;
@@ -381,19 +327,82 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmParams p)
   }
 }
 
+// Split-K finish + GroupNorm partial sums.  Workgroup = 16 consecutive output rows (never straddling an image:
+// HW % 16 == 0) x 64 channels; thread = one row x 4 consecutive channels, so the splitk partial loads of a thread
+// are independent and the grid is (M/16) x (N/64) workgroups.  stats[row_block][n] = (sum, sumsq) of the
+// stored values, reduced over the 16 rows in a fixed order through LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const IgemmParams p) {
+  __shared__ float red[16][64][2];
+  const int64_t total = (int64_t)p.M * p.N;
+  const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
+  const int r = threadIdx.x >> 4, cq = threadIdx.x & 15;
+  const int m = blockIdx.x * 16 + r, n = blockIdx.y * 64 + cq * 4;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool ok = m < p.M && n < p.N;
+  if (ok) {
+    const int64_t i = (int64_t)m * p.N + n;
+    float4 a = *reinterpret_cast<const float4*>(p.partial + i);
+#pragma unroll 4
+    for (int s = 1; s < p.splitk; ++s) {
+      const float4 b = *reinterpret_cast<const float4*>(p.partial + (int64_t)s * total + i);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    if (p.bias != nullptr) {
+      const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+      v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if (res != nullptr) {
+      float rv[4];
+      load4f<T>(res + (int64_t)m * p.ldr + n, rv);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += rv[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+    if (p.out_mode == IG_OUT_ROWMAJOR) {
+      store4<T>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.ldo + n, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = to_f32(from_f32<T>(v[e]));
+    } else {
+      store4<float>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n, v);
+    }
+  }
+  if (p.stats == nullptr) return;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[r][cq * 4 + e][0] = ok ? v[e] : 0.f;
+    red[r][cq * 4 + e][1] = ok ? v[e] * v[e] : 0.f;
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int ch = threadIdx.x >> 1, which = threadIdx.x & 1;
+    float a = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) a += red[rr][ch][which];
+    const int nn = blockIdx.y * 64 + ch;
+    if (nn < p.N) p.stats[((int64_t)blockIdx.x * p.N + nn) * 2 + which] = a;
+  }
+}
+
 // ---- host side ------------------------------------------------------------------------
-struct IgemmPlan { int bm, bn, splitk, stages; };  // stages == 0 -> register-staged igemm_kernel
+struct IgemmPlan { int halo, bm, bn, splitk, stages; };  // halo: conv3_halo.hip kernel (bm = 256 / 128, bn = 128)
 
 static int g_stages_override = -1;
-void igemm_set_default_stages(int v) { g_stages_override = (v == 0 || (v >= 2 && v <= 4)) ? v : -1; }
+static int g_xcd_remap = 1;
+static int g_conv_algo = 0;
+void igemm_set_default_stages(int v) { g_stages_override = (v >= 2 && v <= 4) ? v : -1; }
+void igemm_set_xcd_remap(int v) { g_xcd_remap = v ? 1 : 0; }
+void igemm_set_conv_algo(int v) { g_conv_algo = (v >= 0 && v <= 2) ? v : 0; }
 
 static int g_default_stages() {
   static int v = -1;
   if (g_stages_override >= 0) return g_stages_override;
   if (v < 0) {
-    const char* e = getenv("K22_IGEMM_STAGES");  // 0 = register staging, 2..4 = LDS-DMA pipeline depth
+    const char* e = getenv("K22_IGEMM_STAGES");  // 2..4 = LDS-DMA pipeline depth
     v = e ? atoi(e) : 2;
-    if (v == 1 || v > 4) v = 0;
+    if (v < 2 || v > 4) v = 2;
   }
   return v;
 }
@@ -402,7 +411,36 @@ static IgemmPlan igemm_plan(const IgemmParams& p, int dtype) {
   const int BK = (dtype == K22_BF16) ? 64 : 32;
   const int nkt = p.taps * (p.Kc / BK);
   IgemmPlan pl;
+  pl.halo = 0;
+  pl.stages = (p.stages >= 2 && p.stages <= 4) ? p.stages : g_default_stages();
   auto blocks = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  // ---- 3x3 convolution: LDS-resident halo kernel when it applies --------------------------------
+  const int algo = p.algo ? p.algo : g_conv_algo;
+  if (p.taps == 9 && algo != 1 && p.N >= 128) {
+    int bm = 0;
+    if (p.force_bm == 256 || p.force_bm == 128) {
+      if (conv3_halo_supported(p, dtype, p.force_bm) && (algo == 2 || p.force_bn == 0)) bm = p.force_bm;
+    } else if (p.force_bm == 0) {
+      if (conv3_halo_supported(p, dtype, 256)) bm = 256;
+      else if (conv3_halo_supported(p, dtype, 128)) bm = 128;
+    }
+    if (bm) {
+      const int nslab = p.Kc / BK;
+      pl.halo = 1; pl.bm = bm; pl.bn = 128;
+      if (p.splitk > 0) {
+        pl.splitk = p.splitk;
+      } else {
+        const int B = p.M / (p.H * p.W);
+        const int nb = B * conv3_halo_tiles_per_image(p, bm) * ((p.N + 127) / 128);
+        int sk = 1;
+        while (nb * sk < 200 && sk < 16 && nslab / (sk * 2) >= 2) sk *= 2;
+        pl.splitk = sk;
+      }
+      if (pl.splitk > nslab) pl.splitk = nslab;
+      if (pl.splitk < 1) pl.splitk = 1;
+      return pl;
+    }
+  }
   if (p.force_bm && p.force_bn) {
     pl.bm = p.force_bm;
     pl.bn = p.force_bn;
@@ -411,8 +449,6 @@ static IgemmPlan igemm_plan(const IgemmParams& p, int dtype) {
     pl.bn = 64;
   } else if (blocks(128, 128) >= 160) {
     pl.bm = 128; pl.bn = 128;
-  } else if (p.M > 64 && blocks(128, 64) >= 96) {
-    pl.bm = 128; pl.bn = 64;
   } else if (p.M > 64) {
     pl.bm = 128; pl.bn = 64;
   } else {
@@ -427,7 +463,6 @@ static IgemmPlan igemm_plan(const IgemmParams& p, int dtype) {
     pl.splitk = sk;
   }
   if (pl.splitk > nkt) pl.splitk = nkt > 0 ? nkt : 1;
-  pl.stages = p.stages >= 0 ? p.stages : g_default_stages();
   return pl;
 }
 
@@ -437,72 +472,68 @@ int igemm_choose_splitk(const IgemmParams& p, int dtype) {
   return igemm_plan(q, dtype).splitk;
 }
 
-template <typename T, int BM, int BN>
-static int launch_cfg(const IgemmParams& p, int splitk, hipStream_t stream) {
-  constexpr int smem = 2 * (BM + BN) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
-  IgemmParams q = p;
-  q.splitk = splitk;
-  dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, splitk);
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN>), grid, dim3(256), smem, stream, q);
-  K22_CHECK_LAUNCH();
-  if (splitk > 1) {
-    const int64_t total = (int64_t)p.M * p.N;
-    int nb = (int)((total + 255) / 256);
-    if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(nb), dim3(256), 0, stream, q);
+static bool reduce_rows_ok(const IgemmParams& p) {
+  const int hw = (p.taps == 9) ? p.H * p.W : 0;
+  return hw > 0 && hw % 16 == 0 && (p.N & 3) == 0 && (p.ldo & 3) == 0 && (p.ldr & 3) == 0 &&
+         (p.out_mode == IG_OUT_ROWMAJOR || p.out_mode == IG_OUT_ROWMAJOR_F32);
+}
+
+int igemm_stats_rows_per_image(const IgemmParams& p, int dtype) {
+  if (p.taps != 9) return 0;
+  const IgemmPlan pl = igemm_plan(p, dtype);
+  if (pl.splitk > 1) return reduce_rows_ok(p) ? p.H * p.W / 16 : 0;
+  if (pl.halo) return conv3_halo_tiles_per_image(p, pl.bm);
+  return 0;
+}
+
+template <typename T>
+static int launch_reduce(const IgemmParams& q, hipStream_t stream) {
+  if (q.stats != nullptr || reduce_rows_ok(q)) {
+    if (!reduce_rows_ok(q)) return k22_set_error(K22_EINVAL, "igemm: GroupNorm partial sums are not available for this split-K problem");
+    hipLaunchKernelGGL((splitk_reduce_rows_kernel<T>), dim3((q.M + 15) / 16, (q.N + 63) / 64), dim3(256), 0, stream, q);
     K22_CHECK_LAUNCH();
+    return K22_OK;
   }
+  const int64_t total = (int64_t)q.M * q.N;
+  int nb = (int)((total / 4 + 255) / 256);
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(nb), dim3(256), 0, stream, q);
+  K22_CHECK_LAUNCH();
   return K22_OK;
 }
 
 template <typename T, int BM, int BN, int STAGES>
-static int launch_glds(const IgemmParams& p, int splitk, hipStream_t stream) {
+static int launch_cfg(const IgemmParams& p, int splitk, hipStream_t stream) {
   constexpr int smem = STAGES * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_glds_kernel<T, BM, BN, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   IgemmParams q = p;
   q.splitk = splitk;
-  dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, splitk);
-  hipLaunchKernelGGL((igemm_glds_kernel<T, BM, BN, STAGES>), grid, dim3(256), smem, stream, q);
+  q.xcd_remap = g_xcd_remap;
+  const int nblocks = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * splitk;
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, STAGES>), dim3(nblocks), dim3(256), smem, stream, q);
   K22_CHECK_LAUNCH();
-  if (splitk > 1) {
-    const int64_t total = (int64_t)p.M * p.N;
-    int nb = (int)((total + 255) / 256);
-    if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(nb), dim3(256), 0, stream, q);
-    K22_CHECK_LAUNCH();
-  }
+  if (splitk > 1) return launch_reduce<T>(q, stream);
   return K22_OK;
 }
 
 template <typename T, int BM, int BN>
-static int launch_glds_stages(const IgemmParams& p, const IgemmPlan& pl, hipStream_t stream) {
-  if (pl.stages == 2) return launch_glds<T, BM, BN, 2>(p, pl.splitk, stream);
-  if (pl.stages == 3) return launch_glds<T, BM, BN, 3>(p, pl.splitk, stream);
-  return launch_glds<T, BM, BN, 4>(p, pl.splitk, stream);
+static int launch_stages(const IgemmParams& p, const IgemmPlan& pl, hipStream_t stream) {
+  if (pl.stages == 2) return launch_cfg<T, BM, BN, 2>(p, pl.splitk, stream);
+  if (pl.stages == 3) return launch_cfg<T, BM, BN, 3>(p, pl.splitk, stream);
+  return launch_cfg<T, BM, BN, 4>(p, pl.splitk, stream);
 }
 
 template <typename T>
 static int launch_typed(const IgemmParams& p, const IgemmPlan& pl, hipStream_t stream) {
-  if (pl.stages >= 2) {
-    if (pl.bm == 128 && pl.bn == 128) return launch_glds_stages<T, 128, 128>(p, pl, stream);
-    if (pl.bm == 128 && pl.bn == 64) return launch_glds_stages<T, 128, 64>(p, pl, stream);
-    if (pl.bm == 64 && pl.bn == 128) return launch_glds_stages<T, 64, 128>(p, pl, stream);
-    if (pl.bm == 64 && pl.bn == 64) return launch_glds_stages<T, 64, 64>(p, pl, stream);
-  }
-  if (pl.bm == 128 && pl.bn == 128) return launch_cfg<T, 128, 128>(p, pl.splitk, stream);
-  if (pl.bm == 128 && pl.bn == 64) return launch_cfg<T, 128, 64>(p, pl.splitk, stream);
-  if (pl.bm == 64 && pl.bn == 128) return launch_cfg<T, 64, 128>(p, pl.splitk, stream);
-  if (pl.bm == 64 && pl.bn == 64) return launch_cfg<T, 64, 64>(p, pl.splitk, stream);
-  if (pl.bm == 256 && pl.bn == 128) return launch_cfg<T, 256, 128>(p, pl.splitk, stream);
+  if (pl.bm == 128 && pl.bn == 128) return launch_stages<T, 128, 128>(p, pl, stream);
+  if (pl.bm == 128 && pl.bn == 64) return launch_stages<T, 128, 64>(p, pl, stream);
+  if (pl.bm == 64 && pl.bn == 128) return launch_stages<T, 64, 128>(p, pl, stream);
+  if (pl.bm == 64 && pl.bn == 64) return launch_stages<T, 64, 64>(p, pl, stream);
   return k22_set_error(K22_EINVAL, "igemm: unsupported tile configuration");
 }
 
@@ -515,6 +546,16 @@ int launch_igemm(const IgemmParams& p, int dtype, hipStream_t stream) {
   if (p.K0 < p.Kc && p.A1 == nullptr) return k22_set_error(K22_EINVAL, "igemm: A1 missing for concat operand");
   IgemmPlan pl = igemm_plan(p, dtype);
   if (pl.splitk > 1 && p.partial == nullptr) pl.splitk = 1;
+  if (p.stats != nullptr && pl.splitk == 1 && !pl.halo)
+    return k22_set_error(K22_EINVAL, "igemm: GroupNorm partial sums requested from a configuration that cannot produce them");
+  if (pl.halo) {
+    IgemmParams q = p;
+    q.splitk = pl.splitk;
+    q.xcd_remap = g_xcd_remap;
+    int rc = launch_conv3_halo(q, dtype, pl.bm, pl.splitk, stream);
+    if (rc || pl.splitk == 1) return rc;
+    return dtype == K22_BF16 ? launch_reduce<bf16_t>(q, stream) : launch_reduce<float>(q, stream);
+  }
   if (dtype == K22_BF16) return launch_typed<bf16_t>(p, pl, stream);
   if (dtype == K22_F32) return launch_typed<float>(p, pl, stream);
   return k22_set_error(K22_EINVAL, "igemm: bad dtype");

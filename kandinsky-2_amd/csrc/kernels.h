@@ -39,9 +39,25 @@ struct IgemmParams {
   int act;               // K22Act applied after bias+residual
   int splitk;            // >= 1 (0 = let the launcher choose)
   int force_bm, force_bn;  // 0 = heuristic
-  int stages;            // -1 = default (env K22_IGEMM_STAGES), 0 = register staging, 2..4 = LDS-DMA pipeline depth
+  int stages;            // 2..4 = LDS-DMA pipeline depth, anything else = default (env K22_IGEMM_STAGES, else 2)
+  int xcd_remap;         // set by the launcher: XCD-aware block renumbering on/off
+  int algo;              // taps == 9 only: 0 auto, 1 generic implicit GEMM, 2 LDS-resident halo kernel (conv3_halo.hip)
+  float* stats;          // optional GroupNorm side output: per-row-block, per-channel (sum, sumsq) of the STORED
+                         // values, [stats_rows][N][2] fp32 (see IgemmStatsInfo); null = not wanted
 };
 
+// How a producer laid out its GroupNorm partial sums: image b owns rows [b*rows_per_image, (b+1)*rows_per_image).
+struct IgemmStatsInfo { int rows_per_image; };
+// Number of stats rows per image launch_igemm will write for this problem (0 = this configuration cannot
+// produce stats; the caller must run the stand-alone gn_stats kernel instead).
+int igemm_stats_rows_per_image(const IgemmParams& p, int dtype);
+
 int launch_igemm(const IgemmParams& p, int dtype, hipStream_t stream);
-void igemm_set_default_stages(int v);  // tuning knob: 0 register staging, 2..4 LDS-DMA stages, -1 env/default
+// conv3_halo.hip: 3x3 convolution with the input tile (+halo) resident in LDS across the 9 taps.
+bool conv3_halo_supported(const IgemmParams& p, int dtype, int bm);
+int conv3_halo_tiles_per_image(const IgemmParams& p, int bm);
+int launch_conv3_halo(const IgemmParams& p, int dtype, int bm, int splitk, hipStream_t stream);
+void igemm_set_conv_algo(int v);       // tuning knob: 0 auto, 1 generic, 2 halo
+void igemm_set_default_stages(int v);  // tuning knob: 2..4 LDS-DMA stages, -1 env/default
+void igemm_set_xcd_remap(int v);       // tuning knob: XCD-aware block renumbering (default on)
 int igemm_choose_splitk(const IgemmParams& p, int dtype);  // split-K factor the heuristic picks (scratch = splitk*M*N*4 B)

@@ -52,25 +52,59 @@ __global__ __launch_bounds__(256) void sampler_x0_kernel(SamplerParams p) {
 }
 
 // pass 2: s = max(percentile_99.5(|x0[0]|), 1) — exact order statistics by radix select.
+// One 1024-thread workgroup.  |x0| is clamped, so the high key bytes collapse into two or three histogram
+// bins: lanes of a wave that hit the same bin are combined with ballots and ONE LDS atomic per distinct bin
+// (a plain atomic per element serialises ~n same-address updates per pass).
+__device__ __forceinline__ void hist_add_aggregated(int* hist, bool valid, uint32_t bin) {
+  uint64_t todo = __ballot(valid);
+  const int lane = threadIdx.x & 63;
+  // up to 4 rounds of "combine everybody in the leader's bin"; what is left is spread over many bins
+  // (low contention) and goes through plain LDS atomics.
+  for (int round = 0; round < 4 && todo; ++round) {
+    const int leader = __ffsll((unsigned long long)todo) - 1;
+    const uint32_t lb = __shfl(bin, leader, 64);
+    const uint64_t same = __ballot(valid && bin == lb) & todo;
+    if (lane == leader) atomicAdd(&hist[lb], __popcll(same));
+    todo &= ~same;
+  }
+  if ((todo >> lane) & 1) atomicAdd(&hist[bin], 1);
+}
+
+// k-th smallest key (0-based) of |v[0..n)| (keys = fp32 bit patterns, monotone for non-negative floats).
 __device__ uint32_t radix_select(const float* v, int n, int k, int* hist, uint32_t* bc) {
   const int tid = threadIdx.x;
   uint32_t prefix = 0, mask = 0;
   for (int shift = 24; shift >= 0; shift -= 8) {
     for (int i = tid; i < 256; i += blockDim.x) hist[i] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += blockDim.x) {
-      const uint32_t key = __float_as_uint(fabsf(v[i]));
-      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+    for (int i0 = 0; i0 < n; i0 += blockDim.x) {
+      const int i = i0 + tid;
+      uint32_t key = 0;
+      bool valid = false;
+      if (i < n) {
+        key = __float_as_uint(fabsf(v[i]));
+        valid = (key & mask) == prefix;
+      }
+      hist_add_aggregated(hist, valid, (key >> shift) & 255);
     }
     __syncthreads();
-    if (tid == 0) {
-      int cum = 0, b = 0;
-      for (; b < 256; ++b) {
-        if (cum + hist[b] > k) break;
-        cum += hist[b];
+    if (tid < 64) {
+      // wave 0: inclusive scan of the 256 bins (4 per lane), then locate the bin holding rank k
+      int c[4], run = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { run += hist[tid * 4 + j]; c[j] = run; }
+      int incl = run;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (tid >= o) incl += t;
       }
-      bc[0] = (uint32_t)b;
-      bc[1] = (uint32_t)(k - cum);
+      const int excl = incl - run;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int lo = excl + (j ? c[j - 1] : 0), hi = excl + c[j];
+        if (k >= lo && k < hi) { bc[0] = (uint32_t)(tid * 4 + j); bc[1] = (uint32_t)(k - lo); }
+      }
     }
     __syncthreads();
     prefix |= bc[0] << shift;
@@ -84,11 +118,30 @@ __device__ uint32_t radix_select(const float* v, int n, int k, int* hist, uint32
 __global__ __launch_bounds__(1024) void sampler_threshold_kernel(SamplerParams p) {
   __shared__ int hist[256];
   __shared__ uint32_t bc[2];
+  __shared__ unsigned int succ_cnt[2];  // [0] = #keys <= a, [1] = min key > a
   const int n = 4 * p.HW;
   const int k_hi = p.n_lo + 1 < n ? p.n_lo + 1 : n - 1;
-  const float a = __uint_as_float(radix_select(p.x0_buf, n, p.n_lo, hist, bc));
-  const float b = __uint_as_float(radix_select(p.x0_buf, n, k_hi, hist, bc));
+  const uint32_t ka = radix_select(p.x0_buf, n, p.n_lo, hist, bc);
+  // the next order statistic: a itself if enough keys are <= a, else the smallest key above a
+  if (threadIdx.x == 0) { succ_cnt[0] = 0u; succ_cnt[1] = 0xffffffffu; }
+  __syncthreads();
+  unsigned int cnt = 0, mn = 0xffffffffu;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const uint32_t key = __float_as_uint(fabsf(p.x0_buf[i]));
+    if (key <= ka) ++cnt;
+    else mn = key < mn ? key : mn;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    cnt += __shfl_xor(cnt, o, 64);
+    const unsigned int t = __shfl_xor(mn, o, 64);
+    mn = t < mn ? t : mn;
+  }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&succ_cnt[0], cnt); atomicMin(&succ_cnt[1], mn); }
+  __syncthreads();
   if (threadIdx.x == 0) {
+    const uint32_t kb = ((int)succ_cnt[0] > k_hi || k_hi == p.n_lo) ? ka : succ_cnt[1];
+    const float a = __uint_as_float(ka), b = __uint_as_float(kb);
     // numpy _lerp in float32: a + (b-a)*t, or b - (b-a)*(1-t) when t >= 0.5
     const float t = (float)p.gamma;
     const float d = __fsub_rn(b, a);

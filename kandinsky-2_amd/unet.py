@@ -185,6 +185,12 @@ class Text2ImUNetHIP(nn.Module):
         kinds = ["conv3x3", "gemm", "groupnorm", "attention", "other"]
         return {k: dict(ms=ms[i], flops=fl[i], bytes=by[i], launches=ln[i]) for i, k in enumerate(kinds)}
 
+    def tuning_report(self) -> str:
+        """Tile configuration chosen (by measurement at the first forward) for every distinct conv / GEMM problem."""
+        buf = C.create_string_buffer(1 << 16)
+        _lib.check(_lib.lib().k22_unet_tuning_report(self._handle, buf, len(buf)))
+        return buf.value.decode()
+
     def workspace_bytes(self) -> int:
         return 0 if self._ws is None else self._ws.numel()
 

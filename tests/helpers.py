@@ -51,8 +51,18 @@ def pack_conv3(w, T):
     return pad_rows(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(T))
 
 
-def conv3x3(x, w, bias=None, residual=None, dtype=_lib.K22_BF16, splitk=1, bm=0, bn=0, out_mode=0):
-    """x [B,Cin,H,W], w [Cout,Cin,3,3], residual [B,Cout,H,W] (float32 cuda) -> NCHW float32."""
+def conv3x3(x, w, bias=None, residual=None, dtype=_lib.K22_BF16, splitk=1, bm=0, bn=0, out_mode=0, algo=0, stats=False):
+    """x [B,Cin,H,W], w [Cout,Cin,3,3], residual [B,Cout,H,W] (float32 cuda) -> NCHW float32.
+    algo: 0 auto, 1 generic implicit GEMM, 2 LDS-resident halo kernel.  stats=True also returns the per-image,
+    per-channel (sum, sumsq) reduced from the kernel's GroupNorm partial sums."""
+    _lib.check(_lib.lib().k22_set_option(b"conv_algo", algo))
+    try:
+        return _conv3x3(x, w, bias, residual, dtype, splitk, bm, bn, out_mode, stats)
+    finally:
+        _lib.check(_lib.lib().k22_set_option(b"conv_algo", 0))
+
+
+def _conv3x3(x, w, bias, residual, dtype, splitk, bm, bn, out_mode, stats):
     T = tdt(dtype)
     B, Cin, H, W_ = x.shape
     Cout = w.shape[0]
@@ -64,13 +74,26 @@ def conv3x3(x, w, bias=None, residual=None, dtype=_lib.K22_BF16, splitk=1, bm=0,
     else:
         out = torch.empty(B, H, W_, Cout, dtype=T, device=x.device)
     partial = torch.empty(max(1, splitk if splitk else 16) * B * H * W_ * Cout + 64, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().k22_conv3x3(
-        xp.data_ptr(), wp.data_ptr(), _lib.ptr(bias), _lib.ptr(res), out.data_ptr(), partial.data_ptr(),
-        B, H, W_, Cin, Cout, wp.shape[0], out_mode, 0, splitk, bm, bn, dtype, stream()))
+    st = None
+    if stats:
+        import ctypes as C
+        cap = B * (H * (W_ + 2) // 16 + 2)
+        sbuf = torch.full((cap, Cout, 2), float("nan"), dtype=torch.float32, device=x.device)
+        rpi = C.c_int(0)
+        _lib.check(_lib.lib().k22_conv3x3_gnstats(
+            xp.data_ptr(), wp.data_ptr(), _lib.ptr(bias), _lib.ptr(res), out.data_ptr(), partial.data_ptr(),
+            B, H, W_, Cin, Cout, wp.shape[0], splitk, bm, bn, sbuf.data_ptr(), cap, C.byref(rpi), dtype, stream()))
+        st = sbuf[: B * rpi.value].view(B, rpi.value, Cout, 2).double().sum(1)  # [B, Cout, 2]
+    else:
+        _lib.check(_lib.lib().k22_conv3x3(
+            xp.data_ptr(), wp.data_ptr(), _lib.ptr(bias), _lib.ptr(res), out.data_ptr(), partial.data_ptr(),
+            B, H, W_, Cin, Cout, wp.shape[0], out_mode, 0, splitk, bm, bn, dtype, stream()))
     o = out.float() if out_mode == _lib.OUT_NCHW_F32 else out.float().permute(0, 3, 1, 2).contiguous()
     ref = F.conv2d(x.to(T).float(), w.to(T).float(), bias, padding=1)
     if res is not None:
         ref = ref + res.float().permute(0, 3, 1, 2)
+    if stats:
+        return o, ref, st
     return o, ref
 
 

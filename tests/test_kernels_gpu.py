@@ -33,7 +33,7 @@ def rnd(*shape, seed=0, scale=1.0):
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("M,N,K,bm,bn,splitk", [
     (256, 256, 128, 128, 128, 1), (300, 192, 192, 128, 64, 1), (77, 768, 1024, 64, 64, 1), (128, 128, 64, 64, 128, 1),
-    (512, 384, 256, 256, 128, 1), (288, 320, 1152, 128, 64, 4), (2, 1536, 384, 64, 64, 2), (1000, 8, 384, 128, 64, 1),
+    (512, 384, 256, 64, 128, 1), (288, 320, 1152, 128, 64, 4), (2, 1536, 384, 64, 64, 2), (1000, 8, 384, 128, 64, 1),
     (333, 200, 320, 0, 0, 0),
 ])
 def test_gemm(dtype, M, N, K, bm, bn, splitk):
@@ -70,6 +70,36 @@ def test_conv3x3(dtype, B, Cin, Cout, H, W, bm, bn, splitk):
     bias, res = rnd(Cout, seed=3), rnd(B, Cout, H, W, seed=4)
     out, ref = hp.conv3x3(x, w, bias, res, dtype=dtype, splitk=splitk, bm=bm, bn=bn)
     close(out, ref, dtype, f"conv {B}x{Cin}->{Cout}@{H}x{W}")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,Cin,Cout,H,W,bm,splitk", [
+    (2, 128, 128, 16, 16, 256, 1), (1, 64, 192, 9, 13, 128, 1), (2, 256, 128, 8, 8, 256, 3), (3, 192, 256, 6, 10, 128, 2),
+    (2, 384, 384, 24, 24, 256, 1), (1, 128, 256, 96, 96, 256, 1), (2, 128, 128, 12, 12, 0, 0), (1, 128, 136, 48, 48, 128, 1),
+])
+def test_conv3x3_halo(dtype, B, Cin, Cout, H, W, bm, splitk):
+    """LDS-resident halo kernel (conv3_halo.hip): junk columns, image boundaries, ragged last tile, split-K."""
+    x, w = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
+    bias, res = rnd(Cout, seed=3), rnd(B, Cout, H, W, seed=4)
+    out, ref = hp.conv3x3(x, w, bias, res, dtype=dtype, splitk=splitk, bm=bm, bn=0, algo=2)
+    close(out, ref, dtype, f"halo conv {B}x{Cin}->{Cout}@{H}x{W}")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,Cin,Cout,H,W,bm,splitk", [
+    (2, 128, 128, 16, 16, 256, 1), (2, 128, 256, 24, 24, 128, 1), (2, 256, 128, 12, 12, 256, 2), (1, 128, 128, 48, 48, 256, 1),
+])
+def test_conv3x3_groupnorm_partial_sums(dtype, B, Cin, Cout, H, W, bm, splitk):
+    """The conv epilogue's GroupNorm side output = per-image, per-channel sum / sum of squares of the STORED tensor."""
+    x, w = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
+    bias, res = rnd(Cout, seed=3), rnd(B, Cout, H, W, seed=4)
+    out, ref, st = hp.conv3x3(x, w, bias, res, dtype=dtype, splitk=splitk, bm=bm, bn=0, algo=2, stats=True)
+    close(out, ref, dtype, "halo conv with stats")
+    o = out.double()
+    s_ref, q_ref = o.sum((2, 3)), (o * o).sum((2, 3))
+    n = H * W
+    assert (st[..., 0] - s_ref).abs().max().item() <= 1e-4 * n ** 0.5 * (q_ref.max().item() / n) ** 0.5 + 1e-3
+    assert ((st[..., 1] - q_ref).abs() / q_ref).max().item() <= 1e-5
 
 
 @pytest.mark.parametrize("dtype", DT)

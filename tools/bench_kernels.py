@@ -34,6 +34,24 @@ def conv_shapes(arch, B, lat):
     return shapes
 
 
+def gemm_shapes(arch, B, lat):
+    """(M, N, K) -> count for the MFMA GEMMs of one forward: 1x1 skip convs, qkv and proj_out."""
+    shapes = OrderedDict()
+    h = lat
+    for b in arch.blocks:
+        if b[0] == "res":
+            _, pfx, cin, cout, ud = b
+            h = h // 2 if ud == 1 else (h * 2 if ud == 2 else h)
+            if cin != cout and ud == 0:
+                key = (B * h * h, cout, cin)
+                shapes[key] = shapes.get(key, 0) + 1
+        elif b[0] == "attn":
+            c = b[2]
+            for key in ((B * h * h, 3 * c, c), (B * h * h, c, c)):
+                shapes[key] = shapes.get(key, 0) + 1
+    return shapes
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--lat", type=int, default=96)
@@ -41,29 +59,44 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--configs", default="auto")
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--stages", type=int, default=-1, help="igemm_stages option (0 reg-staged, 2..4 LDS-DMA)")
+    ap.add_argument("--stages", type=int, default=-1, help="igemm_stages option (2..4 LDS-DMA pipeline depth)")
+    ap.add_argument("--xcd", type=int, default=1, help="XCD-aware block renumbering on/off")
+    ap.add_argument("--cold", type=int, default=1, help="rotate weight copies so weights come from HBM, not the Infinity Cache")
+    ap.add_argument("--gemm", action="store_true", help="benchmark the GEMM shapes (1x1 skip, qkv, proj) instead of the 3x3 convs")
     a = ap.parse_args()
     arch = k22.make_arch(k22.MODEL_CONFIG_2_1)
     dt = _lib.K22_BF16 if a.dtype == "bf16" else _lib.K22_F32
     T = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     L = _lib.lib()
     _lib.check(L.k22_set_option(b"igemm_stages", a.stages))
-    print("igemm_stages =", a.stages)
+    _lib.check(L.k22_set_option(b"igemm_xcd_remap", a.xcd))
+    print("igemm_stages =", a.stages, "xcd_remap =", a.xcd)
+    if a.gemm:
+        return bench_gemm(a, arch, L, dt, T)
     shapes = conv_shapes(arch, a.B, a.lat)
     cfgs = []
     for c in a.configs.split(","):
         if c == "auto":
-            cfgs.append((0, 0, 0))
-        else:
+            cfgs.append((0, 0, 0, 0))
+        elif c.startswith("h"):          # h256 / h128x2 : halo kernel, BM, split-K (0 = heuristic)
+            parts = c[1:].split("x")
+            cfgs.append((int(parts[0]), 0, int(parts[1]) if len(parts) > 1 else 0, 2))
+        else:                            # 128x64x8 : generic implicit GEMM
             parts = c.split("x")
-            cfgs.append((int(parts[0]), int(parts[1]), int(parts[2]) if len(parts) > 2 else 1))
+            cfgs.append((int(parts[0]), int(parts[1]), int(parts[2]) if len(parts) > 2 else 1, 1))
     st = torch.cuda.current_stream().cuda_stream
     tot = {c: 0.0 for c in cfgs}
     totfl = 0.0
-    print(f"{'Cin':>5} {'Cout':>5} {'H':>3} {'cnt':>3} {'GFLOP':>8} | " + " | ".join(f"{c[0]}x{c[1]}k{c[2]} TF/s" for c in cfgs))
+    names = a.configs.split(",")
+    print(f"{'Cin':>5} {'Cout':>5} {'H':>3} {'cnt':>3} {'GFLOP':>8} | " + " | ".join(f"{n:>10}" for n in names) + " |  best")
+    best_tot = 0.0
     for (ci, co, h), cnt in shapes.items():
         x = torch.randn(a.B, h + 2, h + 2, ci, device="cuda").to(T)
         w = (torch.randn((co + 63) // 64 * 64, 9 * ci, device="cuda") * (9 * ci) ** -0.5).to(T)
+        # rotate over enough weight copies to defeat the 256 MB Infinity Cache (in a real step the 2.5 GB of
+        # weights stream from HBM once per forward)
+        ncopy = max(1, min(24, int(400e6 // (w.numel() * w.element_size())) + 1)) if a.cold else 1
+        ws = [w] + [w.clone() for _ in range(ncopy - 1)]
         bias = torch.randn(co, device="cuda")
         out = torch.empty(a.B, h, h, co, device="cuda", dtype=T)
         part = torch.empty(16 * a.B * h * h * co + 64, device="cuda")
@@ -71,7 +104,13 @@ def main():
         totfl += fl * cnt
         row = []
         for c in cfgs:
+            it = [0]
+
+            _lib.check(L.k22_set_option(b"conv_algo", c[3]))
+
             def run():
+                w = ws[it[0] % len(ws)]
+                it[0] += 1
                 _lib.check(L.k22_conv3x3(x.data_ptr(), w.data_ptr(), bias.data_ptr(), None, out.data_ptr(), part.data_ptr(),
                                          a.B, h, h, ci, co, w.shape[0], 0, 0, c[2], c[0], c[1], dt, st))
             run()
@@ -85,9 +124,54 @@ def main():
             ms = e0.elapsed_time(e1) / a.reps
             tot[c] += ms * cnt
             row.append(f"{fl / ms / 1e9:10.1f}")
-        print(f"{ci:5d} {co:5d} {h:3d} {cnt:3d} {fl / 1e9:8.1f} | " + " | ".join(row))
+        bi = max(range(len(row)), key=lambda i: float(row[i]))
+        best_tot += fl * cnt / float(row[bi]) / 1e9
+        print(f"{ci:5d} {co:5d} {h:3d} {cnt:3d} {fl / 1e9:8.1f} | " + " | ".join(row) + f" |  {names[bi]}")
+    print(f"best-per-shape: conv total {best_tot:.3f} ms/step -> {totfl / best_tot / 1e9:.1f} TFLOP/s")
     for c in cfgs:
         print(f"config {c}: conv total {tot[c]:.3f} ms/step -> {totfl / tot[c] / 1e9:.1f} TFLOP/s over {totfl / 1e9:.0f} GFLOP")
+
+
+def bench_gemm(a, arch, L, dt, T):
+    shapes = gemm_shapes(arch, a.B, a.lat)
+    cfgs = []
+    for c in a.configs.split(","):
+        if c == "auto":
+            cfgs.append((0, 0, 0))
+        else:
+            parts = c.split("x")
+            cfgs.append((int(parts[0]), int(parts[1]), int(parts[2]) if len(parts) > 2 else 1))
+    st = torch.cuda.current_stream().cuda_stream
+    tot = {c: 0.0 for c in cfgs}
+    totfl = 0.0
+    print(f"{'M':>6} {'N':>5} {'K':>5} {'cnt':>3} {'GFLOP':>8} | " + " | ".join(f"{c[0]}x{c[1]}k{c[2]} TF/s" for c in cfgs))
+    for (M, N, K), cnt in shapes.items():
+        x = torch.randn(M, K, device="cuda").to(T)
+        w = (torch.randn((N + 63) // 64 * 64, K, device="cuda") * K ** -0.5).to(T)
+        bias = torch.randn(N, device="cuda")
+        out = torch.empty(M, N, device="cuda", dtype=T)
+        part = torch.empty(16 * M * N + 64, device="cuda")
+        fl = 2.0 * M * N * K
+        totfl += fl * cnt
+        row = []
+        for c in cfgs:
+            def run():
+                _lib.check(L.k22_gemm(x.data_ptr(), None, w.data_ptr(), bias.data_ptr(), None, out.data_ptr(), part.data_ptr(),
+                                      M, N, w.shape[0], K, 0, K, 0, N, N, 0, 0, c[2], c[0], c[1], dt, st))
+            run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.reps):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / a.reps
+            tot[c] += ms * cnt
+            row.append(f"{fl / ms / 1e9:10.1f}")
+        print(f"{M:6d} {N:5d} {K:5d} {cnt:3d} {fl / 1e9:8.1f} | " + " | ".join(row))
+    for c in cfgs:
+        print(f"config {c}: gemm total {tot[c]:.3f} ms/step -> {totfl / tot[c] / 1e9:.1f} TFLOP/s over {totfl / 1e9:.0f} GFLOP")
 
 
 if __name__ == "__main__":
