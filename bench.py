@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--sched-steps", type=int, default=50, help="decoder_steps of the schedule being sampled")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-op HIP-event pass (roofline object = null)")
     ap.add_argument("--cpu-baseline-size", type=int, default=0, help="image side for the CPU sample (0 = same as --size)")
     ap.add_argument("--tuning-report", default="", help="write the chosen conv/GEMM tile configurations to this file")
     ap.add_argument("--tiny", action="store_true", help="1/3-width UNet (debug only; not a valid bench config)")
@@ -143,24 +144,36 @@ def main():
         if a.tuning_report:
             with open(a.tuning_report, "w") as f:
                 f.write(m.tuning_report())
-        prof = m.profile(reps=3)
-        conv = prof["conv3x3"]
-        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
-        conv_tf = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
-        tot_ms = sum(v["ms"] for v in prof.values())
-        tot_fl = sum(v["flops"] for v in prof.values())
-        gn = prof["groupnorm"]
-        roofline = {
-            "kernel": "igemm_kernel (implicit-GEMM conv3x3)", "bound": "mfma",
-            "achieved": round(conv_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(conv_tf / peak, 4),
-            "traffic": None,
-            "launches_per_step": conv["launches"], "avg_launch_ms": round(conv["ms"] / max(1, conv["launches"]), 5),
-            "flops_per_step": conv["flops"],
-            "by_class_ms": {kk: round(v["ms"], 4) for kk, v in prof.items()},
-            "unet_flops_per_step": tot_fl, "unet_tflops_events": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2) if tot_ms else 0.0,
-            "groupnorm_gbs": round(gn["bytes"] / (gn["ms"] * 1e-3) / 1e9, 1) if gn["ms"] else 0.0,
-            "groupnorm_frac_hbm": round(gn["bytes"] / (gn["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if gn["ms"] else 0.0,
-        }
+        roofline = None
+        if not a.no_profile:
+            prof = m.profile(reps=3)
+            conv = prof["conv3x3"]
+            peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+            conv_tf = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+            tot_ms = sum(v["ms"] for v in prof.values())
+            tot_fl = sum(v["flops"] for v in prof.values())
+            gn = prof["groupnorm"]
+            # HBM traffic of the same kernel class from the committed rocprofv3 PMC pass (tools/gpu_pmc.sh):
+            # FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE, per launch; null when no pass is on file
+            traffic = None
+            pmc_path = os.path.join(ROOT, "profiles", "pmc_conv.json")
+            if a.size == 768 and a.bs == 1 and a.dtype == "bf16" and os.path.exists(pmc_path):
+                with open(pmc_path) as f:
+                    traffic = json.load(f).get("hbm_bytes_per_launch")
+            roofline = {
+                "kernel": "conv3_halo_kernel (3x3 convolutions of the ResBlocks: LDS-resident halo implicit GEMM, incl. "
+                          "split-K finish; 83% of the step's FLOPs)",
+                "bound": "mfma",
+                "achieved": round(conv_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(conv_tf / peak, 4),
+                "traffic": traffic,
+                "launches_per_step": conv["launches"], "avg_launch_ms": round(conv["ms"] / max(1, conv["launches"]), 5),
+                "flops_per_launch": conv["flops"] / max(1, conv["launches"]), "flops_per_step": conv["flops"],
+                "timing": "HIP events around every engine op on the launch stream, eager replay of the step, mean of 3",
+                "by_class_ms": {kk: round(v["ms"], 4) for kk, v in prof.items()},
+                "unet_flops_per_step": tot_fl, "unet_tflops_events": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2) if tot_ms else 0.0,
+                "groupnorm_gbs": round(gn["bytes"] / (gn["ms"] * 1e-3) / 1e9, 1) if gn["ms"] else 0.0,
+                "groupnorm_frac_hbm": round(gn["bytes"] / (gn["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if gn["ms"] else 0.0,
+            }
         cpu = None
         if not a.no_cpu_baseline:
             cpu = cpu_baseline(arch, sd, a, B)
@@ -188,7 +201,9 @@ def main():
 def cpu_baseline(arch, sd, a, B):
     """The CPU oracle (PyTorch fp32 restatement of the reference's UNet + p_sampler step) on this box's cores."""
     from oracle import diffusion_ref, unet_ref
-    cores = os.cpu_count() or 1
+    # oneDNN/PyTorch on this many-core host is fastest at 16-32 threads (measured: one 32x32-latent forward takes
+    # 0.8 s at 16 threads, 1.0 s at 32, 4.3 s at 128 and 161 s at 256), so the baseline uses 32, not all cores
+    cores = int(os.environ.get("K22_CPU_THREADS", min(32, os.cpu_count() or 1)))
     torch.set_num_threads(cores)
     size = a.cpu_baseline_size or a.size
     lat = size // 8
@@ -207,7 +222,7 @@ def cpu_baseline(arch, sd, a, B):
     el = time.perf_counter() - t0
     return {"value": round(n / el, 4), "unit": "steps/s", "cores": cores, "kind": "port",
             "sample": f"{n} denoise step (UNet fwd CFG batch {B}x4x{lat}x{lat} + p_sample) of the same workload, fp32, "
-                      f"{cores} threads, no warm-up"}
+                      f"{cores} threads (of {os.cpu_count()} host cores; more threads are slower), no warm-up"}
 
 
 if __name__ == "__main__":

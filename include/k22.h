@@ -136,6 +136,12 @@ int k22_gemm(const void* A0, const void* A1, const void* Wp, const float* bias, 
 int k22_conv3x3(const void* x_padded, const void* Wp, const float* bias, const void* residual, void* out,
                 void* partial, int B, int H, int W, int Cin, int Cout, int Npad, int out_mode, int act, int splitk,
                 int bm, int bn, int dtype, void* stream);
+/* Tail of a channel-changing ResBlock in one launch (unet.py:191,219-220): out = conv3x3(x_padded) + bias +
+ * [skip0 | skip1](unpadded NHWC, SK0 + SK1 channels) . Ws[Npad][SK0+SK1]^T + bias_s   (1x1 skip_connection fused
+ * as a second K loop of the halo kernel; skip1 may be null with SK1 = 0). */
+int k22_conv3x3_skip(const void* x_padded, const void* Wp, const float* bias, const void* skip0, const void* skip1,
+                     int SK0, int SK1, const void* Ws, const float* bias_s, void* out, void* partial, int B, int H, int W,
+                     int Cin, int Cout, int Npad, int splitk, int bm, int dtype, void* stream);
 /* Same convolution (row-major T output, no activation) that also emits the per-channel partial sums the next
  * GroupNorm needs (ResBlock: conv -> GroupNorm32, unet.py:157-164/212-216), so the tensor is not re-read:
  * stats[row][c] = (sum, sum of squares) of the STORED outputs, image b owning rows [b*rpi, (b+1)*rpi);
@@ -149,6 +155,11 @@ int k22_groupnorm(const void* x0, const void* x1, int C0, int C1, int B, int H, 
 size_t k22_groupnorm_scratch_bytes(int B, int C);
 int k22_attention(const void* qkv, const void* ctxkv, void* kall, void* vtall, void* out, int B, int H, int T, int S,
                   int dtype, void* stream);
+/* qkv projection of an AttentionBlock (Conv1d C -> 3C, unet.py:251) written straight into the attention operands:
+ * x [B*T][K], packed weight rows ordered [q | k | v] x [H][64]; q -> q_out [B*T][C]; k -> kall[b][h][S+t][64];
+ * v -> vtall[b][h][d][S+t] (both [..][Tkp = roundup(S+T,64)]; the first S keys belong to the context). */
+int k22_qkv_project(const void* x, const void* Wp, const float* bias, void* q_out, void* kall, void* vtall,
+                    int B, int H, int T, int S, int K, int bm, int bn, int dtype, void* stream);
 int k22_linear_smallm(const float* x, const void* W, const float* bias, const float* add, float* out, int M, int N,
                       int K, int act_in, int act_out, int wdtype, void* stream);
 

@@ -51,10 +51,12 @@ SIGNATURES = {
     "k22_sampler_step": (_I, [_P, _P, _P, _P, _P, _P, _I, _F, _I, _F, _F, _I, _D, _P, _P, _P, _I, _I, _P]),
     "k22_gemm": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "k22_conv3x3": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "k22_conv3x3_skip": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "k22_conv3x3_gnstats": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, C.POINTER(_I), _I, _P]),
     "k22_groupnorm": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _L, _F, _I, _I, _I, _P, _P, _I, _P]),
     "k22_groupnorm_scratch_bytes": (_Z, [_I, _I]),
     "k22_attention": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "k22_qkv_project": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "k22_linear_smallm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
 }
 

@@ -31,10 +31,10 @@ __device__ __forceinline__ void ld_frag_split(Frag<float>& f, const char* tile, 
   f.v[4] = hi.x; f.v[5] = hi.y; f.v[6] = hi.z; f.v[7] = hi.w;
 }
 __device__ __forceinline__ void make_pfrag(Frag<bf16_t>& f, const float* p) {
-  f.v = u32x4_t{(uint32_t)f32_to_bf16(p[0]) | ((uint32_t)f32_to_bf16(p[1]) << 16),
-                (uint32_t)f32_to_bf16(p[2]) | ((uint32_t)f32_to_bf16(p[3]) << 16),
-                (uint32_t)f32_to_bf16(p[4]) | ((uint32_t)f32_to_bf16(p[5]) << 16),
-                (uint32_t)f32_to_bf16(p[6]) | ((uint32_t)f32_to_bf16(p[7]) << 16)};
+  f.v = u32x4_t{pack2_bf16(p[0], p[1]),
+                pack2_bf16(p[2], p[3]),
+                pack2_bf16(p[4], p[5]),
+                pack2_bf16(p[6], p[7])};
 }
 __device__ __forceinline__ void make_pfrag(Frag<float>& f, const float* p) {
 #pragma unroll
@@ -46,9 +46,11 @@ __device__ __forceinline__ void ld_qfrag(Frag<float>& f, const float* p) {
   f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
   f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
 }
-template <typename T> __device__ __forceinline__ float exp_t(float x);
-template <> __device__ __forceinline__ float exp_t<bf16_t>(float x) { return __expf(x); }
-template <> __device__ __forceinline__ float exp_t<float>(float x) { return expf(x); }
+// 2^x: the bf16 path uses the raw v_exp_f32 (inputs here are <= 0; results below 2^-126 flush, which is
+// far below bf16 resolution of the probabilities), the fp32 parity path the accurate exp2f.
+template <typename T> __device__ __forceinline__ float exp2_t(float x);
+template <> __device__ __forceinline__ float exp2_t<bf16_t>(float x) { return __builtin_amdgcn_exp2f(x); }
+template <> __device__ __forceinline__ float exp2_t<float>(float x) { return exp2f(x); }
 
 template <typename T>
 __global__ __launch_bounds__(256) void attention_kernel(AttentionParams p) {
@@ -101,6 +103,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttentionParams p) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
   float m_run = -1e30f, l_run = 0.f;
+  const float cexp = p.scale * 1.4426950408889634f;  // exp(s*scale - m*scale) = exp2((s - m) * cexp)
 
   K22_ATT_GLOAD(0);
   for (int kt = 0; kt < nkt; ++kt) {
@@ -121,34 +124,41 @@ __global__ __launch_bounds__(256) void attention_kernel(AttentionParams p) {
         mma_atom(s[kb], kf, qf[a]);
       }
 
+    // ---- online softmax, lane-local: p = exp2(s*c - m*c) with c = scale*log2(e) folded into ONE fma per
+    // score; the running maximum is kept on the raw scores (c > 0), and the accumulator rescale is skipped
+    // (wave-uniform test) on the tiles that do not raise any query's maximum — the common case.
     float pv[2][16];
-    float mloc = -1e30f;
     const bool tail = (kt * 64 + 64 > p.Tk);
+    if (tail) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = s[kb][r] * p.scale;
-        if (tail && (kt * 64 + kb * 32 + c_row(r, lane) >= p.Tk)) v = -INFINITY;
-        pv[kb][r] = v;
-        mloc = fmaxf(mloc, v);
-      }
+        for (int r = 0; r < 16; ++r)
+          if (kt * 64 + kb * 32 + c_row(r, lane) >= p.Tk) s[kb][r] = -INFINITY;
+    }
+    float mloc = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, fmaxf(s[0][r], s[1][r]));
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-    const float m_new = fmaxf(m_run, mloc);
-    const float alpha = exp_t<T>(m_run - m_new);
+    if (__any(mloc > m_run)) {
+      const float m_new = fmaxf(m_run, mloc);
+      const float alpha = exp2_t<T>((m_run - m_new) * cexp);
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+    }
+    const float mc = m_run * cexp;
     float lsum = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = exp_t<T>(pv[kb][r] - m_new);
+        const float e = exp2_t<T>(fmaf(s[kb][r], cexp, -mc));
         pv[kb][r] = e;
         lsum += e;
       }
-    l_run = l_run * alpha + lsum;
-    m_run = m_new;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+    l_run += lsum;
 
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -174,8 +184,8 @@ __global__ __launch_bounds__(256) void attention_kernel(AttentionParams p) {
         const int d = db * 32 + 8 * g + 4 * h;
         if constexpr (sizeof(T) == 2) {
           uint2 w;
-          w.x = (uint32_t)f32_to_bf16(o[db][4 * g] * inv) | ((uint32_t)f32_to_bf16(o[db][4 * g + 1] * inv) << 16);
-          w.y = (uint32_t)f32_to_bf16(o[db][4 * g + 2] * inv) | ((uint32_t)f32_to_bf16(o[db][4 * g + 3] * inv) << 16);
+          w.x = pack2_bf16(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
+          w.y = pack2_bf16(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
           *reinterpret_cast<uint2*>(orow + d) = w;
         } else {
           *reinterpret_cast<float4*>(orow + d) =

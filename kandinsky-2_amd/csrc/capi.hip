@@ -73,6 +73,19 @@ int k22_conv3x3_gnstats(const void* x_padded, const void* Wp, const float* bias,
   return launch_igemm(p, dtype, reinterpret_cast<hipStream_t>(stream));
 }
 
+int k22_conv3x3_skip(const void* x_padded, const void* Wp, const float* bias, const void* skip0, const void* skip1,
+                     int SK0, int SK1, const void* Ws, const float* bias_s, void* out, void* partial, int B, int H, int W,
+                     int Cin, int Cout, int Npad, int splitk, int bm, int dtype, void* stream) {
+  IgemmParams p = {};
+  p.stages = -1;
+  p.A0 = x_padded; p.Wp = Wp; p.bias = bias; p.out = out; p.partial = reinterpret_cast<float*>(partial);
+  p.M = B * H * W; p.N = Cout; p.Npad = Npad; p.Kc = Cin; p.K0 = Cin; p.taps = 9; p.H = H; p.W = W;
+  p.ldo = Cout; p.ldr = Cout; p.out_mode = IG_OUT_ROWMAJOR; p.act = K22_ACT_NONE; p.splitk = splitk; p.force_bm = bm; p.force_bn = 0;
+  p.S0 = skip0; p.S1 = skip1; p.SK0 = SK0; p.SK1 = SK1; p.Ws = Ws; p.bias2 = bias_s; p.algo = 2;
+  if (p.splitk == 0) p.splitk = partial ? igemm_choose_splitk(p, dtype) : 1;
+  return launch_igemm(p, dtype, reinterpret_cast<hipStream_t>(stream));
+}
+
 size_t k22_groupnorm_scratch_bytes(int B, int C) {
   return (size_t)B * 128 * C * 2 * sizeof(float) + (size_t)B * C * 2 * sizeof(float) + 512;
 }
@@ -113,6 +126,18 @@ int k22_attention(const void* qkv, const void* ctxkv, void* kall, void* vtall, v
   ap.q = qkv; ap.ldq = 3 * C; ap.kall = kall; ap.vtall = vtall; ap.out = out; ap.ldo = C;
   ap.B = B; ap.H = H; ap.T = T; ap.Tk = Tk; ap.Tkp = Tkp; ap.scale = 0.125f;
   return launch_attention(ap, dtype, st);
+}
+
+int k22_qkv_project(const void* x, const void* Wp, const float* bias, void* q_out, void* kall, void* vtall,
+                    int B, int H, int T, int S, int K, int bm, int bn, int dtype, void* stream) {
+  const int C = H * 64, Tkp = (S + T + 63) / 64 * 64;
+  IgemmParams p = {};
+  p.stages = -1;
+  p.A0 = x; p.Wp = Wp; p.bias = bias; p.out = q_out; p.kall = kall; p.vtall = vtall;
+  p.M = B * T; p.N = 3 * C; p.Npad = 3 * C; p.Kc = K; p.K0 = K; p.taps = 1; p.lda0 = K; p.lda1 = 0;
+  p.ldo = C; p.ldr = 3 * C; p.out_mode = IG_OUT_QKV; p.act = K22_ACT_NONE; p.splitk = 1; p.force_bm = bm; p.force_bn = bn;
+  p.att_T = T; p.att_S = S; p.att_Tkp = Tkp;
+  return launch_igemm(p, dtype, reinterpret_cast<hipStream_t>(stream));
 }
 
 int k22_linear_smallm(const float* x, const void* W, const float* bias, const float* add, float* out, int M, int N,

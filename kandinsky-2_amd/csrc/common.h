@@ -19,12 +19,15 @@ enum K22DType { K22_BF16 = 0, K22_F32 = 1 };
 enum K22Act { K22_ACT_NONE = 0, K22_ACT_SILU = 1, K22_ACT_GELU = 2 };
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);  // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);                                           // round-to-nearest-even
-  return (bf16_t)(u >> 16);
+// fp32 -> bf16, round-to-nearest-even: one v_cvt_pk_bf16_f32 per PAIR on gfx950 (the integer
+// add-and-shift emulation costs ~5 VALU per element and made the elementwise kernels ALU-bound)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack2_bf16(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float to_f32(bf16_t v) { return bf16_to_f32(v); }
 __device__ __forceinline__ float to_f32(float v) { return v; }
 template <typename T> __device__ __forceinline__ T from_f32(float f);
@@ -111,7 +114,7 @@ template <> struct Vec16<bf16_t> {
     return __uint_as_float((i & 1) ? (w & 0xffff0000u) : (w << 16));
   }
   __device__ __forceinline__ void set2(int pair, float lo, float hi) {
-    (&raw.x)[pair] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    (&raw.x)[pair] = pack2_bf16(lo, hi);
   }
 };
 template <> struct Vec16<float> {

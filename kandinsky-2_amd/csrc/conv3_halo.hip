@@ -22,6 +22,9 @@
 //     fp32 tile -> 32 B per thread row segments: bias, residual, one rounding, 16-byte stores, and the per-channel
 //     (sum, sum of squares) of the STORED values for the next GroupNorm (deterministic, no atomics)
 //   * split-K over channel slabs for the low-resolution levels (fp32 partials, finished by splitk_reduce)
+//   * optional fused 1x1 skip_connection of the ResBlock (out += x . Ws^T): a second, plain-GEMM K loop over the
+//     block input's channels (A rows = the tile's own pixels, no halo) that accumulates into the same registers,
+//     so the skip tensor is never written, re-read or launched separately
 #include "kernels.h"
 
 namespace {
@@ -41,10 +44,10 @@ __device__ __forceinline__ void ld_frag_at(Frag<float>& f, const char* rowp, int
 template <typename T> __device__ __forceinline__ void store8(T* dst, const float* v);
 template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* dst, const float* v) {
   uint4 w;
-  w.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-  w.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-  w.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
-  w.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+  w.x = pack2_bf16(v[0], v[1]);
+  w.y = pack2_bf16(v[2], v[3]);
+  w.z = pack2_bf16(v[4], v[5]);
+  w.w = pack2_bf16(v[6], v[7]);
   *reinterpret_cast<uint4*>(dst) = w;
 }
 template <> __device__ __forceinline__ void store8<float>(float* dst, const float* v) {
@@ -246,6 +249,81 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const IgemmParams p) {
   }
 #undef K22_ISSUE_A
 #undef K22_ISSUE_B
+  // ---- fused 1x1 skip connection: acc += X[tile pixels][SK] . Ws[n][SK]^T, 2-stage LDS-DMA pipeline ----------
+  if (p.S0 != nullptr) {
+    const int SK = p.SK0 + p.SK1;
+    const int nss = SK / BK;
+    const int sp = p.splitk > 1 ? p.splitk : 1;
+    const int q0 = nss * bz / sp, q1 = nss * (bz + 1) / sp;
+    if (q0 < q1) {
+      constexpr int SA_SLOTS = BM / 8 / NW;             // input-tile LDS-DMA instructions per wave per slab
+      constexpr int SBUF = BM * 128 + B_BYTES;
+      wait_vmcnt<0>();
+      __syncthreads();                                   // main-loop buffers are free
+      int spix[SA_SLOTS], schunk[SA_SLOTS];
+#pragma unroll
+      for (int i = 0; i < SA_SLOTS; ++i) {
+        const int row = 8 * (wave + NW * i) + (lane >> 3);
+        int v = v0 + row;
+        if (v > VR - 1) v = VR - 1;
+        const int y = v / W2;
+        int x = v - y * W2;
+        if (x > p.W - 1) x = p.W - 1;                    // junk columns read a valid pixel; their rows are dropped
+        spix[i] = (img * p.H + y) * p.W + x;
+        schunk[i] = ((lane & 7) ^ ((row >> 1) & 7)) * EPC;
+      }
+      int wsoff[B_SLOTS];
+#pragma unroll
+      for (int i = 0; i < B_SLOTS; ++i) {
+        const int row = 8 * (wave + NW * i) + (lane >> 3);
+        int n = n0 + row;
+        if (n > p.Npad - 1) n = p.Npad - 1;
+        wsoff[i] = n * SK + ((lane & 7) ^ ((row >> 1) & 7)) * EPC;
+      }
+      const T* __restrict__ X0 = reinterpret_cast<const T*>(p.S0);
+      const T* __restrict__ X1 = reinterpret_cast<const T*>(p.S1);
+      const T* __restrict__ Ws = reinterpret_cast<const T*>(p.Ws);
+#define K22_ISSUE_SKIP(Q, BUFI)                                                                            \
+      {                                                                                                    \
+        const int k0_ = (Q) * BK;                                                                          \
+        const bool second_ = k0_ >= p.SK0;                                                                 \
+        const T* xs_ = second_ ? X1 : X0;                                                                  \
+        const int ldx_ = second_ ? p.SK1 : p.SK0;                                                          \
+        const int kk_ = second_ ? k0_ - p.SK0 : k0_;                                                       \
+        char* dA_ = smem + (BUFI) * SBUF + wave * 1024;                                                    \
+        _Pragma("unroll") for (int i = 0; i < SA_SLOTS; ++i)                                               \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs_ + (int64_t)spix[i] * ldx_ + kk_ + schunk[i]), \
+                                             (__attribute__((address_space(3))) void*)(dA_ + i * NW * 1024), 16, 0, 0); \
+        char* dB_ = smem + (BUFI) * SBUF + BM * 128 + wave * 1024;                                         \
+        _Pragma("unroll") for (int i = 0; i < B_SLOTS; ++i)                                                \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ws + wsoff[i] + k0_), \
+                                             (__attribute__((address_space(3))) void*)(dB_ + i * NW * 1024), 16, 0, 0); \
+      }
+      K22_ISSUE_SKIP(q0, 0);
+      int buf = 0;
+      for (int q = q0; q < q1; ++q) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (q + 1 < q1) K22_ISSUE_SKIP(q + 1, buf ^ 1);
+        const char* sA = smem + buf * SBUF;
+        const char* sB = sA + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          Frag<T> a[MI], b[NI];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) ld_frag_at(a[mi], sA + (abase + mi * 32) * 128, bsw, ks, h);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) ld_frag_at(b[ni], sB + brow[ni], bsw, ks, h);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], b[ni], a[mi]);
+        }
+        buf ^= 1;
+      }
+#undef K22_ISSUE_SKIP
+    }
+  }
   wait_vmcnt<0>();
   __syncthreads();  // every wave is done with the operand buffers: the LDS becomes the fp32 output tile
 
@@ -279,6 +357,11 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const IgemmParams p) {
     const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
     bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
     bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+  }
+  if (finish && n_ok && p.bias2 != nullptr) {
+    const float4 b0 = *reinterpret_cast<const float4*>(p.bias2 + n), b1 = *reinterpret_cast<const float4*>(p.bias2 + n + 4);
+    bias8[0] += b0.x; bias8[1] += b0.y; bias8[2] += b0.z; bias8[3] += b0.w;
+    bias8[4] += b1.x; bias8[5] += b1.y; bias8[6] += b1.z; bias8[7] += b1.w;
   }
   const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
   float* part = finish ? nullptr : p.partial + (int64_t)bz * p.M * p.N;
@@ -347,15 +430,19 @@ static size_t halo_smem_bytes(const IgemmParams& p, int bm, int nbst) {
   const size_t main_loop = (size_t)2 * halo_rows(p, bm) * 128 + (size_t)nbst * HALO_BN * 128;
   const size_t epi = (size_t)bm * (HALO_BN * 4 + 16);
   const size_t red = (size_t)32 * HALO_BN * 2 * 4;
+  const size_t skip = p.S0 ? (size_t)2 * (bm * 128 + HALO_BN * 128) : 0;
   size_t m = main_loop > epi ? main_loop : epi;
+  m = m > skip ? m : skip;
   return m > red ? m : red;
 }
 
-// deepest weight ring (<= 4) that fits the LDS next to the double-buffered halo and still leaves enough
-// halo slots (taps 0 .. 9-NBST, one 8-row piece per wave each); 0 = the problem does not fit at all
+// deepest weight ring (2, 3, 4 or 6 tiles) that fits the LDS next to the double-buffered halo and still leaves
+// enough halo slots (taps 0 .. 9-NBST, one 8-row piece per wave each); 0 = the problem does not fit at all.
+// Depth matters at the low-resolution levels: their weights stream from HBM (~2 us away) while a tap is
+// 0.2-0.4 us of MFMA work, so a workgroup must keep ~64+ KB of weight tiles in flight (Little's law).
 static int halo_pick_nbst(const IgemmParams& p, int bm) {
   const int np = halo_rows(p, bm) / 8;
-  for (int nbst = 4; nbst >= 2; --nbst) {
+  for (int nbst : {6, 4, 3, 2}) {
     if (np > (10 - nbst) * HALO_NW) continue;
     if (halo_smem_bytes(p, bm, nbst) > 160 * 1024) continue;
     return nbst;
@@ -369,6 +456,10 @@ bool conv3_halo_supported(const IgemmParams& p, int dtype, int bm) {
   if (p.out_mode != IG_OUT_ROWMAJOR && p.out_mode != IG_OUT_ROWMAJOR_F32) return false;
   if (p.N % 8 || p.ldo % 8 || (p.residual && p.ldr % 8) || p.Kc % BK) return false;
   if (p.H <= 0 || p.W <= 0 || p.M % (p.H * p.W)) return false;
+  if (p.S0 != nullptr) {
+    if (!p.Ws || p.SK0 % BK || p.SK1 % BK || (p.SK1 > 0 && !p.S1) || p.SK0 <= 0) return false;
+    if ((int64_t)p.M * (p.SK0 > p.SK1 ? p.SK0 : p.SK1) >= (1ll << 31) || (int64_t)p.Npad * (p.SK0 + p.SK1) >= (1ll << 31)) return false;
+  }
   if (halo_pick_nbst(p, bm) == 0) return false;
   if ((int64_t)(p.H + 2) * (p.W + 2) * p.Kc >= (1ll << 31) || (int64_t)p.Npad * 9 * p.Kc >= (1ll << 31)) return false;
   return true;
@@ -398,14 +489,15 @@ template <typename T, int BM>
 static int launch_halo_nbst(const IgemmParams& p, int nbst, int splitk, hipStream_t stream) {
   if (nbst == 2) return launch_halo_cfg<T, BM, 2>(p, splitk, stream);
   if (nbst == 3) return launch_halo_cfg<T, BM, 3>(p, splitk, stream);
-  return launch_halo_cfg<T, BM, 4>(p, splitk, stream);
+  if (nbst <= 5) return launch_halo_cfg<T, BM, 4>(p, splitk, stream);
+  return launch_halo_cfg<T, BM, 6>(p, splitk, stream);
 }
 
 // Launches the halo kernel only (the split-K reduction, if any, is the caller's: launch_igemm).
 int launch_conv3_halo(const IgemmParams& p, int dtype, int bm, int splitk, hipStream_t stream) {
   if (!conv3_halo_supported(p, dtype, bm)) return k22_set_error(K22_EINVAL, "conv3_halo: unsupported problem");
   int nbst = halo_pick_nbst(p, bm);
-  if (p.stages >= 2 && p.stages < nbst) nbst = p.stages;  // tuning knob: shallower ring on request
+  if (p.stages >= 2 && p.stages < nbst) nbst = p.stages == 5 ? 4 : p.stages;  // tuning knob: shallower ring on request
   if (dtype == K22_BF16) return bm == 256 ? launch_halo_nbst<bf16_t, 256>(p, nbst, splitk, stream) : launch_halo_nbst<bf16_t, 128>(p, nbst, splitk, stream);
   return bm == 256 ? launch_halo_nbst<float, 256>(p, nbst, splitk, stream) : launch_halo_nbst<float, 128>(p, nbst, splitk, stream);
 }

@@ -85,3 +85,25 @@ int launch_cast_rows(const float* x, void* y, int rows, int cols, int64_t ldx, i
 int launch_kv_pack(const KvPackParams& p, int dtype, hipStream_t s);
 int launch_attention(const AttentionParams& p, int dtype, hipStream_t s);
 int launch_sampler_step(const SamplerParams& p, hipStream_t s);
+
+// ---- MoVQ decoder (movq.hip / movq_kernels.hip) -----------------------------------------------------------
+struct SpatialNormParams {
+  const void* x;          // NHWC T [B][H][W][C]
+  const float* coeff;     // [B][C][2] GroupNorm (A, Bc) incl. gamma / beta
+  const float* zq;        // NHWC fp32 [B][h0][w0][4] raw latent; nearest-resized: (y, x) -> (y >> shift, x >> shift)
+  const float* wy; const float* by;   // conv_y 1x1: [C][4], [C]
+  const float* wb; const float* bb;   // conv_b 1x1: [C][4], [C]
+  void* out;              // NHWC T, optionally zero-bordered
+  int B, H, W, C, h0, w0, shift, act, pad;
+};
+int launch_spatialnorm_apply(const SpatialNormParams& p, int dtype, hipStream_t s);
+// nearest x2 upsample of an unpadded NHWC tensor into a zero-bordered one (input of Upsample.conv)
+int launch_upsample2_pad(const void* x, void* y, int B, int H, int W, int C, int dtype, hipStream_t s);
+// in-place softmax over rows of length L (scaled logits), T storage, fp32 math
+int launch_softmax_rows(void* x, int64_t rows, int L, float scale, int dtype, hipStream_t s);
+// z [B][4][h][w] fp32 NCHW -> zq NHWC fp32 [B][h][w][4] and post_quant_conv(z) as zero-bordered NHWC T with the 4
+// channels zero-extended to Cpad (the K slab of the implicit GEMM)
+int launch_movq_prepare(const float* z, const float* wpq, const float* bpq, float* zq, void* xin, int B, int h, int w,
+                        int Cpad, int dtype, hipStream_t s);
+// fp32 NCHW [-1,1] image -> uint8 NHWC:  ((x + 1) * 127.5).round().clamp(0, 255)   (kandinsky2/utils.py:57-70)
+int launch_to_uint8_nhwc(const float* x, unsigned char* y, int B, int C, int H, int W, hipStream_t s);

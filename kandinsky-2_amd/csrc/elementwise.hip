@@ -102,11 +102,14 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnStatsParams p) {
 }
 
 // ---- GroupNorm pass 2: fold mean/rstd, gamma/beta and FiLM into y = x*A[c] + Bc[c] -------------
-// grid (groups, B), one wave per (batch, group): lanes sum the per-channel partials of the group's channels
-// over all row blocks in a fixed strided order (fp64, deterministic), butterfly-reduce, then write
-// coeff[b][c] = (A, Bc).  The input may be a virtual concat of two tensors (a group may straddle them).
-__global__ __launch_bounds__(64) void gn_coeff_kernel(GnCoeffParams p) {
-  const int lane = threadIdx.x, g = blockIdx.x, b = blockIdx.y;
+// grid (groups, B), 256 threads per (batch, group): threads sum the per-channel partials of the group's channels
+// over all row blocks in a fixed strided order (fp64, 4 loads in flight per thread), fixed-order block reduction
+// (deterministic), then write coeff[b][c] = (A, Bc).  The input may be a virtual concat of two tensors (a group
+// may straddle them).
+__global__ __launch_bounds__(256) void gn_coeff_kernel(GnCoeffParams p) {
+  __shared__ double red[4][2];
+  __shared__ float ms[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = blockIdx.x, b = blockIdx.y;
   const int cg = p.C / p.groups;
   double s = 0.0, q = 0.0;
   int off = 0;
@@ -119,7 +122,18 @@ __global__ __launch_bounds__(64) void gn_coeff_kernel(GnCoeffParams p) {
       if (nc > 0) {
         const float* base = sr.st + ((int64_t)b * sr.rpi * sr.C + (c_lo - off)) * 2;
         const int items = sr.rpi * nc;
-        for (int i = lane; i < items; i += 64) {
+        int i = tid;
+        for (; i + 768 < items; i += 1024) {
+          float2 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int ii = i + 256 * u, r = ii / nc, cc = ii - r * nc;
+            v[u] = *reinterpret_cast<const float2*>(base + ((int64_t)r * sr.C + cc) * 2);
+          }
+          s += ((double)v[0].x + (double)v[1].x) + ((double)v[2].x + (double)v[3].x);
+          q += ((double)v[0].y + (double)v[1].y) + ((double)v[2].y + (double)v[3].y);
+        }
+        for (; i < items; i += 256) {
           const int r = i / nc, cc = i - r * nc;
           const float2 v = *reinterpret_cast<const float2*>(base + ((int64_t)r * sr.C + cc) * 2);
           s += (double)v.x;
@@ -134,13 +148,21 @@ __global__ __launch_bounds__(64) void gn_coeff_kernel(GnCoeffParams p) {
     s += __shfl_xor(s, o, 64);
     q += __shfl_xor(q, o, 64);
   }
-  const double n = (double)p.HW * (double)cg;
-  const double mean = s / n;
-  double var = q / n - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const float mean_f = (float)mean;
-  const float rstd_f = (float)(1.0 / sqrt(var + (double)p.eps));
-  for (int c = g * cg + lane; c < (g + 1) * cg; c += 64) {
+  if (lane == 0) { red[wave][0] = s; red[wave][1] = q; }
+  __syncthreads();
+  if (tid == 0) {
+    const double st = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    const double qt = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    const double n = (double)p.HW * (double)cg;
+    const double mean = st / n;
+    double var = qt / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    ms[0] = (float)mean;
+    ms[1] = (float)(1.0 / sqrt(var + (double)p.eps));
+  }
+  __syncthreads();
+  const float mean_f = ms[0], rstd_f = ms[1];
+  for (int c = g * cg + tid; c < (g + 1) * cg; c += 256) {
     float A = rstd_f * p.gamma[c];
     float Bc = p.beta[c] - mean_f * A;
     if (p.film != nullptr) {
@@ -154,7 +176,8 @@ __global__ __launch_bounds__(64) void gn_coeff_kernel(GnCoeffParams p) {
 }
 
 // ---- GroupNorm pass 3: apply (+act) (+avgpool2 / nearest-up2) and write the (optionally
-// zero-bordered) NHWC tensor the next conv / GEMM consumes.  One thread = 16 bytes of output.
+// zero-bordered) NHWC tensor the next conv / GEMM consumes.  One thread = 16 bytes of output;
+// grid (chunks of one output row, padded output rows, batch): one 32-bit division per thread.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyParams p) {
   constexpr int EPV = Vec16<T>::N;
@@ -162,57 +185,53 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyParams p) {
   const int Ho = p.mode == 1 ? p.H / 2 : (p.mode == 2 ? p.H * 2 : p.H);
   const int Wo = p.mode == 1 ? p.W / 2 : (p.mode == 2 ? p.W * 2 : p.W);
   const int pad = p.pad, Hp = Ho + 2 * pad, Wp = Wo + 2 * pad;
-  const int64_t total = (int64_t)p.B * Hp * Wp * CV;
-  T* out = reinterpret_cast<T*>(p.out);
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int cv = (int)(i % CV);
-    int64_t t = i / CV;
-    const int xo = (int)(t % Wp) - pad; t /= Wp;
-    const int yo = (int)(t % Hp) - pad;
-    const int b = (int)(t / Hp);
-    Vec16<T> o;
-    if (xo < 0 || yo < 0 || xo >= Wo || yo >= Ho) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Wp * CV) return;
+  const int xp = idx / CV, cv = idx - xp * CV;
+  const int xo = xp - pad, yo = (int)blockIdx.y - pad, b = blockIdx.z;
+  T* out = reinterpret_cast<T*>(p.out) + (((int64_t)b * Hp + blockIdx.y) * Wp + xp) * C + cv * EPV;
+  Vec16<T> o;
+  if (xo < 0 || yo < 0 || xo >= Wo || yo >= Ho) {
 #pragma unroll
-      for (int k = 0; k < EPV / 2; ++k) o.set2(k, 0.f, 0.f);
-    } else {
-      const int c = cv * EPV;
-      const T* src; int cs, ld;
-      if (c < p.C0) { src = reinterpret_cast<const T*>(p.x0); cs = c; ld = p.C0; }
-      else { src = reinterpret_cast<const T*>(p.x1); cs = c - p.C0; ld = p.C1; }
-      float A[EPV], Bc[EPV];
-      const float* cf = p.coeff + ((int64_t)b * C + c) * 2;
+    for (int k = 0; k < EPV / 2; ++k) o.set2(k, 0.f, 0.f);
+  } else {
+    const int c = cv * EPV;
+    const T* src; int cs, ld;
+    if (c < p.C0) { src = reinterpret_cast<const T*>(p.x0); cs = c; ld = p.C0; }
+    else { src = reinterpret_cast<const T*>(p.x1); cs = c - p.C0; ld = p.C1; }
+    float A[EPV], Bc[EPV];
+    const float* cf = p.coeff + ((int64_t)b * C + c) * 2;
 #pragma unroll
-      for (int k = 0; k < EPV; k += 2) {
-        const float4 q = *reinterpret_cast<const float4*>(cf + 2 * k);
-        A[k] = q.x; Bc[k] = q.y; A[k + 1] = q.z; Bc[k + 1] = q.w;
-      }
-      float r[EPV];
-      if (p.mode == 1) {
-#pragma unroll
-        for (int k = 0; k < EPV; ++k) r[k] = 0.f;
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < 2; ++dx) {
-            Vec16<T> v;
-            v.raw = *reinterpret_cast<const decltype(v.raw)*>(src + ((int64_t)(b * p.H + 2 * yo + dy) * p.W + 2 * xo + dx) * ld + cs);
-#pragma unroll
-            for (int k = 0; k < EPV; ++k) r[k] += apply_act(v.get(k) * A[k] + Bc[k], p.act);
-          }
-#pragma unroll
-        for (int k = 0; k < EPV; ++k) r[k] *= 0.25f;
-      } else {
-        const int yi = p.mode == 2 ? yo >> 1 : yo, xi = p.mode == 2 ? xo >> 1 : xo;
-        Vec16<T> v;
-        v.raw = *reinterpret_cast<const decltype(v.raw)*>(src + ((int64_t)(b * p.H + yi) * p.W + xi) * ld + cs);
-#pragma unroll
-        for (int k = 0; k < EPV; ++k) r[k] = apply_act(v.get(k) * A[k] + Bc[k], p.act);
-      }
-#pragma unroll
-      for (int k = 0; k < EPV / 2; ++k) o.set2(k, r[2 * k], r[2 * k + 1]);
+    for (int k = 0; k < EPV; k += 2) {
+      const float4 q = *reinterpret_cast<const float4*>(cf + 2 * k);
+      A[k] = q.x; Bc[k] = q.y; A[k + 1] = q.z; Bc[k + 1] = q.w;
     }
-    *reinterpret_cast<decltype(o.raw)*>(out + i * EPV) = o.raw;
+    float r[EPV];
+    if (p.mode == 1) {
+      Vec16<T> v[4];
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx)
+          v[dy * 2 + dx].raw = *reinterpret_cast<const decltype(v[0].raw)*>(src + ((int64_t)(b * p.H + 2 * yo + dy) * p.W + 2 * xo + dx) * ld + cs);
+#pragma unroll
+      for (int k = 0; k < EPV; ++k) {
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc += apply_act(v[q].get(k) * A[k] + Bc[k], p.act);
+        r[k] = acc * 0.25f;
+      }
+    } else {
+      const int yi = p.mode == 2 ? yo >> 1 : yo, xi = p.mode == 2 ? xo >> 1 : xo;
+      Vec16<T> v;
+      v.raw = *reinterpret_cast<const decltype(v.raw)*>(src + ((int64_t)(b * p.H + yi) * p.W + xi) * ld + cs);
+#pragma unroll
+      for (int k = 0; k < EPV; ++k) r[k] = apply_act(v.get(k) * A[k] + Bc[k], p.act);
+    }
+#pragma unroll
+    for (int k = 0; k < EPV / 2; ++k) o.set2(k, r[2 * k], r[2 * k + 1]);
   }
+  *reinterpret_cast<decltype(o.raw)*>(out) = o.raw;
 }
 
 // ---- raw 2x resample of the residual branch (x_upd), unpadded NHWC -> unpadded NHWC ------------
@@ -451,7 +470,7 @@ int launch_gn_stats(const GnStatsParams& p, int dtype, hipStream_t s) {
   return K22_OK;
 }
 int launch_gn_coeff(const GnCoeffParams& p, int B, hipStream_t s) {
-  hipLaunchKernelGGL(gn_coeff_kernel, dim3(p.groups, B), dim3(64), 0, s, p);
+  hipLaunchKernelGGL(gn_coeff_kernel, dim3(p.groups, B), dim3(256), 0, s, p);
   K22_CHECK_LAUNCH();
   return K22_OK;
 }
@@ -461,10 +480,11 @@ int launch_gn_apply(const GnApplyParams& p, int dtype, hipStream_t s) {
   if (C % epv || p.C0 % epv) return k22_set_error(K22_EINVAL, "gn_apply: channel alignment");
   const int Ho = p.mode == 1 ? p.H / 2 : (p.mode == 2 ? p.H * 2 : p.H);
   const int Wo = p.mode == 1 ? p.W / 2 : (p.mode == 2 ? p.W * 2 : p.W);
-  const int64_t total = (int64_t)p.B * (Ho + 2 * p.pad) * (Wo + 2 * p.pad) * (C / epv);
-  const int nb = grid_for(total, 256, 8192);
-  if (dtype == K22_BF16) hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(nb), dim3(256), 0, s, p);
+  const int Hp = Ho + 2 * p.pad, Wp = Wo + 2 * p.pad;
+  if (Hp > 65535 || p.B > 65535) return k22_set_error(K22_EINVAL, "gn_apply: tensor too large");
+  dim3 grid((Wp * (C / epv) + 255) / 256, Hp, p.B);
+  if (dtype == K22_BF16) hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, p);
   K22_CHECK_LAUNCH();
   return K22_OK;
 }

@@ -36,6 +36,7 @@ struct Op {
   std::function<int(hipStream_t)> fn;
   int kind = OP_MISC;
   double flops = 0.0;   // algorithmic FLOPs (2*M*N*K) for MFMA ops
+  double flops2 = 0.0;  // FLOPs of a fused 1x1 skip connection riding on a conv op
   double bytes = 0.0;   // algorithmic HBM bytes (read + write) for HBM-bound ops
   int kernels = 1;      // kernel launches issued by fn
   Op() {}
@@ -56,6 +57,7 @@ struct Tuned {
   bool want_stats = false;     // epilogue also emits the GroupNorm partial sums of its output
   int rpi = 0;                 // stats rows per image under cfg
   float best_us = 0.f;
+  Slot* aux0 = nullptr; Slot* aux1 = nullptr;  // IG_OUT_QKV: this block's K_all / V^T_all
   std::function<int(hipStream_t)> run;
 };
 
@@ -84,6 +86,7 @@ struct K22UNet {
   std::deque<Tuned> tuned;  // stable addresses: op closures and Act descriptors point into it
   bool tuned_done = false;
   int autotune = 1;
+  int fuse_skip = 1;
   size_t ws_bytes = 0;
   char* ws = nullptr;
   bool cond_set = false;
@@ -179,8 +182,8 @@ struct K22UNet {
       for (int bm : {256, 128}) {
         if (!conv3_halo_supported(p, dtype, bm) || p.N < 128) continue;
         const int nb = B * conv3_halo_tiles_per_image(p, bm) * ((p.N + 127) / 128);
-        for (int sk : {1, 2, 3, 4, 6, 8, 12}) {
-          if (sk > nslab || (sk > 1 && nb * sk > 1024) || (sk > 1 && nb >= 256)) continue;
+        for (int sk : {1, 2, 3, 4, 5, 6, 8, 10, 12}) {
+          if (sk > nslab || (sk > 1 && nb * sk > 800) || (sk > 1 && nb >= 256)) continue;
           Cfg c; c.algo = 2; c.bm = bm; c.bn = 0; c.splitk = sk; c.stages = 0;
           all.push_back(c);
         }
@@ -188,11 +191,12 @@ struct K22UNet {
     }
     const int tiles[3][2] = {{128, 128}, {128, 64}, {64, 64}};
     for (auto& tl : tiles) {
+      if (p.S0 != nullptr) break;  // a fused skip connection rides on the halo kernel only
       if (tl[1] == 128 && p.N <= 64) continue;
       if (tl[0] == 128 && p.M <= 64) continue;
       const int nb = ((p.M + tl[0] - 1) / tl[0]) * ((p.N + tl[1] - 1) / tl[1]);
       for (int sk : {1, 2, 4, 8, 16}) {
-        if (sk > 1 && (nkt / sk < 4 || nb * sk > 1536 || nb >= 384)) continue;
+        if (sk > 1 && (nkt / sk < 4 || nb * sk > 1536 || nb >= 384 || p.out_mode == IG_OUT_QKV)) continue;
         Cfg c; c.algo = 1; c.bm = tl[0]; c.bn = tl[1]; c.splitk = sk; c.stages = 2;
         all.push_back(c);
       }
@@ -212,6 +216,7 @@ struct K22UNet {
     IgemmParams q = t.p;
     q.algo = 0; q.force_bm = 0; q.force_bn = 0; q.splitk = 0; q.stages = 0;
     Cfg c; c.algo = 0; c.bm = 0; c.bn = 0; c.splitk = igemm_choose_splitk(q, dtype); c.stages = 0;
+    if (q.out_mode == IG_OUT_QKV) c.splitk = 1;
     apply_cfg(q, c);
     if (t.want_stats && igemm_stats_rows_per_image(q, dtype) <= 0) {
       if (t.cands.empty()) { t.want_stats = false; }
@@ -241,7 +246,8 @@ struct K22UNet {
   // conv3x3 over a zero-bordered slot `src` [B][Hc+2][Wc+2][Cin].  `stats` (optional) receives the GroupNorm
   // partial sums of the output; returns the launch descriptor (null when the output is not a tunable T tensor).
   Tuned* op_conv(OpList& L, Slot* src, int Hc, int Wc, int Cin, int Cout,
-                 const std::string& pfx, const Act* residual, Slot* dst, int out_mode, Slot* stats = nullptr) {
+                 const std::string& pfx, const Act* residual, Slot* dst, int out_mode, Slot* stats = nullptr,
+                 const Act* skip_in = nullptr, const std::string& skip_pfx = std::string()) {
     tuned.emplace_back();
     Tuned* t = &tuned.back();
     IgemmParams& p = t->p;
@@ -249,6 +255,14 @@ struct K22UNet {
     p.M = B * Hc * Wc; p.N = Cout; p.Npad = (Cout + 63) / 64 * 64; p.Kc = Cin; p.K0 = Cin; p.taps = 9;
     p.H = Hc; p.W = Wc; p.ldo = Cout; p.ldr = Cout; p.out_mode = out_mode; p.act = K22_ACT_NONE;
     p.Wp = W_(pfx + ".weight"); p.bias = Wf(pfx + ".bias");
+    Act sk;
+    if (skip_in) {
+      // fused 1x1 skip_connection: S0 is only a non-null marker here, the device pointers are set at launch
+      sk = *skip_in;
+      p.S0 = reinterpret_cast<const void*>(1); p.S1 = sk.s1 ? reinterpret_cast<const void*>(1) : nullptr;
+      p.SK0 = sk.C0; p.SK1 = sk.C1;
+      p.Ws = W_(skip_pfx + ".weight"); p.bias2 = Wf(skip_pfx + ".bias");
+    }
     t->want_stats = stats != nullptr;
     make_candidates(*t);
     default_cfg(*t);
@@ -262,21 +276,24 @@ struct K22UNet {
       apply_cfg(q, t->cfg);
       q.A0 = ptr(src); q.residual = rs ? ptr(rs) : nullptr; q.out = ptr(dst); q.partial = ptr<float>(s_splitk);
       q.stats = t->want_stats ? ptr<float>(stats) : nullptr;
+      if (q.S0) { q.S0 = ptr(sk.s0); q.S1 = sk.s1 ? ptr(sk.s1) : nullptr; }
       return launch_igemm(q, dt, st);
     };
-    L.push_back(Op([=](hipStream_t st) { return t->run(st); }, OP_CONV3, 2.0 * p.M * (double)p.N * 9.0 * p.Kc, 0.0, 1));
+    const double fl = 2.0 * p.M * (double)p.N * 9.0 * p.Kc;
+    L.push_back(Op([=](hipStream_t st) { return t->run(st); }, OP_CONV3, fl, 0.0, 1));
+    if (skip_in) L.back().flops2 = 2.0 * p.M * (double)p.N * (p.SK0 + p.SK1);  // counted in the GEMM class
     return t;
   }
 
   // GEMM over unpadded rows (1x1 conv / linear); `in` may be a virtual concat.
   Tuned* op_gemm(OpList& L, const Act& in, int M, int N, const std::string& pfx,
-                 const Act* residual, Slot* dst, int ldo = 0) {
+                 const Act* residual, Slot* dst, int ldo = 0, int out_mode = IG_OUT_ROWMAJOR) {
     tuned.emplace_back();
     Tuned* t = &tuned.back();
     IgemmParams& p = t->p;
     p.stages = -1;
     p.M = M; p.N = N; p.Npad = (N + 63) / 64 * 64; p.Kc = in.C(); p.K0 = in.C0; p.taps = 1;
-    p.lda0 = in.C0; p.lda1 = in.C1; p.ldo = ldo ? ldo : N; p.ldr = N; p.out_mode = IG_OUT_ROWMAJOR;
+    p.lda0 = in.C0; p.lda1 = in.C1; p.ldo = ldo ? ldo : N; p.ldr = N; p.out_mode = out_mode;
     p.act = K22_ACT_NONE;
     p.Wp = W_(pfx + ".weight"); p.bias = Wf(pfx + ".bias");
     make_candidates(*t);
@@ -291,6 +308,7 @@ struct K22UNet {
       apply_cfg(q, t->cfg);
       q.A0 = ptr(a.s0); q.A1 = a.s1 ? ptr(a.s1) : nullptr;
       q.residual = rs ? ptr(rs) : nullptr; q.out = ptr(dst); q.partial = ptr<float>(s_splitk);
+      if (t->aux0) { q.kall = ptr(t->aux0); q.vtall = ptr(t->aux1); }
       return launch_igemm(q, dt, st);
     };
     L.push_back(Op([=](hipStream_t st) { return t->run(st); }, OP_GEMM, 2.0 * p.M * (double)p.N * p.Kc, 0.0, 1));
@@ -303,6 +321,22 @@ struct K22UNet {
   int tune_all(hipStream_t st) {
     typedef std::tuple<int, int, int, int, int, int, int, int, bool, bool> Key;
     std::map<Key, std::pair<Cfg, float>> cache;
+    // optional persistent cache (env K22_TUNE_CACHE=<file>): one line per problem, reused by later processes
+    const char* cache_path = getenv("K22_TUNE_CACHE");
+    size_t loaded = 0;
+    if (cache_path) {
+      if (FILE* f = fopen(cache_path, "r")) {
+        int dtp, taps, M, N, Kc, K0, H, W, om, ws, algo, bm, bn, sk, stg; float us;
+        while (fscanf(f, "%d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %f", &dtp, &taps, &M, &N, &Kc, &K0, &H, &W, &om, &ws,
+                      &algo, &bm, &bn, &sk, &stg, &us) == 16) {
+          if (dtp != dtype) continue;
+          Cfg c; c.algo = algo; c.bm = bm; c.bn = bn; c.splitk = sk; c.stages = stg;
+          cache[Key(taps, M, N, Kc, K0, H, W, om, ws != 0, false)] = std::make_pair(c, us * 1e-3f);
+        }
+        fclose(f);
+        loaded = cache.size();
+      }
+    }
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return k22_set_error(K22_EHIP, "tune: hipEventCreate");
     int rc = K22_OK;
@@ -334,11 +368,29 @@ struct K22UNet {
         if (rc) break;
         it = cache.emplace(key, std::make_pair(best, best_ms)).first;
       }
-      t.cfg = it->second.first;
-      t.best_us = it->second.second * 1e3f;
+      {
+        // a cached line from an older build may name a configuration this build would not generate: check it
+        const Cfg& c = it->second.first;
+        bool ok = false;
+        for (auto& k : t.cands) ok = ok || (k.algo == c.algo && k.bm == c.bm && k.bn == c.bn && k.splitk == c.splitk);
+        if (ok) { t.cfg = c; t.best_us = it->second.second * 1e3f; }
+      }
       finish_cfg(t);
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (rc == K22_OK && cache_path && cache.size() > loaded) {
+      if (FILE* f = fopen(cache_path, "a")) {
+        size_t i = 0;
+        for (auto& kv : cache) {
+          (void)i;
+          const Key& k = kv.first; const Cfg& c = kv.second.first;
+          fprintf(f, "%d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %.2f\n", dtype, std::get<0>(k), std::get<1>(k), std::get<2>(k),
+                  std::get<3>(k), std::get<4>(k), std::get<5>(k), std::get<6>(k), std::get<7>(k), std::get<8>(k) ? 1 : 0,
+                  c.algo, c.bm, c.bn, c.splitk, c.stages, kv.second.second * 1e3f);
+        }
+        fclose(f);
+      }
+    }
     return rc;
   }
 
@@ -365,6 +417,19 @@ struct K22UNet {
       ops.push_back([=](hipStream_t st) { return launch_resample(ptr(a.s0), ptr(s_S), Bn, a.H, a.W, Cin, updown, dt, st); });
       skip.s0 = s_S;
     } else if (Cin != Cout) {
+      // 1x1 skip_connection: fused into the second conv (halo kernel) when it applies, else its own GEMM
+      IgemmParams probe = {};
+      probe.M = B * Ho * Wo; probe.N = Cout; probe.Npad = (Cout + 63) / 64 * 64; probe.Kc = Cout; probe.K0 = Cout; probe.taps = 9;
+      probe.H = Ho; probe.W = Wo; probe.ldo = Cout; probe.ldr = Cout; probe.out_mode = IG_OUT_ROWMAJOR;
+      probe.S0 = reinterpret_cast<const void*>(1); probe.S1 = in.s1 ? reinterpret_cast<const void*>(1) : nullptr;
+      probe.SK0 = in.C0; probe.SK1 = in.C1; probe.Ws = reinterpret_cast<const void*>(1);
+      if (fuse_skip && Cout >= 128 && (conv3_halo_supported(probe, dtype, 256) || conv3_halo_supported(probe, dtype, 128))) {
+        Tuned* t2 = op_conv(ops, s_P2, Ho, Wo, Cout, Cout, pfx + ".out_layers.3", nullptr, dst, IG_OUT_ROWMAJOR, dst_stats,
+                            &in, pfx + ".skip_connection");
+        Act out; out.s0 = dst; out.C0 = Cout; out.H = Ho; out.W = Wo;
+        if (t2->want_stats) { out.p0 = t2; out.st0 = dst_stats; }
+        return out;
+      }
       op_gemm(ops, in, B * Ho * Wo, Cout, pfx + ".skip_connection", nullptr, s_S);
       skip.s0 = s_S;
     } else {
@@ -377,36 +442,45 @@ struct K22UNet {
     return out;
   }
 
-  // AttentionBlock (unet.py:223-269) + QKVAttention (:272-340)
+  // AttentionBlock (unet.py:223-269) + QKVAttention (:272-340).  The qkv projection writes q row-major and k / v
+  // straight into this block's attention operands (K_all, V^T_all) behind the context keys, which were projected
+  // (encoder_kv) and packed once per conditioning: no per-step packing kernel.
   Act attnblock(const std::string& pfx, const Act& in, Slot* dst) {
     const int C = in.C0, T = in.H * in.W, Hh = C / 64, S = cfg.ctx_len;
     const int Tk = S + T, Tkp = (Tk + 63) / 64 * 64;
-    const int idx = n_attn++;
+    n_attn++;
     op_gn(ops, in, pfx + ".norm", -1, K22_ACT_NONE, 0, 0, s_N);
     Act n; n.s0 = s_N; n.C0 = C; n.H = in.H; n.W = in.W;
-    op_gemm(ops, n, B * T, 3 * C, pfx + ".qkv", nullptr, s_QKV);
-    // encoder_kv (step-invariant) -> cond_ops
+    Slot* kall = new_slot((size_t)B * Hh * Tkp * 64 * esz);
+    Slot* vtall = new_slot((size_t)B * Hh * Tkp * 64 * esz);
+    // encoder_kv (step-invariant) + context part of K_all / V^T_all (and zero padding) -> cond_ops
     Slot* ckv = new_slot((size_t)B * S * 2 * C * esz);
     s_ctxkv.push_back(ckv);
+    const int Bn = B, dt = dtype;
     {
       Act c; c.s0 = s_ctx; c.C0 = cfg.ctx_dim; c.H = 1; c.W = S;
       op_gemm(cond_ops, c, B * S, 2 * C, pfx + ".encoder_kv", nullptr, ckv);
+      cond_ops.push_back(Op([=](hipStream_t st) {
+        KvPackParams kp;
+        kp.qkv = nullptr; kp.ctxkv = ptr(ckv); kp.kall = ptr(kall); kp.vtall = ptr(vtall);
+        kp.B = Bn; kp.H = Hh; kp.T = 0; kp.S = S; kp.Tkp = Tkp;
+        return launch_kv_pack(kp, dt, st);
+      }));
     }
-    need(s_KALL, (size_t)B * Hh * Tkp * 64 * esz);
-    need(s_VT, (size_t)B * Hh * Tkp * 64 * esz);
+    // qkv projection in IG_OUT_QKV mode
+    need(s_QKV, (size_t)B * T * C * esz);  // q only
+    {
+      Tuned* t = op_gemm(ops, n, B * T, 3 * C, pfx + ".qkv", nullptr, s_QKV, C, IG_OUT_QKV);
+      t->p.att_T = T; t->p.att_S = S; t->p.att_Tkp = Tkp;
+      t->aux0 = kall; t->aux1 = vtall;
+    }
     need(s_ATT, (size_t)B * T * C * esz);
-    const int Bn = B, dt = dtype;
     ops.push_back(Op([=](hipStream_t st) {
-      KvPackParams kp;
-      kp.qkv = ptr(s_QKV); kp.ctxkv = ptr(ckv); kp.kall = ptr(s_KALL); kp.vtall = ptr(s_VT);
-      kp.B = Bn; kp.H = Hh; kp.T = T; kp.S = S; kp.Tkp = Tkp;
-      int rc = launch_kv_pack(kp, dt, st);
-      if (rc) return rc;
       AttentionParams ap;
-      ap.q = ptr(s_QKV); ap.ldq = 3 * C; ap.kall = ptr(s_KALL); ap.vtall = ptr(s_VT); ap.out = ptr(s_ATT); ap.ldo = C;
+      ap.q = ptr(s_QKV); ap.ldq = C; ap.kall = ptr(kall); ap.vtall = ptr(vtall); ap.out = ptr(s_ATT); ap.ldo = C;
       ap.B = Bn; ap.H = Hh; ap.T = T; ap.Tk = Tk; ap.Tkp = Tkp; ap.scale = 0.125f;
       return launch_attention(ap, dt, st);
-    }, OP_ATTN, 4.0 * Bn * Hh * (double)T * Tk * 64.0, 0.0, 2));
+    }, OP_ATTN, 4.0 * Bn * Hh * (double)T * Tk * 64.0, 0.0, 1));
     Act a; a.s0 = s_ATT; a.C0 = C; a.H = in.H; a.W = in.W;
     op_gemm(ops, a, B * T, C, pfx + ".proj_out", &in, dst);
     Act out; out.s0 = dst; out.C0 = C; out.H = in.H; out.W = in.W;
@@ -652,6 +726,8 @@ int k22_unet_create(const K22UNetConfig* cfg, const K22Weight* weights, int n_we
   {
     const char* e = getenv("K22_AUTOTUNE");  // 0 = heuristics only (no measurement at the first forward)
     u->autotune = e ? (atoi(e) != 0) : 1;
+    const char* f = getenv("K22_FUSE_SKIP");  // 0 = 1x1 skip connections as separate GEMMs
+    u->fuse_skip = f ? (atoi(f) != 0) : 1;
   }
   for (int i = 0; i < n_weights; ++i) u->w[weights[i].name] = weights[i].ptr;
   *out = u;
@@ -786,7 +862,7 @@ int k22_unet_profile(K22UNet* u, int reps, double* ms, double* flops, double* by
   for (auto& e : ev) { hipError_t r = hipEventCreate(&e); if (r != hipSuccess) return k22_set_error_hip(r, __FILE__, __LINE__); }
   for (int k = 0; k < OP_NKINDS; ++k) { ms[k] = 0.0; flops[k] = 0.0; bytes[k] = 0.0; launches[k] = 0; }
   for (size_t i = 0; i < n; ++i) {
-    flops[u->ops[i].kind] += u->ops[i].flops;
+    flops[u->ops[i].kind] += u->ops[i].flops + u->ops[i].flops2;  // a fused 1x1 skip is work of the conv launch
     bytes[u->ops[i].kind] += u->ops[i].bytes;
     launches[u->ops[i].kind] += u->ops[i].kernels;
   }

@@ -35,8 +35,8 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 template <typename T> __device__ __forceinline__ void store4(T* dst, const float* v);
 template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* dst, const float* v) {
   uint2 w;
-  w.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-  w.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+  w.x = pack2_bf16(v[0], v[1]);
+  w.y = pack2_bf16(v[2], v[3]);
   *reinterpret_cast<uint2*>(dst) = w;
 }
 template <> __device__ __forceinline__ void store4<float>(float* dst, const float* v) {
@@ -241,6 +241,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             store4<T>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.ldo + n, v);
           } else if (p.out_mode == IG_OUT_ROWMAJOR_F32) {
             store4<float>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n, v);
+          } else if (p.out_mode == IG_OUT_QKV) {
+            const int C = p.N / 3, heads = C >> 6;
+            const int which = n / C, c = n - which * C;
+            const int head = c >> 6, d = c & 63;
+            const int b = m / p.att_T, t = m - b * p.att_T;
+            if (which == 0) {
+              store4<T>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.ldo + c, v);
+            } else if (which == 1) {
+              store4<T>(reinterpret_cast<T*>(p.kall) + ((int64_t)(b * heads + head) * p.att_Tkp + p.att_S + t) * 64 + d, v);
+            } else {
+              T* vt = reinterpret_cast<T*>(p.vtall) + ((int64_t)(b * heads + head) * 64 + d) * p.att_Tkp + p.att_S + t;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) vt[(int64_t)e * p.att_Tkp] = from_f32<T>(v[e]);
+            }
           } else {
             const int64_t hw = (int64_t)p.H * p.W;
 #pragma unroll
@@ -287,6 +301,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmParams p)
         const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
         v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
       }
+      if (p.bias2 != nullptr) {
+        const float4 bv = *reinterpret_cast<const float4*>(p.bias2 + n);
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+      }
       if (res != nullptr) {
         float rv[4];
         load4f<T>(res + (int64_t)m * p.ldr + n, rv);
@@ -313,6 +331,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmParams p)
     float v = 0.f;
     for (int s = 0; s < p.splitk; ++s) v += p.partial[(int64_t)s * total + i];
     if (p.bias != nullptr) v += p.bias[n];
+    if (p.bias2 != nullptr) v += p.bias2[n];
     if (res != nullptr) v += to_f32(res[(int64_t)m * p.ldr + n]);
     v = apply_act(v, p.act);
     if (p.out_mode == IG_OUT_ROWMAJOR) {
@@ -351,6 +370,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const IgemmPara
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
     if (p.bias != nullptr) {
       const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+      v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if (p.bias2 != nullptr) {
+      const float4 b = *reinterpret_cast<const float4*>(p.bias2 + n);
       v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
     }
     if (res != nullptr) {
@@ -544,8 +567,14 @@ int launch_igemm(const IgemmParams& p, int dtype, hipStream_t stream) {
   if (p.Kc % BK != 0 || p.K0 % BK != 0) return k22_set_error(K22_EINVAL, "igemm: K per tap must be a multiple of 64 (bf16) / 32 (fp32)");
   if (p.Npad % 64 != 0 || p.Npad < p.N) return k22_set_error(K22_EINVAL, "igemm: Npad must be roundup(N,64)");
   if (p.K0 < p.Kc && p.A1 == nullptr) return k22_set_error(K22_EINVAL, "igemm: A1 missing for concat operand");
+  if (p.out_mode == IG_OUT_QKV) {
+    if (p.taps != 1 || p.N % 192 || (p.ldo & 3) || !p.kall || !p.vtall || p.att_T <= 0 || p.M % p.att_T || p.residual || p.splitk > 1)
+      return k22_set_error(K22_EINVAL, "igemm: bad qkv-projection problem (N = 3*heads*64, no residual, no split-K)");
+  }
   IgemmPlan pl = igemm_plan(p, dtype);
+  if (p.out_mode == IG_OUT_QKV) pl.splitk = 1;
   if (pl.splitk > 1 && p.partial == nullptr) pl.splitk = 1;
+  if (p.S0 != nullptr && !pl.halo) return k22_set_error(K22_EINVAL, "igemm: the fused 1x1 skip connection needs the halo kernel");
   if (p.stats != nullptr && pl.splitk == 1 && !pl.halo)
     return k22_set_error(K22_EINVAL, "igemm: GroupNorm partial sums requested from a configuration that cannot produce them");
   if (pl.halo) {

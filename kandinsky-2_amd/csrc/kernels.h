@@ -18,7 +18,10 @@
 // ---------------------------------------------------------------------------------------
 enum IgemmOut { IG_OUT_ROWMAJOR = 0,  // T out[m*ldo + n]
                 IG_OUT_ROWMAJOR_F32 = 1,  // float out[m*ldo + n]
-                IG_OUT_NCHW_F32 = 2 };    // float out[((b*N + n)*H + y)*W + x]   (m = (b*H+y)*W+x)
+                IG_OUT_NCHW_F32 = 2,      // float out[((b*N + n)*H + y)*W + x]   (m = (b*H+y)*W+x)
+                IG_OUT_QKV = 3 };         // qkv projection (N = 3C, columns [q | k | v] x [heads][64]) written straight into
+                                          // the attention operands: q -> T out[m*ldo + n];  k -> kall[b][head][S+t][d];
+                                          // v -> vtall[b][head][d][S+t]   (m = b*T + t; see AttentionParams)
 
 struct IgemmParams {
   const void* A0;
@@ -42,6 +45,12 @@ struct IgemmParams {
   int stages;            // 2..4 = LDS-DMA pipeline depth, anything else = default (env K22_IGEMM_STAGES, else 2)
   int xcd_remap;         // set by the launcher: XCD-aware block renumbering on/off
   int algo;              // taps == 9 only: 0 auto, 1 generic implicit GEMM, 2 LDS-resident halo kernel (conv3_halo.hip)
+  // optional fused 1x1 "skip_connection" of a ResBlock (unet.py:191), halo kernel only:
+  //   out += [S0 | S1](unpadded NHWC rows m, SK0 + SK1 channels) . Ws[n][SK0+SK1]^T + bias2[n]
+  const void* S0; const void* S1; const void* Ws; const float* bias2;
+  int SK0, SK1;
+  void* kall; void* vtall;                 // IG_OUT_QKV only
+  int att_T, att_S, att_Tkp;               // IG_OUT_QKV only: tokens per image, context keys, padded key count
   float* stats;          // optional GroupNorm side output: per-row-block, per-channel (sum, sumsq) of the STORED
                          // values, [stats_rows][N][2] fp32 (see IgemmStatsInfo); null = not wanted
 };

@@ -1,0 +1,188 @@
+// k22 — HBM-bound kernels of the MoVQ decoder (kandinsky2/vqgan/movq_modules.py).
+//
+//   SpatialNorm.forward (movq_modules.py:61-68): GroupNorm(f, 32 groups, eps 1e-6) * conv_y(zq) + conv_b(zq) with
+//     zq = the raw 4-channel latent, nearest-resized to f's size; conv_y / conv_b are 1x1 (4 -> C), evaluated on the
+//     fly here (8 FMAs per element) instead of materialising two [B,C,H,W] maps.  Optional SiLU (nonlinearity,
+//     :29-31) and zero border for the consuming 3x3 conv.
+//   Upsample.forward (:85-98): nearest x2 (+ zero border for its conv).
+//   AttnBlock softmax (:218): softmax(q.k * C^-0.5) over keys, rows of a materialised [T][T] score matrix.
+//   post_quant_conv (autoencoder.py:167,182-185) and the uint8 image epilogue (kandinsky2/utils.py:57-70).
+#include "kernels.h"
+#include "elementwise.h"
+
+template <typename T>
+__global__ __launch_bounds__(256) void spatialnorm_apply_kernel(SpatialNormParams p) {
+  constexpr int EPV = Vec16<T>::N;
+  const int CV = p.C / EPV;
+  const int pad = p.pad, Hp = p.H + 2 * pad, Wp = p.W + 2 * pad;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Wp * CV) return;
+  const int xp = idx / CV, cv = idx - xp * CV;
+  const int xo = xp - pad, yo = (int)blockIdx.y - pad, b = blockIdx.z;
+  T* out = reinterpret_cast<T*>(p.out) + (((int64_t)b * Hp + blockIdx.y) * Wp + xp) * p.C + cv * EPV;
+  Vec16<T> o;
+  if (xo < 0 || yo < 0 || xo >= p.W || yo >= p.H) {
+#pragma unroll
+    for (int k = 0; k < EPV / 2; ++k) o.set2(k, 0.f, 0.f);
+  } else {
+    const int c = cv * EPV;
+    const float4 z = *reinterpret_cast<const float4*>(p.zq + (((int64_t)b * p.h0 + (yo >> p.shift)) * p.w0 + (xo >> p.shift)) * 4);
+    Vec16<T> v;
+    v.raw = *reinterpret_cast<const decltype(v.raw)*>(reinterpret_cast<const T*>(p.x) + (((int64_t)b * p.H + yo) * p.W + xo) * p.C + c);
+    const float* cf = p.coeff + ((int64_t)b * p.C + c) * 2;
+    float r[EPV];
+#pragma unroll
+    for (int k = 0; k < EPV; ++k) {
+      const float2 ab = *reinterpret_cast<const float2*>(cf + 2 * k);
+      const float4 wy = *reinterpret_cast<const float4*>(p.wy + (c + k) * 4);
+      const float4 wb = *reinterpret_cast<const float4*>(p.wb + (c + k) * 4);
+      const float norm = v.get(k) * ab.x + ab.y;
+      const float sy = ((wy.x * z.x + wy.y * z.y) + (wy.z * z.z + wy.w * z.w)) + p.by[c + k];
+      const float sb = ((wb.x * z.x + wb.y * z.y) + (wb.z * z.z + wb.w * z.w)) + p.bb[c + k];
+      r[k] = apply_act(norm * sy + sb, p.act);
+    }
+#pragma unroll
+    for (int k = 0; k < EPV / 2; ++k) o.set2(k, r[2 * k], r[2 * k + 1]);
+  }
+  *reinterpret_cast<decltype(o.raw)*>(out) = o.raw;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2_pad_kernel(const void* xin, void* yout, int B, int H, int W, int C) {
+  constexpr int EPV = Vec16<T>::N;
+  const int CV = C / EPV, Hp = 2 * H + 2, Wp = 2 * W + 2;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Wp * CV) return;
+  const int xp = idx / CV, cv = idx - xp * CV;
+  const int xo = xp - 1, yo = (int)blockIdx.y - 1, b = blockIdx.z;
+  Vec16<T> o;
+  if (xo < 0 || yo < 0 || xo >= 2 * W || yo >= 2 * H) {
+#pragma unroll
+    for (int k = 0; k < EPV / 2; ++k) o.set2(k, 0.f, 0.f);
+  } else {
+    o.raw = *reinterpret_cast<const decltype(o.raw)*>(reinterpret_cast<const T*>(xin) + (((int64_t)b * H + (yo >> 1)) * W + (xo >> 1)) * C + cv * EPV);
+  }
+  *reinterpret_cast<decltype(o.raw)*>(reinterpret_cast<T*>(yout) + (((int64_t)b * Hp + blockIdx.y) * Wp + xp) * C + cv * EPV) = o.raw;
+}
+
+// one workgroup per row; the row (<= 16 K elements at 1024^2) is read twice from L2, written once
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(void* xio, int L, float scale) {
+  constexpr int EPV = Vec16<T>::N;
+  __shared__ float red[8];
+  T* x = reinterpret_cast<T*>(xio) + (int64_t)blockIdx.x * L;
+  const int tid = threadIdx.x;
+  const int nv = L / EPV;
+  float m = -INFINITY;
+  for (int i = tid; i < nv; i += 256) {
+    Vec16<T> v;
+    v.raw = *reinterpret_cast<const decltype(v.raw)*>(x + i * EPV);
+#pragma unroll
+    for (int k = 0; k < EPV; ++k) m = fmaxf(m, v.get(k));
+  }
+  m = wave_max(m);
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * scale;
+  float s = 0.f;
+  for (int i = tid; i < nv; i += 256) {
+    Vec16<T> v;
+    v.raw = *reinterpret_cast<const decltype(v.raw)*>(x + i * EPV);
+#pragma unroll
+    for (int k = 0; k < EPV; ++k) s += expf(v.get(k) * scale - m);
+  }
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[4 + (tid >> 6)] = s;
+  __syncthreads();
+  const float inv = 1.f / ((red[4] + red[5]) + (red[6] + red[7]));
+  for (int i = tid; i < nv; i += 256) {
+    Vec16<T> v, o;
+    v.raw = *reinterpret_cast<const decltype(v.raw)*>(x + i * EPV);
+#pragma unroll
+    for (int k = 0; k < EPV / 2; ++k) o.set2(k, expf(v.get(2 * k) * scale - m) * inv, expf(v.get(2 * k + 1) * scale - m) * inv);
+    *reinterpret_cast<decltype(o.raw)*>(x + i * EPV) = o.raw;
+  }
+}
+
+template <typename T>
+__global__ void movq_prepare_kernel(const float* z, const float* wpq, const float* bpq, float* zq, void* xin, int B, int h, int w, int Cpad) {
+  // one thread per PADDED pixel
+  const int Hp = h + 2, Wp = w + 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * Hp * Wp) return;
+  const int xp = i % Wp, yp = (i / Wp) % Hp, b = i / (Wp * Hp);
+  T* dst = reinterpret_cast<T*>(xin) + (int64_t)i * Cpad;
+  const int y = yp - 1, x = xp - 1;
+  float q[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool inside = (x >= 0 && y >= 0 && x < w && y < h);
+  if (inside) {
+    float zi[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) zi[c] = z[(((int64_t)b * 4 + c) * h + y) * w + x];
+    *reinterpret_cast<float4*>(zq + (((int64_t)b * h + y) * w + x) * 4) = make_float4(zi[0], zi[1], zi[2], zi[3]);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) q[o] = ((wpq[o * 4] * zi[0] + wpq[o * 4 + 1] * zi[1]) + (wpq[o * 4 + 2] * zi[2] + wpq[o * 4 + 3] * zi[3])) + bpq[o];
+  }
+  for (int c = 0; c < Cpad; ++c) dst[c] = from_f32<T>(c < 4 ? q[c] : 0.f);
+}
+
+__global__ void to_uint8_nhwc_kernel(const float* x, unsigned char* y, int B, int C, int H, int W) {
+  const int64_t total = (int64_t)B * H * W * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t pix = i / C;
+    const int b = (int)(pix / ((int64_t)H * W));
+    const int64_t rem = pix - (int64_t)b * H * W;
+    float v = (x[((int64_t)b * C + c) * H * W + rem] + 1.f) * 127.5f;
+    v = rintf(v);                       // torch.round: half to even
+    v = fminf(fmaxf(v, 0.f), 255.f);
+    y[i] = (unsigned char)v;
+  }
+}
+
+int launch_spatialnorm_apply(const SpatialNormParams& p, int dtype, hipStream_t s) {
+  const int epv = dtype == K22_BF16 ? 8 : 4;
+  if (p.C % epv) return k22_set_error(K22_EINVAL, "spatialnorm: channel alignment");
+  const int Hp = p.H + 2 * p.pad, Wp = p.W + 2 * p.pad;
+  if (Hp > 65535 || p.B > 65535) return k22_set_error(K22_EINVAL, "spatialnorm: tensor too large");
+  dim3 grid((Wp * (p.C / epv) + 255) / 256, Hp, p.B);
+  if (dtype == K22_BF16) hipLaunchKernelGGL(spatialnorm_apply_kernel<bf16_t>, grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(spatialnorm_apply_kernel<float>, grid, dim3(256), 0, s, p);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+int launch_upsample2_pad(const void* x, void* y, int B, int H, int W, int C, int dtype, hipStream_t s) {
+  const int epv = dtype == K22_BF16 ? 8 : 4;
+  if (C % epv) return k22_set_error(K22_EINVAL, "upsample2_pad: channel alignment");
+  const int Hp = 2 * H + 2, Wp = 2 * W + 2;
+  if (Hp > 65535) return k22_set_error(K22_EINVAL, "upsample2_pad: tensor too large");
+  dim3 grid((Wp * (C / epv) + 255) / 256, Hp, B);
+  if (dtype == K22_BF16) hipLaunchKernelGGL(upsample2_pad_kernel<bf16_t>, grid, dim3(256), 0, s, x, y, B, H, W, C);
+  else hipLaunchKernelGGL(upsample2_pad_kernel<float>, grid, dim3(256), 0, s, x, y, B, H, W, C);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+int launch_softmax_rows(void* x, int64_t rows, int L, float scale, int dtype, hipStream_t s) {
+  const int epv = dtype == K22_BF16 ? 8 : 4;
+  if (L % epv || rows <= 0 || rows > 0x7fffffff) return k22_set_error(K22_EINVAL, "softmax_rows: bad shape");
+  if (dtype == K22_BF16) hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, dim3((unsigned)rows), dim3(256), 0, s, x, L, scale);
+  else hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3((unsigned)rows), dim3(256), 0, s, x, L, scale);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+int launch_movq_prepare(const float* z, const float* wpq, const float* bpq, float* zq, void* xin, int B, int h, int w,
+                        int Cpad, int dtype, hipStream_t s) {
+  const int total = B * (h + 2) * (w + 2);
+  if (dtype == K22_BF16) hipLaunchKernelGGL(movq_prepare_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, s, z, wpq, bpq, zq, xin, B, h, w, Cpad);
+  else hipLaunchKernelGGL(movq_prepare_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, s, z, wpq, bpq, zq, xin, B, h, w, Cpad);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+int launch_to_uint8_nhwc(const float* x, unsigned char* y, int B, int C, int H, int W, hipStream_t s) {
+  const int64_t total = (int64_t)B * C * H * W;
+  int nb = (int)((total + 255) / 256);
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(to_uint8_nhwc_kernel, dim3(nb), dim3(256), 0, s, x, y, B, C, H, W);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}

@@ -103,6 +103,33 @@ def test_conv3x3_groupnorm_partial_sums(dtype, B, Cin, Cout, H, W, bm, splitk):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,Cin,Cout,SK0,SK1,H,W,bm,splitk", [
+    (2, 128, 128, 64, 0, 16, 16, 256, 1), (1, 128, 256, 128, 64, 24, 24, 128, 1), (2, 256, 128, 192, 128, 12, 12, 256, 2),
+    (2, 128, 128, 320, 0, 8, 8, 128, 4),
+])
+def test_conv3x3_with_fused_skip_connection(dtype, B, Cin, Cout, SK0, SK1, H, W, bm, splitk):
+    """out = conv3x3(h) + conv1x1(cat(x0, x1)): the channel-changing ResBlock tail in one halo-kernel launch."""
+    import torch.nn.functional as F
+    T = hp.tdt(dtype)
+    h, w3 = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
+    x0 = rnd(B, SK0, H, W, seed=5)
+    x1 = rnd(B, SK1, H, W, seed=6) if SK1 else None
+    ws, b3, bs = rnd(Cout, SK0 + SK1, seed=7, scale=(SK0 + SK1) ** -0.5), rnd(Cout, seed=3), rnd(Cout, seed=8)
+    hpad, w3p = hp.nhwc_padded(h, T), hp.pack_conv3(w3, T)
+    x0n = x0.permute(0, 2, 3, 1).contiguous().to(T)
+    x1n = None if x1 is None else x1.permute(0, 2, 3, 1).contiguous().to(T)
+    wsp = hp.pad_rows(ws.to(T))
+    out = torch.empty(B, H, W, Cout, dtype=T, device="cuda")
+    partial = torch.empty(max(1, splitk) * B * H * W * Cout + 64, device="cuda")
+    _lib.check(_lib.lib().k22_conv3x3_skip(hpad.data_ptr(), w3p.data_ptr(), b3.data_ptr(), x0n.data_ptr(), _lib.ptr(x1n), SK0, SK1,
+                                           wsp.data_ptr(), bs.data_ptr(), out.data_ptr(), partial.data_ptr(), B, H, W, Cin, Cout,
+                                           w3p.shape[0], splitk, bm, dtype, hp.stream()))
+    xin = x0.to(T).float() if x1 is None else torch.cat([x0.to(T).float(), x1.to(T).float()], 1)
+    ref = F.conv2d(h.to(T).float(), w3.to(T).float(), b3, padding=1) + F.conv2d(xin, ws.to(T).float()[:, :, None, None], bs)
+    close(out.float().permute(0, 3, 1, 2), ref, dtype, "conv3x3 + fused 1x1 skip")
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_conv3x3_nchw_f32_output(dtype):
     x, w, bias = rnd(2, 128, 16, 16, seed=1), rnd(8, 128, 3, 3, seed=2, scale=0.03), rnd(8, seed=3)
     out, ref = hp.conv3x3(x, w, bias, None, dtype=dtype, out_mode=_lib.OUT_NCHW_F32)
@@ -135,6 +162,27 @@ def test_attention(dtype, B, H, T, S):
     qkv, ctx = rnd(B * T, 3 * C, seed=1) * 1.5, rnd(B * S, 2 * C, seed=2) * 1.5
     out, ref = hp.attention(qkv, ctx, B, H, T, S, dtype)
     close(out, ref, dtype, f"attention B{B} H{H} T{T}")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,H,T,S,K,bm,bn", [(2, 2, 144, 87, 128, 64, 64), (1, 3, 100, 5, 192, 128, 64), (2, 6, 64, 87, 384, 128, 128)])
+def test_qkv_projection_writes_attention_operands(dtype, B, H, T, S, K, bm, bn):
+    """qkv GEMM epilogue (IG_OUT_QKV): q row-major, k into K_all, v transposed into V^T_all behind the S context keys."""
+    T_ = hp.tdt(dtype)
+    C, Tkp = 64 * H, (S + T + 63) // 64 * 64
+    x, W, bias = rnd(B * T, K, seed=1), rnd(3 * C, K, seed=2, scale=K ** -0.5), rnd(3 * C, seed=3)
+    xt, wt = x.to(T_).contiguous(), W.to(T_).contiguous()
+    q = torch.empty(B * T, C, dtype=T_, device="cuda")
+    kall = torch.full((B, H, Tkp, 64), 7.0, dtype=T_, device="cuda")
+    vtall = torch.full((B, H, 64, Tkp), 7.0, dtype=T_, device="cuda")
+    _lib.check(_lib.lib().k22_qkv_project(xt.data_ptr(), wt.data_ptr(), bias.data_ptr(), q.data_ptr(), kall.data_ptr(), vtall.data_ptr(),
+                                          B, H, T, S, K, bm, bn, dtype, hp.stream()))
+    ref = (xt.float() @ wt.float().T + bias).view(B, T, 3, H, 64)
+    close(q.float().view(B, T, H, 64), ref[:, :, 0], dtype, "q")
+    close(kall.float()[:, :, S:S + T], ref[:, :, 1].permute(0, 2, 1, 3), dtype, "k")
+    close(vtall.float()[:, :, :, S:S + T], ref[:, :, 2].permute(0, 2, 3, 1), dtype, "v^T")
+    assert (kall[:, :, :S] == 7).all() and (kall[:, :, S + T:] == 7).all()          # context rows / padding untouched
+    assert (vtall[:, :, :, :S] == 7).all() and (vtall[:, :, :, S + T:] == 7).all()
 
 
 def test_attention_online_softmax_rescale_branch():
