@@ -163,6 +163,37 @@ int k22_qkv_project(const void* x, const void* Wp, const float* bias, void* q_ou
 int k22_linear_smallm(const float* x, const void* W, const float* bias, const float* add, float* out, int M, int N,
                       int K, int act_in, int act_out, int wdtype, void* stream);
 
+/* ---- MoVQ decoder ---------------------------------------------------------------------------
+ * Replaces MOVQ.decode (kandinsky2/vqgan/autoencoder.py:182-185: post_quant_conv + MOVQDecoder.forward,
+ * kandinsky2/vqgan/movq_modules.py:228-357: conv_in, mid ResnetBlock/AttnBlock/ResnetBlock, up levels with
+ * SpatialNorm ResnetBlocks (+AttnBlocks at the lowest level), nearest-x2 Upsample convs, norm_out + swish +
+ * conv_out) and the uint8 epilogue of process_images (kandinsky2/utils.py:57-70).  Hyper-parameters mirror
+ * CONFIG_2_1["image_enc_params"]["params"]["ddconfig"] (kandinsky2/configs.py:75-86).
+ * Weight names are the reference state_dict keys ("post_quant_conv.weight", "decoder.conv_in.weight",
+ * "decoder.mid.block_1.norm1.norm_layer.weight", ".conv_y.weight" ...); 3x3 weights packed [Npad][ky][kx][Cin]
+ * (conv_in zero-extended to Cin = 64), 1x1 weights [Npad][Cin], everything else fp32 as the reference. */
+typedef struct K22MoVQConfig {
+  int dtype;           /* K22_BF16 | K22_F32 */
+  int ch;              /* 128 */
+  int n_levels;        /* len(ch_mult) */
+  int ch_mult[8];      /* (1, 2, 2, 4) */
+  int num_res_blocks;  /* 2  (the decoder runs num_res_blocks + 1 blocks per level) */
+  int attn_levels;     /* bit i set = AttnBlock after every ResnetBlock of level i (resolution/2^i in attn_resolutions) */
+  int z_channels;      /* 4 */
+  int out_ch;          /* 3 */
+} K22MoVQConfig;
+typedef struct K22MoVQ K22MoVQ;
+int k22_movq_create(const K22MoVQConfig* cfg, const K22Weight* weights, int n_weights, K22MoVQ** out);
+void k22_movq_destroy(K22MoVQ* m);
+/* latent [B][4][h][w]; the caller allocates *workspace_bytes (256-byte aligned) and binds it */
+int k22_movq_plan(K22MoVQ* m, int B, int h, int w, size_t* workspace_bytes);
+int k22_movq_bind(K22MoVQ* m, void* workspace, size_t workspace_bytes);
+/* z: fp32 NCHW latent (un-quantised, as the sampler leaves it: decode(h, force_not_quantize) semantics);
+ * out: fp32 NCHW [B][3][H][W] (may be null); out_u8: uint8 NHWC [B][H][W][3] = ((x+1)*127.5).round().clamp(0,255)
+ * (may be null); H = h << (n_levels-1). */
+int k22_movq_decode(K22MoVQ* m, const float* z, float* out, unsigned char* out_u8, void* stream);
+int k22_movq_num_ops(const K22MoVQ* m);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,11 @@ class K22UNetConfig(C.Structure):
     ]
 
 
+class K22MoVQConfig(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("ch", C.c_int), ("n_levels", C.c_int), ("ch_mult", C.c_int * 8),
+                ("num_res_blocks", C.c_int), ("attn_levels", C.c_int), ("z_channels", C.c_int), ("out_ch", C.c_int)]
+
+
 class K22Weight(C.Structure):
     _fields_ = [("name", C.c_char_p), ("ptr", C.c_void_p)]
 
@@ -47,6 +52,12 @@ SIGNATURES = {
     "k22_unet_set_autotune": (_I, [_P, _I]),
     "k22_unet_tuning_report": (_I, [_P, C.c_char_p, _Z]),
     "k22_unet_profile": (_I, [_P, _I, C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), C.POINTER(_I), _P]),
+    "k22_movq_create": (_I, [C.POINTER(K22MoVQConfig), C.POINTER(K22Weight), _I, C.POINTER(_P)]),
+    "k22_movq_destroy": (None, [_P]),
+    "k22_movq_plan": (_I, [_P, _I, _I, _I, C.POINTER(_Z)]),
+    "k22_movq_bind": (_I, [_P, _P, _Z]),
+    "k22_movq_decode": (_I, [_P, _P, _P, _P, _P]),
+    "k22_movq_num_ops": (_I, [_P]),
     "k22_sampler_scratch_bytes": (_Z, [_I, _I]),
     "k22_sampler_step": (_I, [_P, _P, _P, _P, _P, _P, _I, _F, _I, _F, _F, _I, _D, _P, _P, _P, _I, _I, _P]),
     "k22_gemm": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 import kandinsky2_amd as k22  # noqa: E402
-from oracle import diffusion_ref, ref_loader, unet_ref  # noqa: E402
+from oracle import diffusion_ref, movq_ref, ref_loader, unet_ref  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 
@@ -123,6 +123,29 @@ def run_case(name, model_config, inpainting, B, h, w, steps, guidance=4.0, seed_
     torch.save(fix, os.path.join(GOLD, name + ".pt"))
 
 
+def movq_case(name, B, h, w, seed_w=0, seed_z=5):
+    """MOVQ.decode of the REFERENCE module (kandinsky2/vqgan/autoencoder.py:163-185) on seeded weights / latent."""
+    cfg = k22.MOVQ_CONFIG_2_1
+    arch = k22.MoVQArch(cfg["ddconfig"], cfg["embed_dim"])
+    sd = k22.init_movq_state_dict(arch, seed=seed_w)
+    ae = ref_loader.ref("vqgan.autoencoder")
+    m = ae.MOVQ(ddconfig=cfg["ddconfig"], n_embed=cfg["n_embed"], embed_dim=cfg["embed_dim"]).eval()
+    r = m.load_state_dict(sd, strict=False)
+    assert not r.unexpected_keys and all(not k.startswith(("decoder.", "post_quant_conv")) for k in r.missing_keys)
+    g = torch.Generator().manual_seed(seed_z)
+    z = torch.randn(B, 4, h, w, generator=g)
+    with torch.no_grad():
+        ref_out = m.decode(z)
+        ora = movq_ref.movq_decode(sd, arch, z)
+    u8 = ref_loader.ref("utils")  # process_images needs PIL only at the very end; restate the tensor part
+    ref_u8 = ((ref_out + 1) * 127.5).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+    d = (ora - ref_out).abs().max().item()
+    print(f"{name}: MOVQ.decode ref absmax {ref_out.abs().max():.4f}  oracle-vs-ref max|d| {d:.3e}")
+    assert d < 1e-5 and torch.equal(movq_ref.process_images_u8(ref_out), ref_u8)
+    torch.save(dict(name=name, B=B, h=h, w=w, seed_w=seed_w, seed_z=seed_z, out=ref_out.clone(), out_u8=ref_u8.clone()),
+               os.path.join(GOLD, name + ".pt"))
+
+
 def table_fixtures():
     out = {}
     for steps in (10, 50, 100):
@@ -159,5 +182,7 @@ if __name__ == "__main__":
     tiny = k22.tiny_model_config()
     run_case("tiny_text2img", tiny, False, B=2, h=16, w=16, steps=6)
     run_case("tiny_inpaint", tiny, True, B=4, h=16, w=24, steps=4)
+    movq_case("movq_small", B=2, h=8, w=8)
+    movq_case("movq_wide", B=1, h=8, w=16)
     if a.full:
         run_case("full_c1_text2img", k22.MODEL_CONFIG_2_1, False, B=2, h=32, w=32, steps=10)

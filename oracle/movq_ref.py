@@ -1,0 +1,65 @@
+"""CPU oracle (test infrastructure only) — MoVQ decode restated in plain PyTorch fp32 from a state_dict.
+
+Follows kandinsky2/vqgan/autoencoder.py:182-185 (MOVQ.decode), kandinsky2/vqgan/movq_modules.py:61-68 (SpatialNorm),
+:160-182 (ResnetBlock.forward), :201-225 (AttnBlock.forward), :85-98 (Upsample), :326-357 (MOVQDecoder.forward) and
+kandinsky2/utils.py:57-70 (process_images).  Pinned against the reference's own MOVQ module by oracle/make_golden.py
+(bit-identical on the golden cases).  Never imported by the product path.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _conv(sd, name, x, padding=0):
+    return F.conv2d(x, sd[name + ".weight"], sd[name + ".bias"], padding=padding)
+
+
+def _snorm(sd, name, f, zq):
+    zq = F.interpolate(zq, size=f.shape[-2:], mode="nearest")
+    nf = F.group_norm(f, 32, sd[name + ".norm_layer.weight"], sd[name + ".norm_layer.bias"], eps=1e-6)
+    return nf * _conv(sd, name + ".conv_y", zq) + _conv(sd, name + ".conv_b", zq)
+
+
+def _swish(x):
+    return x * torch.sigmoid(x)
+
+
+def _res(sd, pfx, x, zq, cin, cout):
+    h = _conv(sd, pfx + ".conv1", _swish(_snorm(sd, pfx + ".norm1", x, zq)), 1)
+    h = _conv(sd, pfx + ".conv2", _swish(_snorm(sd, pfx + ".norm2", h, zq)), 1)
+    if cin != cout:
+        x = _conv(sd, pfx + ".nin_shortcut", x)
+    return x + h
+
+
+def _attn(sd, pfx, x, zq):
+    h_ = _snorm(sd, pfx + ".norm", x, zq)
+    q, k, v = _conv(sd, pfx + ".q", h_), _conv(sd, pfx + ".k", h_), _conv(sd, pfx + ".v", h_)
+    b, c, h, w = q.shape
+    q = q.reshape(b, c, h * w).permute(0, 2, 1)
+    k = k.reshape(b, c, h * w)
+    w_ = torch.bmm(q, k) * (int(c) ** (-0.5))
+    w_ = F.softmax(w_, dim=2)
+    v = v.reshape(b, c, h * w)
+    h_ = torch.bmm(v, w_.permute(0, 2, 1)).reshape(b, c, h, w)
+    return x + _conv(sd, pfx + ".proj_out", h_)
+
+
+def movq_decode(sd, arch, quant):
+    """sd: fp32 state_dict (post_quant_conv.*, decoder.*); quant [B,4,h,w] -> [B,3,8h,8w]."""
+    zq = quant
+    blocks, last = arch.blocks()
+    h = _conv(sd, "decoder.conv_in", _conv(sd, "post_quant_conv", quant), 1)
+    for kind, pfx, cin, cout in blocks:
+        if kind == "res":
+            h = _res(sd, pfx, h, zq, cin, cout)
+        elif kind == "attn":
+            h = _attn(sd, pfx, h, zq)
+        else:
+            h = _conv(sd, pfx, F.interpolate(h, scale_factor=2.0, mode="nearest"), 1)
+    h = _swish(_snorm(sd, "decoder.norm_out", h, zq))
+    return _conv(sd, "decoder.conv_out", h, 1)
+
+
+def process_images_u8(batch):
+    """kandinsky2/utils.py:57-70 up to the PIL conversion: NCHW float -> NHWC uint8."""
+    return ((batch + 1) * 127.5).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()

@@ -142,3 +142,37 @@ def test_pack_layouts():
     meta = {k: torch.empty(v, device="meta") for k, v in k22.param_shapes(arch).items()}
     _, table2 = pack_arena(arch, meta, torch.bfloat16, "meta")
     assert table == table2 and all(o % 256 == 0 for o, _ in table.values())
+
+
+# ---- MoVQ decoder ----------------------------------------------------------------
+def test_movq_oracle_matches_reference_golden(golden_dir):
+    from oracle import movq_ref
+    fx = _load(golden_dir, "movq_small")
+    arch = k22.MoVQArch(k22.MOVQ_CONFIG_2_1["ddconfig"])
+    sd = k22.init_movq_state_dict(arch, seed=fx["seed_w"])
+    g = torch.Generator().manual_seed(fx["seed_z"])
+    z = torch.randn(fx["B"], 4, fx["h"], fx["w"], generator=g)
+    out = movq_ref.movq_decode(sd, arch, z)
+    assert out.abs().max() > 0.5
+    assert (out - fx["out"]).abs().max().item() <= 1e-5
+    assert torch.equal(movq_ref.process_images_u8(fx["out"]), fx["out_u8"])
+
+
+def test_movq_state_dict_keys_match_reference(golden_dir):
+    with open(os.path.join(golden_dir, "ref_movq_keys.json")) as f:
+        ref = json.load(f)
+    arch = k22.MoVQArch(k22.MOVQ_CONFIG_2_1["ddconfig"])
+    mine = {k: list(v) for k, v in k22.movq_param_shapes(arch).items()}
+    assert mine == ref
+    assert arch.attn_levels == [3]  # resolution 256 / 2^3 = 32 is the only entry of attn_resolutions
+
+
+def test_movq_arena_layout_is_shape_determined():
+    from kandinsky2_amd.movq import pack_movq_arena
+    arch = k22.MoVQArch(k22.MOVQ_CONFIG_2_1["ddconfig"])
+    sd = {k: torch.zeros(v) for k, v in k22.movq_param_shapes(arch).items()}
+    arena, table = pack_movq_arena(arch, sd, torch.bfloat16, "cpu")
+    assert table["decoder.conv_in.weight"][1] == 512 * 9 * 64 * 2          # Cin 4 zero-extended to one 64-channel K slab
+    assert table["decoder.conv_out.weight"][1] == 64 * 9 * 128 * 2         # 3 output rows padded to 64
+    assert table["decoder.mid.block_1.norm1.conv_y.weight"][1] == 512 * 4 * 4  # fp32, evaluated inside the norm kernel
+    assert all(off % 256 == 0 for off, _ in table.values()) and arena.dtype == torch.uint8
