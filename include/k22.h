@@ -163,6 +163,40 @@ int k22_qkv_project(const void* x, const void* Wp, const float* bias, void* q_ou
 int k22_linear_smallm(const float* x, const void* W, const float* bias, const float* add, float* out, int M, int N,
                       int K, int act_in, int act_out, int wdtype, void* stream);
 
+/* ---- diffusion prior ----------------------------------------------------------------------------
+ * Replaces PriorTransformer.forward (kandinsky2/model/prior.py:226-270) and the per-step update of
+ * PriorDiffusionModel.forward's sampling loop (prior.py:336-384; gaussian_diffusion.py:223-322, 352-382 with
+ * model_mean_type START_X, model_var_type FIXED_SMALL, clip_denoised False, denoised_fn clamp(+-10)).
+ * Hyper-parameters mirror CONFIG_2_1["prior"]["params"]["model"]["hparams"] (kandinsky2/configs.py:101-111).
+ * Weight names are the reference state_dict keys of PriorDiffusionModel.model (time_embed.0.weight ...,
+ * transformer.resblocks.<l>.attn.c_qkv.weight ...); transformer Linear weights packed T [roundup(N,64)][K] with
+ * c_qkv rows re-ordered to Q | K | V planes x [head][64]; everything else fp32; plus "time_freqs" [xf_width/2]. */
+typedef struct K22PriorConfig {
+  int dtype;          /* K22_BF16 | K22_F32 */
+  int text_ctx;       /* 77 */
+  int xf_width;       /* 2048 */
+  int xf_layers;      /* 20 */
+  int xf_heads;       /* 32 (64 channels per head) */
+  int xf_final_ln;    /* 1 */
+  int clip_dim;       /* 768 */
+  int clip_xf_width;  /* 768 */
+} K22PriorConfig;
+typedef struct K22Prior K22Prior;
+int k22_prior_create(const K22PriorConfig* cfg, const K22Weight* weights, int n_weights, K22Prior** out);
+void k22_prior_destroy(K22Prior* m);
+int k22_prior_plan(K22Prior* m, int B, size_t* workspace_bytes);   /* B = 2*bs rows [cond | uncond], <= 8 */
+int k22_prior_bind(K22Prior* m, void* workspace, size_t workspace_bytes);
+/* x [B][clip_dim], timesteps [B] (as the reference passes them: original indices as floats), text_emb [B][clip_dim],
+ * text_enc [B][text_ctx][clip_xf_width], key_valid [B][text_ctx] (1 = token, 0 = padding; the `mask` argument of
+ * the reference as floats) -> out [B][clip_dim]; all fp32 device buffers. */
+int k22_prior_forward(K22Prior* m, const float* x, const float* timesteps, const float* text_emb, const float* text_enc,
+                      const float* key_valid, float* out, void* stream);
+/* One ancestral step: x0 = clamp(uncond + scales[j]*(cond - uncond), +-clamp); mean = c1*x0 + c2*x;
+ * x_out = mean + nonzero*exp(0.5*logvar)*noise.  table_row: device fp32[4] = (posterior_mean_coef1, coef2,
+ * posterior_log_variance_clipped, t != 0); x / model_out / noise / x_out: [2*bs][D]; scales [bs]. */
+int k22_prior_sampler_step(const float* x, const float* model_out, const float* noise, const float* scales, const float* table_row,
+                           float clamp, float* x_out, int bs, int D, void* stream);
+
 /* ---- MoVQ decoder ---------------------------------------------------------------------------
  * Replaces MOVQ.decode (kandinsky2/vqgan/autoencoder.py:182-185: post_quant_conv + MOVQDecoder.forward,
  * kandinsky2/vqgan/movq_modules.py:228-357: conv_in, mid ResnetBlock/AttnBlock/ResnetBlock, up levels with

@@ -31,6 +31,11 @@ class K22MoVQConfig(C.Structure):
                 ("num_res_blocks", C.c_int), ("attn_levels", C.c_int), ("z_channels", C.c_int), ("out_ch", C.c_int)]
 
 
+class K22PriorConfig(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("text_ctx", C.c_int), ("xf_width", C.c_int), ("xf_layers", C.c_int), ("xf_heads", C.c_int),
+                ("xf_final_ln", C.c_int), ("clip_dim", C.c_int), ("clip_xf_width", C.c_int)]
+
+
 class K22Weight(C.Structure):
     _fields_ = [("name", C.c_char_p), ("ptr", C.c_void_p)]
 
@@ -52,6 +57,12 @@ SIGNATURES = {
     "k22_unet_set_autotune": (_I, [_P, _I]),
     "k22_unet_tuning_report": (_I, [_P, C.c_char_p, _Z]),
     "k22_unet_profile": (_I, [_P, _I, C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), C.POINTER(_I), _P]),
+    "k22_prior_create": (_I, [C.POINTER(K22PriorConfig), C.POINTER(K22Weight), _I, C.POINTER(_P)]),
+    "k22_prior_destroy": (None, [_P]),
+    "k22_prior_plan": (_I, [_P, _I, C.POINTER(_Z)]),
+    "k22_prior_bind": (_I, [_P, _P, _Z]),
+    "k22_prior_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "k22_prior_sampler_step": (_I, [_P, _P, _P, _P, _P, _F, _P, _I, _I, _P]),
     "k22_movq_create": (_I, [C.POINTER(K22MoVQConfig), C.POINTER(K22Weight), _I, C.POINTER(_P)]),
     "k22_movq_destroy": (None, [_P]),
     "k22_movq_plan": (_I, [_P, _I, _I, _I, C.POINTER(_Z)]),

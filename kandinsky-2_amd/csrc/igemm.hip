@@ -231,7 +231,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
           }
           if (res != nullptr) {
             float rv[4];
-            load4f<T>(res + (int64_t)m * p.ldr + n, rv);
+            if (p.res_f32) load4f<float>(reinterpret_cast<const float*>(p.residual) + (int64_t)m * p.ldr + n, rv);
+            else load4f<T>(res + (int64_t)m * p.ldr + n, rv);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += rv[e];
           }
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             if (n + e >= p.N) continue;
             float u = v[e];
             if (p.bias != nullptr) u += p.bias[n + e];
-            if (res != nullptr) u += to_f32(res[(int64_t)m * p.ldr + n + e]);
+            if (res != nullptr) u += p.res_f32 ? reinterpret_cast<const float*>(p.residual)[(int64_t)m * p.ldr + n + e] : to_f32(res[(int64_t)m * p.ldr + n + e]);
             u = apply_act(u, p.act);
             if (p.out_mode == IG_OUT_ROWMAJOR) {
               reinterpret_cast<T*>(p.out)[(int64_t)m * p.ldo + n + e] = from_f32<T>(u);
@@ -307,7 +308,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmParams p)
       }
       if (res != nullptr) {
         float rv[4];
-        load4f<T>(res + (int64_t)m * p.ldr + n, rv);
+        if (p.res_f32) load4f<float>(reinterpret_cast<const float*>(p.residual) + (int64_t)m * p.ldr + n, rv);
+        else load4f<T>(res + (int64_t)m * p.ldr + n, rv);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += rv[e];
       }
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmParams p)
     for (int s = 0; s < p.splitk; ++s) v += p.partial[(int64_t)s * total + i];
     if (p.bias != nullptr) v += p.bias[n];
     if (p.bias2 != nullptr) v += p.bias2[n];
-    if (res != nullptr) v += to_f32(res[(int64_t)m * p.ldr + n]);
+    if (res != nullptr) v += p.res_f32 ? reinterpret_cast<const float*>(p.residual)[(int64_t)m * p.ldr + n] : to_f32(res[(int64_t)m * p.ldr + n]);
     v = apply_act(v, p.act);
     if (p.out_mode == IG_OUT_ROWMAJOR) {
       reinterpret_cast<T*>(p.out)[(int64_t)m * p.ldo + n] = from_f32<T>(v);
@@ -378,7 +380,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const IgemmPara
     }
     if (res != nullptr) {
       float rv[4];
-      load4f<T>(res + (int64_t)m * p.ldr + n, rv);
+      if (p.res_f32) load4f<float>(reinterpret_cast<const float*>(p.residual) + (int64_t)m * p.ldr + n, rv);
+      else load4f<T>(res + (int64_t)m * p.ldr + n, rv);
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] += rv[e];
     }
@@ -574,6 +577,7 @@ int launch_igemm(const IgemmParams& p, int dtype, hipStream_t stream) {
   IgemmPlan pl = igemm_plan(p, dtype);
   if (p.out_mode == IG_OUT_QKV) pl.splitk = 1;
   if (pl.splitk > 1 && p.partial == nullptr) pl.splitk = 1;
+  if (p.res_f32 && pl.halo) return k22_set_error(K22_EINVAL, "igemm: fp32 residual is not supported by the halo kernel");
   if (p.S0 != nullptr && !pl.halo) return k22_set_error(K22_EINVAL, "igemm: the fused 1x1 skip connection needs the halo kernel");
   if (p.stats != nullptr && pl.splitk == 1 && !pl.halo)
     return k22_set_error(K22_EINVAL, "igemm: GroupNorm partial sums requested from a configuration that cannot produce them");

@@ -28,7 +28,7 @@ struct IgemmParams {
   const void* A1;
   const void* Wp;
   const float* bias;     // [N] or null
-  const void* residual;  // T [M][ldr] or null
+  const void* residual;  // T [M][ldr] or null (fp32 [M][ldr] when res_f32 is set: fp32 residual stream of the prior)
   void* out;
   float* partial;        // split-K scratch [splitk][M][N] fp32 (needed when splitk > 1)
   int M, N, Npad;
@@ -51,6 +51,7 @@ struct IgemmParams {
   int SK0, SK1;
   void* kall; void* vtall;                 // IG_OUT_QKV only
   int att_T, att_S, att_Tkp;               // IG_OUT_QKV only: tokens per image, context keys, padded key count
+  int res_f32;           // residual is fp32 (generic kernel / split-K finish only)
   float* stats;          // optional GroupNorm side output: per-row-block, per-channel (sum, sumsq) of the STORED
                          // values, [stats_rows][N][2] fp32 (see IgemmStatsInfo); null = not wanted
 };

@@ -1,0 +1,347 @@
+// k22 — diffusion-prior transformer engine + its sampler step.
+//
+// Replaces PriorTransformer.forward (kandinsky2/model/prior.py:226-270) with its blocks (LayerNorm :48-54,
+// MultiheadAttention / QKVMultiheadAttention :57-102, MLP :74-83, ResidualAttentionBlock :105-127) and the per-step
+// arithmetic of PriorDiffusionModel.forward's sampling loop (:336-384: guided_model_fn CFG with per-sample scales,
+// START_X mean, FIXED_SMALL variance, denoised_fn clamp, gaussian_diffusion.py:223-322, 352-382).
+//
+// MI355X mapping: the transformer is weight-streaming bound (2.0 GB of bf16 weights per forward for 162 token rows at
+// bs = 1), so every Linear is one launch_igemm over the [N][K] weight exactly as the reference stores it, the fp32
+// residual stream is updated in place by the GEMM epilogue (res_f32), LayerNorm writes the GEMM's T operand, and
+// the 81-token attention runs one workgroup per (batch, head) out of LDS.  c_qkv rows are packed as Q | K | V planes
+// (the reference keeps per-head [q|k|v] interleaved, prior.py:93-95).
+#include "kernels.h"
+#include "elementwise.h"
+#include "../../include/k22.h"
+
+#include <deque>
+#include <functional>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+// ---- LayerNorm over the last dim: fp32 rows (stride ldx) -> T or fp32 rows -----------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void prior_layernorm_kernel(const float* x, int64_t ldx, const float* g, const float* bta,
+                                                              TO* y, int64_t ldy, int D, float eps) {
+  __shared__ float red[8];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* xr = x + (int64_t)row * ldx;
+  float s = 0.f;
+  for (int i = tid; i < D; i += 256) s += xr[i];
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / D;
+  float q = 0.f;
+  for (int i = tid; i < D; i += 256) { const float d = xr[i] - mean; q += d * d; }
+  q = wave_sum(q);
+  if ((tid & 63) == 0) red[4 + (tid >> 6)] = q;
+  __syncthreads();
+  const float rstd = rsqrtf(((red[4] + red[5]) + (red[6] + red[7])) / D + eps);
+  for (int i = tid; i < D; i += 256) y[(int64_t)row * ldy + i] = from_f32<TO>((xr[i] - mean) * rstd * g[i] + bta[i]);
+}
+
+// ---- input sequence: rows 0..n_text-1 / n_text / n_text+1 / n_text+2 were written by the projections; add the
+// positional embedding everywhere and put prd_emb in the last row (prior.py:248-256) -----------------------------
+__global__ void prior_finish_input_kernel(float* inp, const float* pos, const float* prd, int B, int n_ctx, int D) {
+  const int64_t total = (int64_t)B * n_ctx * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D), t = (int)((i / D) % n_ctx);
+    const float base = (t == n_ctx - 1) ? prd[d] : inp[i];
+    inp[i] = base + pos[(int64_t)t * D + d];
+  }
+}
+
+// additive attention mask (prior.py:262-263): mask[b][t][s] = (key s valid ? 0 : -inf) + (s > t ? -inf : 0);
+// key_valid [B][n_text] (1 = token, 0 = padding); the 4 extra positions are always valid (F.pad(..., value=True)).
+__global__ void prior_mask_kernel(const float* key_valid, float* mask, int B, int n_text, int n_ctx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * n_ctx * n_ctx) return;
+  const int s = i % n_ctx, t = (i / n_ctx) % n_ctx, b = i / (n_ctx * n_ctx);
+  const bool valid = s >= n_text || key_valid[(int64_t)b * n_text + s] != 0.f;
+  mask[i] = (valid && s <= t) ? 0.f : -INFINITY;
+}
+
+// ---- attention, one workgroup per (head, batch): n_ctx <= 128 tokens, 64 channels per head ----------------------
+// qkv rows [B*n_ctx][3*W] as planes Q | K | V x [heads][64]; out rows [B*n_ctx][W].  fp32 math
+// (softmax in fp32 like the reference, prior.py:96-101); scale = 64^-1/4 on q and on k = 1/8 on the product.
+template <typename T>
+__global__ __launch_bounds__(256) void prior_attention_kernel(const T* qkv, const float* mask, T* out, int n_ctx, int W) {
+  __shared__ float Ks[96][65];   // +1 column: the score loop reads one row per lane
+  __shared__ float Vs[96][65];
+  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t ld = 3 * (int64_t)W;
+  const T* base = qkv + (int64_t)b * n_ctx * ld + h * 64;
+  for (int i = tid; i < n_ctx * 64; i += 256) {
+    const int s = i >> 6, d = i & 63;
+    Ks[s][d] = to_f32(base[(int64_t)s * ld + W + d]);
+    Vs[s][d] = to_f32(base[(int64_t)s * ld + 2 * W + d]);
+  }
+  __syncthreads();
+  for (int t = wave; t < n_ctx; t += 4) {
+    const float qv = to_f32(base[(int64_t)t * ld + lane]);  // lane d holds q[d]; broadcast by readlane below
+    // scores for keys lane and lane + 64
+    float sc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int s = lane + 64 * u;
+      const int sr = s < n_ctx ? s : 0;
+      float a = 0.f;
+#pragma unroll 16
+      for (int d = 0; d < 64; ++d) a += __shfl(qv, d, 64) * Ks[sr][d];
+      sc[u] = s < n_ctx ? a * 0.125f + mask[((int64_t)b * n_ctx + t) * n_ctx + s] : -INFINITY;
+    }
+    const float m = wave_max(fmaxf(sc[0], sc[1]));
+    const float e0 = expf(sc[0] - m), e1 = expf(sc[1] - m);
+    const float inv = 1.f / wave_sum(e0 + e1);
+    const float p0 = e0 * inv, p1 = e1 * inv;
+    // out[d = lane] = sum_s P[s] V[s][d]
+    float o = 0.f;
+    for (int s = 0; s < n_ctx; ++s) o += (s < 64 ? __shfl(p0, s, 64) : __shfl(p1, s - 64, 64)) * Vs[s][lane];
+    out[((int64_t)b * n_ctx + t) * W + h * 64 + lane] = from_f32<T>(o);
+  }
+}
+
+// ---- one ancestral step of the prior (START_X mean, FIXED_SMALL variance) with classifier-free guidance -------------
+// x, model_out, noise, x_out: [2*bs][D] with halves [cond | uncond]; scales [bs]; tab = (coef1, coef2, log_var, nonzero)
+__global__ void prior_sampler_step_kernel(const float* x, const float* model_out, const float* noise, const float* scales,
+                                          const float* tab, float clamp, float* x_out, int bs, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * bs * D) return;
+  const int d = i % D, n = i / D, j = n % bs;
+  const float c = model_out[(int64_t)j * D + d], u = model_out[(int64_t)(j + bs) * D + d];
+  float x0 = u + scales[j] * (c - u);
+  x0 = fminf(fmaxf(x0, -clamp), clamp);
+  const float mean = __fadd_rn(__fmul_rn(tab[0], x0), __fmul_rn(tab[1], x[i]));
+  x_out[i] = mean + tab[3] * expf(0.5f * tab[2]) * noise[i];
+}
+
+namespace {
+struct PSlot { size_t bytes = 0, off = 0; };
+typedef std::function<int(hipStream_t)> POp;
+}  // namespace
+
+struct K22Prior {
+  K22PriorConfig cfg;
+  int dtype; size_t esz;
+  std::unordered_map<std::string, const void*> w;
+  int B = 0;
+  std::deque<PSlot> slots;
+  std::vector<POp> ops;
+  size_t ws_bytes = 0;
+  char* ws = nullptr;
+  std::string err;
+  PSlot *s_x, *s_t, *s_temb, *s_te1, *s_txtemb, *s_txtenc, *s_txtencT, *s_valid, *s_mask, *s_inp, *s_ln, *s_qkv, *s_att, *s_fc,
+      *s_lnlast, *s_out, *s_splitk;
+
+  PSlot* new_slot(size_t bytes = 0) { slots.emplace_back(); slots.back().bytes = bytes; return &slots.back(); }
+  static void need(PSlot* s, size_t bytes) { if (bytes > s->bytes) s->bytes = bytes; }
+  template <typename T = char> T* ptr(const PSlot* s) const { return reinterpret_cast<T*>(ws + s->off); }
+  const void* W_(const std::string& name) {
+    auto it = w.find(name);
+    if (it == w.end()) { if (err.empty()) err = "missing weight: " + name; return nullptr; }
+    return it->second;
+  }
+  const float* Wf(const std::string& name) { return reinterpret_cast<const float*>(W_(name)); }
+
+  // out (+)= A[M][K] . W[N][K]^T + bias; A is T; out T, or fp32 with an fp32 residual (in-place residual stream)
+  void op_linear(PSlot* a, size_t a_off, int M, int N, int K, const std::string& pfx, int act, PSlot* dst, size_t dst_off, int ldo,
+                 bool f32_out_residual) {
+    IgemmParams p = {};
+    p.stages = -1;
+    p.M = M; p.N = N; p.Npad = (N + 63) / 64 * 64; p.Kc = K; p.K0 = K; p.taps = 1; p.lda0 = K; p.ldo = ldo; p.ldr = ldo;
+    p.out_mode = f32_out_residual ? IG_OUT_ROWMAJOR_F32 : IG_OUT_ROWMAJOR; p.act = act; p.res_f32 = f32_out_residual ? 1 : 0;
+    p.Wp = W_(pfx + ".weight"); p.bias = Wf(pfx + ".bias");
+    p.splitk = igemm_choose_splitk(p, dtype);
+    if (p.splitk > 1) need(s_splitk, (size_t)p.splitk * M * N * sizeof(float));
+    const int dt = dtype;
+    ops.push_back([=](hipStream_t st) {
+      IgemmParams q = p;
+      q.A0 = ptr(a) + a_off; q.out = ptr(dst) + dst_off; q.partial = ptr<float>(s_splitk);
+      q.residual = f32_out_residual ? (ptr(dst) + dst_off) : nullptr;
+      return launch_igemm(q, dt, st);
+    });
+  }
+  void op_ln(PSlot* x, size_t x_off, int64_t ldx, int rows, const std::string& pfx, PSlot* y, bool to_f32) {
+    const float* g = Wf(pfx + ".weight"); const float* b = Wf(pfx + ".bias");
+    const int D = cfg.xf_width, dt = dtype;
+    ops.push_back([=](hipStream_t st) {
+      const float* xp = reinterpret_cast<const float*>(ptr(x) + x_off);
+      if (to_f32) hipLaunchKernelGGL(prior_layernorm_kernel<float>, dim3(rows), dim3(256), 0, st, xp, ldx, g, b, ptr<float>(y), (int64_t)D, D, 1e-5f);
+      else if (dt == K22_BF16) hipLaunchKernelGGL(prior_layernorm_kernel<bf16_t>, dim3(rows), dim3(256), 0, st, xp, ldx, g, b, ptr<bf16_t>(y), (int64_t)D, D, 1e-5f);
+      else hipLaunchKernelGGL(prior_layernorm_kernel<float>, dim3(rows), dim3(256), 0, st, xp, ldx, g, b, ptr<float>(y), (int64_t)D, D, 1e-5f);
+      K22_CHECK_LAUNCH();
+      return K22_OK;
+    });
+  }
+
+  int plan(int nB) {
+    B = nB;
+    slots.clear(); ops.clear(); err.clear(); ws = nullptr;
+    const int D = cfg.xf_width, nt = cfg.text_ctx, nc = nt + 4, cd = cfg.clip_dim, cw = cfg.clip_xf_width, M = B * nc;
+    if (B < 1 || B > 8) return k22_set_error(K22_EINVAL, "prior: batch (2*bs) must be in 1..8 per engine call");
+    if (nc > 96 || D % 64 || D / cfg.xf_heads != 64) return k22_set_error(K22_EINVAL, "prior: text_ctx + 4 <= 96, 64 channels per head");
+    s_x = new_slot((size_t)B * cd * 4); s_t = new_slot((size_t)B * 4 + 64);
+    s_temb = new_slot((size_t)B * D * 4); s_te1 = new_slot((size_t)B * D * 4);
+    s_txtemb = new_slot((size_t)B * cd * 4); s_txtenc = new_slot((size_t)B * nt * cw * 4); s_txtencT = new_slot((size_t)B * nt * cw * esz);
+    s_valid = new_slot((size_t)B * nt * 4); s_mask = new_slot((size_t)B * nc * nc * 4);
+    s_inp = new_slot((size_t)M * D * 4); s_ln = new_slot((size_t)M * D * esz); s_qkv = new_slot((size_t)M * 3 * D * esz);
+    s_att = new_slot((size_t)M * D * esz); s_fc = new_slot((size_t)M * 4 * D * esz);
+    s_lnlast = new_slot((size_t)B * D * 4); s_out = new_slot((size_t)B * cd * 4); s_splitk = new_slot(256);
+    const int Bn = B, dt = dtype;
+    const size_t es = esz;
+
+    // ---- input sequence (prior.py:238-256) ----------------------------------------------------------------
+    {
+      const float* freqs = Wf("time_freqs");
+      const float* w0 = Wf("time_embed.0.weight"); const float* b0 = Wf("time_embed.0.bias");
+      const float* w2 = Wf("time_embed.2.weight"); const float* b2 = Wf("time_embed.2.bias");
+      const float* wte = Wf("text_emb_proj.weight"); const float* bte = Wf("text_emb_proj.bias");
+      const float* wci = Wf("clip_img_proj.weight"); const float* bci = Wf("clip_img_proj.bias");
+      ops.push_back([=](hipStream_t st) {
+        int rc = launch_timestep_embedding(ptr<float>(s_t), freqs, ptr<float>(s_temb), Bn, D / 2, st);
+        if (rc) return rc;
+        LinearSmallParams lp = {};
+        lp.x = ptr<float>(s_temb); lp.ldx = D; lp.W = w0; lp.bias = b0; lp.out = ptr<float>(s_te1); lp.ldo = D;
+        lp.M = Bn; lp.N = D; lp.K = D; lp.act_in = K22_ACT_NONE; lp.act_out = K22_ACT_SILU;
+        rc = launch_linear_smallm(lp, K22_F32, st);
+        if (rc) return rc;
+        float* inp = ptr<float>(s_inp);
+        lp.x = ptr<float>(s_te1); lp.W = w2; lp.bias = b2; lp.out = inp + (size_t)(nt + 1) * D; lp.ldo = (int64_t)nc * D; lp.act_out = K22_ACT_NONE;
+        rc = launch_linear_smallm(lp, K22_F32, st);                                   // t_emb -> row n_text+1
+        if (rc) return rc;
+        lp.x = ptr<float>(s_txtemb); lp.ldx = cd; lp.K = cd; lp.W = wte; lp.bias = bte; lp.out = inp + (size_t)nt * D;
+        rc = launch_linear_smallm(lp, K22_F32, st);                                   // text_emb -> row n_text
+        if (rc) return rc;
+        lp.x = ptr<float>(s_x); lp.W = wci; lp.bias = bci; lp.out = inp + (size_t)(nt + 2) * D;
+        rc = launch_linear_smallm(lp, K22_F32, st);                                   // clip_img_proj(x) -> row n_text+2
+        if (rc) return rc;
+        return launch_cast_rows(ptr<float>(s_txtenc), ptr(s_txtencT), Bn * nt, cw, cw, cw, dt, st);
+      });
+      // text_enc_proj: one GEMM per batch element straight into rows 0..n_text-1 of the sequence (fp32 out)
+      for (int b = 0; b < B; ++b) {
+        IgemmParams p = {};
+        p.stages = -1;
+        p.M = nt; p.N = D; p.Npad = D; p.Kc = cw; p.K0 = cw; p.taps = 1; p.lda0 = cw; p.ldo = D; p.ldr = D;
+        p.out_mode = IG_OUT_ROWMAJOR_F32; p.act = K22_ACT_NONE; p.splitk = 1;
+        p.Wp = W_("text_enc_proj.weight"); p.bias = Wf("text_enc_proj.bias");
+        ops.push_back([=](hipStream_t st) {
+          IgemmParams q = p;
+          q.A0 = ptr(s_txtencT) + (size_t)b * nt * cw * es; q.out = ptr<float>(s_inp) + (size_t)b * nc * D;
+          return launch_igemm(q, dt, st);
+        });
+      }
+      const float* pos = Wf("positional_embedding"); const float* prd = Wf("prd_emb");
+      ops.push_back([=](hipStream_t st) {
+        hipLaunchKernelGGL(prior_finish_input_kernel, dim3(256), dim3(256), 0, st, ptr<float>(s_inp), pos, prd, Bn, nc, D);
+        K22_CHECK_LAUNCH();
+        hipLaunchKernelGGL(prior_mask_kernel, dim3((Bn * nc * nc + 255) / 256), dim3(256), 0, st, ptr<float>(s_valid), ptr<float>(s_mask), Bn, nt, nc);
+        K22_CHECK_LAUNCH();
+        return K22_OK;
+      });
+    }
+    // ---- transformer (prior.py:105-155) ------------------------------------------------------------------
+    for (int l = 0; l < cfg.xf_layers; ++l) {
+      const std::string pfx = "transformer.resblocks." + std::to_string(l);
+      op_ln(s_inp, 0, D, M, pfx + ".ln_1", s_ln, false);
+      op_linear(s_ln, 0, M, 3 * D, D, pfx + ".attn.c_qkv", K22_ACT_NONE, s_qkv, 0, 3 * D, false);
+      const int heads = cfg.xf_heads;
+      ops.push_back([=](hipStream_t st) {
+        dim3 grid(heads, Bn);
+        if (dt == K22_BF16) hipLaunchKernelGGL(prior_attention_kernel<bf16_t>, grid, dim3(256), 0, st, ptr<bf16_t>(s_qkv), ptr<float>(s_mask), ptr<bf16_t>(s_att), nc, D);
+        else hipLaunchKernelGGL(prior_attention_kernel<float>, grid, dim3(256), 0, st, ptr<float>(s_qkv), ptr<float>(s_mask), ptr<float>(s_att), nc, D);
+        K22_CHECK_LAUNCH();
+        return K22_OK;
+      });
+      op_linear(s_att, 0, M, D, D, pfx + ".attn.c_proj", K22_ACT_NONE, s_inp, 0, D, true);
+      op_ln(s_inp, 0, D, M, pfx + ".ln_2", s_ln, false);
+      op_linear(s_ln, 0, M, 4 * D, D, pfx + ".mlp.c_fc", K22_ACT_GELU, s_fc, 0, 4 * D, false);
+      op_linear(s_fc, 0, M, D, 4 * D, pfx + ".mlp.c_proj", K22_ACT_NONE, s_inp, 0, D, true);
+    }
+    // ---- final_ln on the last token + out_proj (prior.py:266-269) -------------------------------------------
+    if (cfg.xf_final_ln) {
+      op_ln(s_inp, (size_t)(nc - 1) * D * 4, (int64_t)nc * D, B, "final_ln", s_lnlast, true);
+    } else {
+      ops.push_back([=](hipStream_t st) {
+        hipError_t e = hipMemcpy2DAsync(ptr(s_lnlast), (size_t)D * 4, ptr(s_inp) + (size_t)(nc - 1) * D * 4, (size_t)nc * D * 4, (size_t)D * 4, Bn,
+                                        hipMemcpyDeviceToDevice, st);
+        return e == hipSuccess ? K22_OK : k22_set_error_hip(e, __FILE__, __LINE__);
+      });
+    }
+    {
+      const float* wo = Wf("out_proj.weight"); const float* bo = Wf("out_proj.bias");
+      ops.push_back([=](hipStream_t st) {
+        LinearSmallParams lp = {};
+        lp.x = ptr<float>(s_lnlast); lp.ldx = D; lp.W = wo; lp.bias = bo; lp.out = ptr<float>(s_out); lp.ldo = cd;
+        lp.M = Bn; lp.N = cd; lp.K = D; lp.act_in = K22_ACT_NONE; lp.act_out = K22_ACT_NONE;
+        return launch_linear_smallm(lp, K22_F32, st);
+      });
+    }
+    if (!err.empty()) return k22_set_error(K22_EINVAL, err.c_str());
+    size_t off = 0;
+    for (auto& s : slots) { s.off = off; off += (s.bytes + 255) / 256 * 256; }
+    ws_bytes = off + 256;
+    return K22_OK;
+  }
+};
+
+extern "C" {
+
+int k22_prior_create(const K22PriorConfig* cfg, const K22Weight* weights, int n_weights, K22Prior** out) {
+  if (!cfg || !out) return k22_set_error(K22_EINVAL, "prior_create: null argument");
+  if (cfg->dtype != K22_BF16 && cfg->dtype != K22_F32) return k22_set_error(K22_EINVAL, "prior_create: dtype");
+  K22Prior* m = new K22Prior();
+  m->cfg = *cfg; m->dtype = cfg->dtype; m->esz = cfg->dtype == K22_BF16 ? 2 : 4;
+  for (int i = 0; i < n_weights; ++i) m->w[weights[i].name] = weights[i].ptr;
+  *out = m;
+  return K22_OK;
+}
+void k22_prior_destroy(K22Prior* m) { delete m; }
+
+int k22_prior_plan(K22Prior* m, int B, size_t* workspace_bytes) {
+  if (!m || !workspace_bytes) return k22_set_error(K22_EINVAL, "prior_plan: null argument");
+  int rc = m->plan(B);
+  if (rc) return rc;
+  *workspace_bytes = m->ws_bytes;
+  return K22_OK;
+}
+int k22_prior_bind(K22Prior* m, void* workspace, size_t workspace_bytes) {
+  if (!m || !workspace) return k22_set_error(K22_EINVAL, "prior_bind: null argument");
+  if (m->ops.empty()) return k22_set_error(K22_EINVAL, "prior_bind: plan first");
+  if (workspace_bytes < m->ws_bytes) return k22_set_error(K22_ENOMEM, "prior_bind: workspace too small");
+  if ((uintptr_t)workspace % 256) return k22_set_error(K22_EINVAL, "prior_bind: workspace must be 256-byte aligned");
+  m->ws = reinterpret_cast<char*>(workspace);
+  return K22_OK;
+}
+int k22_prior_forward(K22Prior* m, const float* x, const float* timesteps, const float* text_emb, const float* text_enc,
+                      const float* key_valid, float* out, void* stream) {
+  if (!m || !m->ws) return k22_set_error(K22_EINVAL, "prior_forward: bind a workspace first");
+  if (!x || !timesteps || !text_emb || !text_enc || !key_valid || !out) return k22_set_error(K22_EINVAL, "prior_forward: null argument");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const K22PriorConfig& c = m->cfg;
+  hipError_t e;
+#define K22_CPY(dst, src, bytes)                                                   \
+  e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);                \
+  if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+  K22_CPY(m->ptr(m->s_x), x, (size_t)m->B * c.clip_dim * 4);
+  K22_CPY(m->ptr(m->s_t), timesteps, (size_t)m->B * 4);
+  K22_CPY(m->ptr(m->s_txtemb), text_emb, (size_t)m->B * c.clip_dim * 4);
+  K22_CPY(m->ptr(m->s_txtenc), text_enc, (size_t)m->B * c.text_ctx * c.clip_xf_width * 4);
+  K22_CPY(m->ptr(m->s_valid), key_valid, (size_t)m->B * c.text_ctx * 4);
+  for (auto& op : m->ops) { int rc = op(st); if (rc) return rc; }
+  K22_CPY(out, m->ptr(m->s_out), (size_t)m->B * c.clip_dim * 4);
+#undef K22_CPY
+  return K22_OK;
+}
+
+int k22_prior_sampler_step(const float* x, const float* model_out, const float* noise, const float* scales, const float* table_row,
+                           float clamp, float* x_out, int bs, int D, void* stream) {
+  if (!x || !model_out || !noise || !scales || !table_row || !x_out || bs < 1 || D < 1) return k22_set_error(K22_EINVAL, "prior_sampler_step: bad argument");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(prior_sampler_step_kernel, dim3((2 * bs * D + 255) / 256), dim3(256), 0, st, x, model_out, noise, scales, table_row, clamp, x_out, bs, D);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+
+}  // extern "C"

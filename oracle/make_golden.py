@@ -20,7 +20,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 import kandinsky2_amd as k22  # noqa: E402
-from oracle import diffusion_ref, movq_ref, ref_loader, unet_ref  # noqa: E402
+import types  # noqa: E402
+
+from oracle import diffusion_ref, movq_ref, prior_ref, ref_loader, unet_ref  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 
@@ -146,6 +148,60 @@ def movq_case(name, B, h, w, seed_w=0, seed_z=5):
                os.path.join(GOLD, name + ".pt"))
 
 
+def prior_inputs(bs, seed=7):
+    """Seeded conditioning of the prior: rows [cond | uncond]; padding masks of different lengths."""
+    g = torch.Generator().manual_seed(seed)
+    N = 2 * bs
+    cm, cs = torch.randn(768, generator=g) * 0.1, torch.rand(768, generator=g) + 0.5
+    txt_feat, txt_seq = torch.randn(N, 768, generator=g), torch.randn(N, 77, 768, generator=g)
+    mask = torch.zeros(N, 77, dtype=torch.bool)
+    for r in range(bs):
+        mask[r, : 9 + 11 * r] = True
+    mask[bs:, :2] = True
+    x = torch.randn(N, 768, generator=g)
+    return cm, cs, txt_feat, txt_seq, mask, x, g
+
+
+def prior_case(name, hp, bs, steps, seed_w=0):
+    """PriorTransformer.forward and PriorDiffusionModel.forward of the REFERENCE (kandinsky2/model/prior.py) with the
+    sampler's randn / randn_like replaced by injected noise."""
+    pr = ref_loader.ref("model.prior")
+    gd = ref_loader.ref("model.gaussian_diffusion")
+    conf = types.SimpleNamespace(model=types.SimpleNamespace(hparams=types.SimpleNamespace(**hp)),
+                                 diffusion=types.SimpleNamespace(**k22.PRIOR_DIFFUSION_2_1))
+
+    class Tok:  # only used for the (unused here) cf_token buffers, prior.py:314-315
+        def padded_tokens_and_mask(self, texts, ctx):
+            return torch.zeros(1, ctx, dtype=torch.long), torch.ones(1, ctx, dtype=torch.bool)
+
+    cm, cs, txt_feat, txt_seq, mask, x, g = prior_inputs(bs)
+    m = pr.PriorDiffusionModel(conf, Tok(), cm, cs).eval()
+    sd = k22.init_prior_state_dict(hp, seed=seed_w)
+    m.model.load_state_dict(sd, strict=True)
+    N = 2 * bs
+    t = torch.tensor(([999, 500, 3, 40] * N)[:N])
+    with torch.no_grad():
+        fwd = m.model(x, t, text_emb=txt_feat, text_enc=txt_seq, mask=mask, causal_mask=m.causal_mask)
+    ora = prior_ref.transformer_forward(sd, hp, x, t, txt_feat, txt_seq, mask)
+    x_T, noise_seq = torch.randn(N, 768, generator=g), torch.randn(steps, N, 768, generator=g)
+    scales = torch.tensor(([4.0, 2.5, 1.0, 7.0] * bs)[:bs])
+    it = iter(noise_seq)
+    o1, o2 = gd.th.randn_like, gd.th.randn
+    gd.th.randn_like = lambda t_: next(it).to(t_)
+    gd.th.randn = lambda *shape, **kw: x_T.clone()
+    try:
+        with torch.no_grad():
+            smp = m(txt_feat, txt_seq, mask, scales, timestep_respacing=str(steps))
+    finally:
+        gd.th.randn_like, gd.th.randn = o1, o2
+    osm = prior_ref.prior_sample(sd, hp, txt_feat, txt_seq, mask, scales, steps, x_T, noise_seq, cm[None], cs[None])
+    d1, d2 = (ora - fwd).abs().max().item(), (osm - smp).abs().max().item()
+    print(f"{name}: transformer absmax {fwd.abs().max():.3f} oracle-vs-ref {d1:.3e}; {steps}-step sample absmax {smp.abs().max():.3f} oracle-vs-ref {d2:.3e}")
+    assert d1 < 1e-5 and d2 < 1e-4
+    torch.save(dict(name=name, hp=hp, bs=bs, steps=steps, seed_w=seed_w, t=t, scales=scales, forward_out=fwd.clone(), sample=smp.clone()),
+               os.path.join(GOLD, name + ".pt"))
+
+
 def table_fixtures():
     out = {}
     for steps in (10, 50, 100):
@@ -182,6 +238,7 @@ if __name__ == "__main__":
     tiny = k22.tiny_model_config()
     run_case("tiny_text2img", tiny, False, B=2, h=16, w=16, steps=6)
     run_case("tiny_inpaint", tiny, True, B=4, h=16, w=24, steps=4)
+    prior_case("prior_tiny", k22.tiny_prior_hparams(), bs=2, steps=5)
     movq_case("movq_small", B=2, h=8, w=8)
     movq_case("movq_wide", B=1, h=8, w=16)
     if a.full:

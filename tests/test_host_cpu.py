@@ -176,3 +176,42 @@ def test_movq_arena_layout_is_shape_determined():
     assert table["decoder.conv_out.weight"][1] == 64 * 9 * 128 * 2         # 3 output rows padded to 64
     assert table["decoder.mid.block_1.norm1.conv_y.weight"][1] == 512 * 4 * 4  # fp32, evaluated inside the norm kernel
     assert all(off % 256 == 0 for off, _ in table.values()) and arena.dtype == torch.uint8
+
+
+# ---- diffusion prior ---------------------------------------------------------------
+def test_prior_oracle_matches_reference_golden(golden_dir):
+    from oracle import prior_ref
+    fx = _load(golden_dir, "prior_tiny")
+    hp = fx["hp"]
+    sd = k22.init_prior_state_dict(hp, seed=fx["seed_w"])
+    g = torch.Generator().manual_seed(7)
+    bs = fx["bs"]; N = 2 * bs
+    cm, cs = torch.randn(768, generator=g) * 0.1, torch.rand(768, generator=g) + 0.5
+    txt_feat, txt_seq = torch.randn(N, 768, generator=g), torch.randn(N, 77, 768, generator=g)
+    mask = torch.zeros(N, 77, dtype=torch.bool)
+    for r in range(bs):
+        mask[r, : 9 + 11 * r] = True
+    mask[bs:, :2] = True
+    x = torch.randn(N, 768, generator=g)
+    out = prior_ref.transformer_forward(sd, hp, x, fx["t"], txt_feat, txt_seq, mask)
+    assert (out - fx["forward_out"]).abs().max().item() <= 1e-5
+    x_T, noise_seq = torch.randn(N, 768, generator=g), torch.randn(fx["steps"], N, 768, generator=g)
+    smp = prior_ref.prior_sample(sd, hp, txt_feat, txt_seq, mask, fx["scales"], fx["steps"], x_T, noise_seq, cm[None], cs[None])
+    assert (smp - fx["sample"]).abs().max().item() <= 1e-4
+
+
+def test_prior_state_dict_keys_match_reference(golden_dir):
+    with open(os.path.join(golden_dir, "ref_prior_keys.json")) as f:
+        ref = json.load(f)
+    mine = {k: list(v) for k, v in k22.prior_param_shapes(k22.PRIOR_HPARAMS_2_1).items()}
+    assert mine == ref
+
+
+def test_prior_schedule_matches_oracle_tables():
+    from oracle import prior_ref
+    for n in (5, 25, 100):
+        a, b = k22.PriorSchedule(timestep_respacing=str(n)), prior_ref.RefPriorSchedule(n)
+        assert a.timestep_map == b.timestep_map and a.num_timesteps == b.T
+        tab = a.step_table()
+        assert np.array_equal(tab[:, 0], b.c1.astype(np.float32)) and np.array_equal(tab[:, 2], b.logvar.astype(np.float32))
+        assert tab[0, 3] == 0 and (tab[1:, 3] == 1).all()
