@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip the per-op HIP-event pass (roofline object = null)")
     ap.add_argument("--cpu-baseline-size", type=int, default=0, help="image side for the CPU sample (0 = same as --size)")
     ap.add_argument("--tuning-report", default="", help="write the chosen conv/GEMM tile configurations to this file")
+    ap.add_argument("--inpaint", action="store_true", help="inpainting UNet (9 input channels, masked-latent blend in the sampler step): config C4")
     ap.add_argument("--tiny", action="store_true", help="1/3-width UNet (debug only; not a valid bench config)")
     a = ap.parse_args()
 
@@ -69,7 +70,7 @@ def main():
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
     mcfg = k22.tiny_model_config() if a.tiny else k22.MODEL_CONFIG_2_1
-    arch = k22.make_arch(mcfg)
+    arch = k22.make_arch(mcfg, inpainting=a.inpaint)
     tdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     lat = a.size // 8
     B = 2 * a.bs
@@ -108,12 +109,19 @@ def main():
     scratch = torch.empty(L.k22_sampler_scratch_bytes(B, HW), dtype=torch.uint8, device=dev)
     lo, gamma = k22.percentile_index(4 * HW)
     stream = torch.cuda.current_stream().cuda_stream
+    init_img = img_mask = None
+    if a.inpaint:
+        init_img = torch.randn(B, 4, lat, lat, generator=g).to(dev)
+        img_mask = torch.zeros(B, 1, lat, lat)
+        img_mask[..., : lat // 2] = 1.0   # half-plane mask
+        img_mask = img_mask.to(dev)
+        kw.update(inpaint_image=init_img * img_mask, inpaint_mask=img_mask)
 
     def step(k, x, x_next):
         i = T - 1 - (k % T)
         half = x[: a.bs]
         out = m(torch.cat([half, half], 0), ts_rows[i], **kw)
-        _lib.check(L.k22_sampler_step(x.data_ptr(), out.data_ptr(), noise[k].data_ptr(), None, None, table.data_ptr(), i,
+        _lib.check(L.k22_sampler_step(x.data_ptr(), out.data_ptr(), noise[k].data_ptr(), _lib.ptr(init_img), _lib.ptr(img_mask), table.data_ptr(), i,
                                       4.0, 1, -2.0, 2.0, lo, gamma, scratch.data_ptr(), x_next.data_ptr(), None, B, HW, stream))
         return x_next, x
 
@@ -180,11 +188,11 @@ def main():
         value = world * a.steps / el
         line = {
             "metric": "UNet denoise steps/sec @ 768x768 bs=1, 50 steps" if (a.size == 768 and a.bs == 1) else
-                      f"UNet denoise steps/sec @ {a.size}x{a.size} bs={a.bs}",
+                      f"UNet denoise steps/sec @ {a.size}x{a.size} bs={a.bs}" + (" inpainting" if a.inpaint else ""),
             "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(el / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic (seeded random-init weights + N(0,1) conditioning/noise)",
-            "config": {"workload": f"Kandinsky-2.x text2img {a.size}x{a.size}, decoder_steps={a.sched_steps}, bs={a.bs}/GPU "
+            "config": {"workload": f"Kandinsky-2.x {'inpainting' if a.inpaint else 'text2img'} {a.size}x{a.size}, decoder_steps={a.sched_steps}, bs={a.bs}/GPU "
                                    f"(CFG batch {B}x4x{lat}x{lat}), 2.1-architecture UNet ({'tiny' if a.tiny else '1.23B'}) p_sampler step",
                        "images_per_gpu": a.bs, "parallelism": f"prompt-sharded x{world}, weights by one RCCL broadcast",
                        "graph": not a.no_graph},

@@ -149,6 +149,11 @@ int k22_conv3x3_skip(const void* x_padded, const void* Wp, const float* bias, co
 int k22_conv3x3_gnstats(const void* x_padded, const void* Wp, const float* bias, const void* residual, void* out,
                         void* partial, int B, int H, int W, int Cin, int Cout, int Npad, int splitk, int bm, int bn,
                         float* stats, int stats_capacity_rows, int* rows_per_image, int dtype, void* stream);
+/* Developer tool: runs the 256-row bf16 halo kernel once with s_memtime stamps; trace = device u64 [2][1024][4]
+ * (wave 0 / wave 5 of workgroup 0; per tap: before the counted vmcnt wait, after it, after the barrier, after the last
+ * MFMA was issued).  tools/conv_trace.py prints the per-phase cycle budget. */
+int k22_debug_conv_trace(const void* x_padded, const void* Wp, const float* bias, void* out, int B, int H, int W, int Cin, int Cout,
+                         int Npad, unsigned long long* trace, void* stream);
 int k22_groupnorm(const void* x0, const void* x1, int C0, int C1, int B, int H, int W, const float* gamma,
                   const float* beta, const float* film, long film_ld, float eps, int act, int mode, int pad,
                   void* scratch, void* out, int dtype, void* stream);
@@ -186,6 +191,7 @@ int k22_prior_create(const K22PriorConfig* cfg, const K22Weight* weights, int n_
 void k22_prior_destroy(K22Prior* m);
 int k22_prior_plan(K22Prior* m, int B, size_t* workspace_bytes);   /* B = 2*bs rows [cond | uncond], <= 8 */
 int k22_prior_bind(K22Prior* m, void* workspace, size_t workspace_bytes);
+int k22_prior_tuning_report(const K22Prior* m, char* buf, size_t cap);  /* as k22_unet_tuning_report */
 /* x [B][clip_dim], timesteps [B] (as the reference passes them: original indices as floats), text_emb [B][clip_dim],
  * text_enc [B][text_ctx][clip_xf_width], key_valid [B][text_ctx] (1 = token, 0 = padding; the `mask` argument of
  * the reference as floats) -> out [B][clip_dim]; all fp32 device buffers. */

@@ -61,6 +61,7 @@ SIGNATURES = {
     "k22_prior_destroy": (None, [_P]),
     "k22_prior_plan": (_I, [_P, _I, C.POINTER(_Z)]),
     "k22_prior_bind": (_I, [_P, _P, _Z]),
+    "k22_prior_tuning_report": (_I, [_P, C.c_char_p, _Z]),
     "k22_prior_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "k22_prior_sampler_step": (_I, [_P, _P, _P, _P, _P, _F, _P, _I, _I, _P]),
     "k22_movq_create": (_I, [C.POINTER(K22MoVQConfig), C.POINTER(K22Weight), _I, C.POINTER(_P)]),
@@ -75,6 +76,7 @@ SIGNATURES = {
     "k22_conv3x3": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "k22_conv3x3_skip": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "k22_conv3x3_gnstats": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, C.POINTER(_I), _I, _P]),
+    "k22_debug_conv_trace": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "k22_groupnorm": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _L, _F, _I, _I, _I, _P, _P, _I, _P]),
     "k22_groupnorm_scratch_bytes": (_Z, [_I, _I]),
     "k22_attention": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -129,12 +129,16 @@ __global__ __launch_bounds__(256) void attention_kernel(AttentionParams p) {
     // (wave-uniform test) on the tiles that do not raise any query's maximum — the common case.
     float pv[2][16];
     const bool tail = (kt * 64 + 64 > p.Tk);
-    if (tail) {
+    if (tail || p.causal || p.key_valid != nullptr) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (kt * 64 + kb * 32 + c_row(r, lane) >= p.Tk) s[kb][r] = -INFINITY;
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 64 + kb * 32 + c_row(r, lane);
+          bool dead = key >= p.Tk || (p.causal && key > t);
+          if (p.key_valid != nullptr && key < p.kv_n) dead = dead || p.key_valid[(int64_t)b * p.kv_ld + key] == 0.f;
+          if (dead) s[kb][r] = -INFINITY;
+        }
     }
     float mloc = fmaxf(s[0][0], s[1][0]);
 #pragma unroll

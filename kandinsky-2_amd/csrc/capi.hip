@@ -81,9 +81,19 @@ int k22_conv3x3_skip(const void* x_padded, const void* Wp, const float* bias, co
   p.A0 = x_padded; p.Wp = Wp; p.bias = bias; p.out = out; p.partial = reinterpret_cast<float*>(partial);
   p.M = B * H * W; p.N = Cout; p.Npad = Npad; p.Kc = Cin; p.K0 = Cin; p.taps = 9; p.H = H; p.W = W;
   p.ldo = Cout; p.ldr = Cout; p.out_mode = IG_OUT_ROWMAJOR; p.act = K22_ACT_NONE; p.splitk = splitk; p.force_bm = bm; p.force_bn = 0;
-  p.S0 = skip0; p.S1 = skip1; p.SK0 = SK0; p.SK1 = SK1; p.Ws = Ws; p.bias2 = bias_s; p.algo = 2;
+  p.S0 = skip0; p.S1 = skip1; p.SK0 = SK0; p.SK1 = SK1; p.Ws = Ws; p.bias2 = bias_s; p.algo = 0;  /* "conv_algo" option 3 selects the 64-byte-row halo kernel */
   if (p.splitk == 0) p.splitk = partial ? igemm_choose_splitk(p, dtype) : 1;
   return launch_igemm(p, dtype, reinterpret_cast<hipStream_t>(stream));
+}
+
+int k22_debug_conv_trace(const void* x_padded, const void* Wp, const float* bias, void* out, int B, int H, int W, int Cin, int Cout,
+                         int Npad, unsigned long long* trace, void* stream) {
+  IgemmParams p = {};
+  p.stages = -1;
+  p.A0 = x_padded; p.Wp = Wp; p.bias = bias; p.out = out;
+  p.M = B * H * W; p.N = Cout; p.Npad = Npad; p.Kc = Cin; p.K0 = Cin; p.taps = 9; p.H = H; p.W = W;
+  p.ldo = Cout; p.ldr = Cout; p.out_mode = IG_OUT_ROWMAJOR; p.act = K22_ACT_NONE; p.splitk = 1; p.trace = trace;
+  return launch_conv3_halo_trace(p, K22_BF16, reinterpret_cast<hipStream_t>(stream));
 }
 
 size_t k22_groupnorm_scratch_bytes(int B, int C) {
@@ -122,7 +132,7 @@ int k22_attention(const void* qkv, const void* ctxkv, void* kall, void* vtall, v
   kp.qkv = qkv; kp.ctxkv = ctxkv; kp.kall = kall; kp.vtall = vtall; kp.B = B; kp.H = H; kp.T = T; kp.S = S; kp.Tkp = Tkp;
   int rc = launch_kv_pack(kp, dtype, st);
   if (rc) return rc;
-  AttentionParams ap;
+  AttentionParams ap = {};
   ap.q = qkv; ap.ldq = 3 * C; ap.kall = kall; ap.vtall = vtall; ap.out = out; ap.ldo = C;
   ap.B = B; ap.H = H; ap.T = T; ap.Tk = Tk; ap.Tkp = Tkp; ap.scale = 0.125f;
   return launch_attention(ap, dtype, st);

@@ -80,11 +80,14 @@ constexpr int HALO_BN = 128;
 constexpr int HALO_NW = 8;        // waves per workgroup
 constexpr int HALO_MAXA = 8;      // halo LDS-DMA slots per wave per slab: taps 0 .. 9-NBST carry one each
 
-// number of halo pieces issued in the NBST-2 iterations before tap T (they sit between the weight tile this
-// tap needs and "now" in the VMEM queue); taps are unrolled, so this is a compile-time constant.
+// Each iteration issues [weight tile NBST-1 taps ahead (2 loads)] THEN [one halo piece]: the halo piece is the
+// youngest entry of the VMEM queue, so the counted wait for the weight tile can leave it in flight — it gets two
+// taps (~1.6 us at 96x96) to come back from the Infinity Cache / HBM instead of one.  This is the number of halo
+// pieces issued in the NBST-1 iterations before tap T, i.e. younger than the weight tile tap T needs; taps are
+// unrolled, so it is a compile-time constant.
 template <int NBST> constexpr int halo_count_a(int t) {
   int c = 0;
-  for (int k = 1; k <= NBST - 2; ++k) {
+  for (int k = 1; k <= NBST - 1; ++k) {
     const int u = t - k;
     if (u >= 0 && u <= 9 - NBST) ++c;
   }
@@ -93,162 +96,29 @@ template <int NBST> constexpr int halo_count_a(int t) {
 
 }  // namespace
 
-template <typename T, int BM, int NBST>
-__global__ __launch_bounds__(512) void conv3_halo_kernel(const IgemmParams p) {
+// Everything after the 3x3 K loop, shared by the halo kernels: optional fused 1x1 skip connection (a plain-GEMM K loop
+// on 128-byte rows), then the epilogue through LDS (bias, residual, one rounding, 16-byte stores, GroupNorm partials).
+template <typename T, int BM>
+__device__ __forceinline__ void halo_tail(const IgemmParams& p, f32x16_t (&acc)[BM / 128][2], char* smem, int bx, int bz, int img, int v0, int n0) {
   using TR = TT<T>;
   constexpr int BK = TR::BK, EPC = TR::EPC, KSTEPS = TR::KSTEPS;
   constexpr int BN = HALO_BN, NW = HALO_NW, WM = 4, WN = 2;
   constexpr int MI = BM / (WM * 32), NI = BN / (WN * 32);
-  constexpr int B_SLOTS = BN / 8 / NW;  // weight LDS-DMA instructions per wave per tap
+  constexpr int B_SLOTS = BN / 8 / NW;
   constexpr int B_BYTES = BN * 128;
-  constexpr int A_SLOTS = 10 - NBST;    // taps 0 .. 9-NBST issue one halo piece per wave
-  constexpr int GM = 8;
   constexpr int TS = BN * 4 + 16;       // epilogue tile row stride (bytes): conflict-free float4 writes
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int h = lane >> 5, l31 = lane & 31;
-
   const int W2 = p.W + 2;
-  const int VR = p.H * W2;                     // virtual output rows per image
-  const int TPI = (VR + BM - 1) / BM;          // m-tiles per image
-  const int HRp = (BM + 2 * W2 + 2 + 7) & ~7;  // halo rows (padded to whole 8-row LDS-DMA pieces)
-  const int NP = HRp >> 3;
-  const int A_BYTES = HRp * 128;
-  const int PR_MAX = (p.H + 2) * W2 - 1;       // last pixel of one padded plane
-  const int B = p.M / (p.H * p.W);
-
-  // ---- block -> (m-tile, n-tile, k-split) ------------------------------------------------------
-  const int gx = B * TPI, gy = (p.N + BN - 1) / BN;
-  int L = p.xcd_remap ? xcd_remap_h(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int per_z = gx * gy;
-  const int bz = L / per_z;
-  L -= bz * per_z;
-  const int grp = L / (GM * gy);
-  const int first_m = grp * GM;
-  const int gsz = gx - first_m < GM ? gx - first_m : GM;
-  const int lin = L - grp * GM * gy;
-  const int bx = first_m + lin % gsz, by = lin / gsz;
-  const int img = bx / TPI, v0 = (bx - img * TPI) * BM;
-  const int n0 = by * BN;
-
-  const T* __restrict__ Aimg = reinterpret_cast<const T*>(p.A0) + (int64_t)img * (p.H + 2) * W2 * p.Kc;
-  const T* __restrict__ Wp = reinterpret_cast<const T*>(p.Wp);
-
-  // ---- loader geometry ---------------------------------------------------------------------------
-  // halo piece j (8 rows) is issued by wave j % NW in its slot j / NW; lane -> (row 8j + lane/8, position lane%8)
-  int aoff[A_SLOTS];
-#pragma unroll
-  for (int q = 0; q < A_SLOTS; ++q) {
-    int j = q * NW + wave;
-    if (j > NP - 1) j = NP - 1;  // surplus slots re-load the last piece (same bytes, same place): uniform counting
-    const int hr = 8 * j + (lane >> 3);
-    int pr = v0 + hr;
-    if (pr > PR_MAX) pr = PR_MAX;
-    const int chunk = (lane & 7) ^ ((hr >> 1) & 7);
-    aoff[q] = pr * p.Kc + chunk * EPC;
-  }
-  int boff[B_SLOTS];
-#pragma unroll
-  for (int i = 0; i < B_SLOTS; ++i) {
-    const int row = 8 * (wave + NW * i) + (lane >> 3);
-    int n = n0 + row;
-    if (n > p.Npad - 1) n = p.Npad - 1;
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    boff[i] = n * 9 * p.Kc + chunk * EPC;
-  }
-  const int nslab = p.Kc / BK;
-  int s0 = 0, s1 = nslab;
-  if (p.splitk > 1) {
-    const int per = (nslab + p.splitk - 1) / p.splitk;
-    s0 = bz * per;
-    s1 = s0 + per < nslab ? s0 + per : nslab;
-  }
-
-  f32x16_t acc[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-  char* const Bst = smem + 2 * A_BYTES;
-  // fragment rows: A row = wm*(BM/4) + mi*32 + l31 + tap shift ; B row = wn*(BN/2) + ni*32 + l31
+  const int VR = p.H * W2;
   const int abase = wm * (BM / WM) + l31;
   int brow[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) brow[ni] = (wn * (BN / WN) + ni * 32 + l31) * 128;
-  const int bsw = (l31 >> 1) & 7;  // (row >> 1) & 7 with row = multiple of 32 + l31
+  const int bsw = (l31 >> 1) & 7;
 
-#define K22_ISSUE_A(Q, SLAB, DST)                                                                          \
-  {                                                                                                        \
-    int j_ = (Q) * NW + wave;                                                                              \
-    if (j_ > NP - 1) j_ = NP - 1;                                                                          \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Aimg + aoff[Q] + (SLAB) * BK), \
-                                     (__attribute__((address_space(3))) void*)((DST) + j_ * 1024), 16, 0, 0); \
-  }
-#define K22_ISSUE_B(SLAB, TAP, STAGE)                                                                      \
-  {                                                                                                        \
-    const int kofs_ = (TAP) * p.Kc + (SLAB) * BK;                                                          \
-    char* dst_ = Bst + (STAGE) * B_BYTES + wave * 1024;                                                    \
-    _Pragma("unroll") for (int i = 0; i < B_SLOTS; ++i)                                                    \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wp + boff[i] + kofs_), \
-                                         (__attribute__((address_space(3))) void*)(dst_ + i * NW * 1024), 16, 0, 0); \
-  }
-
-  if (s0 < s1) {
-    // prologue: the whole halo of the first slab, then the weight tiles of taps 0 .. NBST-2
-#pragma unroll
-    for (int q = 0; q < A_SLOTS; ++q) K22_ISSUE_A(q, s0, smem);
-#pragma unroll
-    for (int t = 0; t < NBST - 1; ++t) K22_ISSUE_B(s0, t, t);
-    int cur = 0;               // ring slot of the current tap's weights
-    int fill = NBST - 1;       // ring slot the tile NBST-1 taps ahead goes into
-    for (int s = s0; s < s1; ++s) {
-      char* const Acur = smem + ((s - s0) & 1) * A_BYTES;
-      char* const Anext = smem + (((s - s0) & 1) ^ 1) * A_BYTES;
-      const int sn = s + 1 < s1 ? s + 1 : s1 - 1;  // past-the-end loads re-read the last slab (uniform counting)
-      // the nine taps are expanded with literal tap numbers: the vmcnt immediates and the (slab, tap) of the
-      // prefetched weight tile are compile-time functions of the tap
-#define K22_TAP(TAP)                                                                                       \
-      {                                                                                                    \
-        wait_vmcnt<B_SLOTS * (NBST - 2) + halo_count_a<NBST>(TAP)>();                                      \
-        __builtin_amdgcn_s_barrier();                                                                      \
-        /* one piece of the next slab's halo, then the weight tile NBST-1 taps ahead */                    \
-        if constexpr ((TAP) < A_SLOTS) K22_ISSUE_A(((TAP) < A_SLOTS ? (TAP) : 0), sn, Anext);              \
-        {                                                                                                  \
-          constexpr int ta_ = ((TAP) + NBST - 1) % 9;                                                      \
-          const int sa_ = ((TAP) + NBST - 1 >= 9) ? sn : s;                                                \
-          K22_ISSUE_B(sa_, ta_, fill);                                                                     \
-        }                                                                                                  \
-        const char* Bcur = Bst + cur * B_BYTES;                                                            \
-        const int shift = ((TAP) / 3) * W2 + ((TAP) % 3);                                                  \
-        const char* arow[MI];                                                                              \
-        int asw[MI];                                                                                       \
-        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                \
-          const int ar = abase + mi * 32 + shift;                                                          \
-          arow[mi] = Acur + ar * 128;                                                                      \
-          asw[mi] = (ar >> 1) & 7;                                                                         \
-        }                                                                                                  \
-        _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks) {                                            \
-          Frag<T> a[MI], b[NI];                                                                            \
-          _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) ld_frag_at(a[mi], arow[mi], asw[mi], ks, h);   \
-          _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) ld_frag_at(b[ni], Bcur + brow[ni], bsw, ks, h); \
-          _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                \
-            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], b[ni], a[mi]);         \
-        }                                                                                                  \
-        cur = (cur + 1 == NBST) ? 0 : cur + 1;                                                             \
-        fill = (fill + 1 == NBST) ? 0 : fill + 1;                                                          \
-      }
-      K22_TAP(0) K22_TAP(1) K22_TAP(2) K22_TAP(3) K22_TAP(4) K22_TAP(5) K22_TAP(6) K22_TAP(7) K22_TAP(8)
-#undef K22_TAP
-    }
-  }
-#undef K22_ISSUE_A
-#undef K22_ISSUE_B
   // ---- fused 1x1 skip connection: acc += X[tile pixels][SK] . Ws[n][SK]^T, 2-stage LDS-DMA pipeline ----------
   if (p.S0 != nullptr) {
     const int SK = p.SK0 + p.SK1;
@@ -423,6 +293,366 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const IgemmParams p) {
   }
 }
 
+template <typename T, int BM, int NBST, bool TRACE = false>
+__global__ __launch_bounds__(512) void conv3_halo_kernel(const IgemmParams p) {
+  using TR = TT<T>;
+  constexpr int BK = TR::BK, EPC = TR::EPC, KSTEPS = TR::KSTEPS;
+  constexpr int BN = HALO_BN, NW = HALO_NW, WM = 4, WN = 2;
+  constexpr int MI = BM / (WM * 32), NI = BN / (WN * 32);
+  constexpr int B_SLOTS = BN / 8 / NW;  // weight LDS-DMA instructions per wave per tap
+  constexpr int B_BYTES = BN * 128;
+  constexpr int A_SLOTS = 10 - NBST;    // taps 0 .. 9-NBST issue one halo piece per wave
+  constexpr int GM = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int h = lane >> 5, l31 = lane & 31;
+
+  const int W2 = p.W + 2;
+  const int VR = p.H * W2;                     // virtual output rows per image
+  const int TPI = (VR + BM - 1) / BM;          // m-tiles per image
+  const int HRp = (BM + 2 * W2 + 2 + 7) & ~7;  // halo rows (padded to whole 8-row LDS-DMA pieces)
+  const int NP = HRp >> 3;
+  const int A_BYTES = HRp * 128;
+  const int PR_MAX = (p.H + 2) * W2 - 1;       // last pixel of one padded plane
+  const int B = p.M / (p.H * p.W);
+
+  // ---- block -> (m-tile, n-tile, k-split) ------------------------------------------------------
+  const int gx = B * TPI, gy = (p.N + BN - 1) / BN;
+  int L = p.xcd_remap ? xcd_remap_h(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int per_z = gx * gy;
+  const int bz = L / per_z;
+  L -= bz * per_z;
+  const int grp = L / (GM * gy);
+  const int first_m = grp * GM;
+  const int gsz = gx - first_m < GM ? gx - first_m : GM;
+  const int lin = L - grp * GM * gy;
+  const int bx = first_m + lin % gsz, by = lin / gsz;
+  const int img = bx / TPI, v0 = (bx - img * TPI) * BM;
+  const int n0 = by * BN;
+
+  const T* __restrict__ Aimg = reinterpret_cast<const T*>(p.A0) + (int64_t)img * (p.H + 2) * W2 * p.Kc;
+  const T* __restrict__ Wp = reinterpret_cast<const T*>(p.Wp);
+
+  // ---- loader geometry ---------------------------------------------------------------------------
+  // halo piece j (8 rows) is issued by wave j % NW in its slot j / NW; lane -> (row 8j + lane/8, position lane%8)
+  int aoff[A_SLOTS];
+#pragma unroll
+  for (int q = 0; q < A_SLOTS; ++q) {
+    int j = q * NW + wave;
+    if (j > NP - 1) j = NP - 1;  // surplus slots re-load the last piece (same bytes, same place): uniform counting
+    const int hr = 8 * j + (lane >> 3);
+    int pr = v0 + hr;
+    if (pr > PR_MAX) pr = PR_MAX;
+    const int chunk = (lane & 7) ^ ((hr >> 1) & 7);
+    aoff[q] = pr * p.Kc + chunk * EPC;
+  }
+  int boff[B_SLOTS];
+#pragma unroll
+  for (int i = 0; i < B_SLOTS; ++i) {
+    const int row = 8 * (wave + NW * i) + (lane >> 3);
+    int n = n0 + row;
+    if (n > p.Npad - 1) n = p.Npad - 1;
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    boff[i] = n * 9 * p.Kc + chunk * EPC;
+  }
+  const int nslab = p.Kc / BK;
+  int s0 = 0, s1 = nslab;
+  if (p.splitk > 1) {
+    const int per = (nslab + p.splitk - 1) / p.splitk;
+    s0 = bz * per;
+    s1 = s0 + per < nslab ? s0 + per : nslab;
+  }
+
+  f32x16_t acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  char* const Bst = smem + 2 * A_BYTES;
+  // fragment rows: A row = wm*(BM/4) + mi*32 + l31 + tap shift ; B row = wn*(BN/2) + ni*32 + l31
+  const int abase = wm * (BM / WM) + l31;
+  int brow[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) brow[ni] = (wn * (BN / WN) + ni * 32 + l31) * 128;
+  const int bsw = (l31 >> 1) & 7;  // (row >> 1) & 7 with row = multiple of 32 + l31
+
+#define K22_ISSUE_A(Q, SLAB, DST)                                                                          \
+  {                                                                                                        \
+    int j_ = (Q) * NW + wave;                                                                              \
+    if (j_ > NP - 1) j_ = NP - 1;                                                                          \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Aimg + aoff[Q] + (SLAB) * BK), \
+                                     (__attribute__((address_space(3))) void*)((DST) + j_ * 1024), 16, 0, 0); \
+  }
+#define K22_ISSUE_B(SLAB, TAP, STAGE)                                                                      \
+  {                                                                                                        \
+    const int kofs_ = (TAP) * p.Kc + (SLAB) * BK;                                                          \
+    char* dst_ = Bst + (STAGE) * B_BYTES + wave * 1024;                                                    \
+    _Pragma("unroll") for (int i = 0; i < B_SLOTS; ++i)                                                    \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wp + boff[i] + kofs_), \
+                                         (__attribute__((address_space(3))) void*)(dst_ + i * NW * 1024), 16, 0, 0); \
+  }
+
+  if (s0 < s1) {
+    // prologue: the whole halo of the first slab, then the weight tiles of taps 0 .. NBST-2
+#pragma unroll
+    for (int q = 0; q < A_SLOTS; ++q) K22_ISSUE_A(q, s0, smem);
+#pragma unroll
+    for (int t = 0; t < NBST - 1; ++t) K22_ISSUE_B(s0, t, t);
+    int trace_it = 0;
+    (void)trace_it;
+    int cur = 0;               // ring slot of the current tap's weights
+    int fill = NBST - 1;       // ring slot the tile NBST-1 taps ahead goes into
+    for (int s = s0; s < s1; ++s) {
+      char* const Acur = smem + ((s - s0) & 1) * A_BYTES;
+      char* const Anext = smem + (((s - s0) & 1) ^ 1) * A_BYTES;
+      const int sn = s + 1 < s1 ? s + 1 : s1 - 1;  // past-the-end loads re-read the last slab (uniform counting)
+      // the nine taps are expanded with literal tap numbers: the vmcnt immediates and the (slab, tap) of the
+      // prefetched weight tile are compile-time functions of the tap
+#define K22_TAP(TAP)                                                                                       \
+      {                                                                                                    \
+        unsigned long long tr0_ = 0, tr1_ = 0, tr2_ = 0;                                                   \
+        if constexpr (TRACE) tr0_ = __builtin_amdgcn_s_memtime();                                          \
+        wait_vmcnt<B_SLOTS * (NBST - 2) + halo_count_a<NBST>(TAP)>();                                      \
+        if constexpr (TRACE) tr1_ = __builtin_amdgcn_s_memtime();                                          \
+        __builtin_amdgcn_s_barrier();                                                                      \
+        if constexpr (TRACE) tr2_ = __builtin_amdgcn_s_memtime();                                          \
+        /* the weight tile NBST-1 taps ahead, then one piece of the next slab's halo */                    \
+        {                                                                                                  \
+          constexpr int ta_ = ((TAP) + NBST - 1) % 9;                                                      \
+          const int sa_ = ((TAP) + NBST - 1 >= 9) ? sn : s;                                                \
+          K22_ISSUE_B(sa_, ta_, fill);                                                                     \
+        }                                                                                                  \
+        if constexpr ((TAP) < A_SLOTS) K22_ISSUE_A(((TAP) < A_SLOTS ? (TAP) : 0), sn, Anext);              \
+        const char* Bcur = Bst + cur * B_BYTES;                                                            \
+        const int shift = ((TAP) / 3) * W2 + ((TAP) % 3);                                                  \
+        const char* arow[MI];                                                                              \
+        int asw[MI];                                                                                       \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                \
+          const int ar = abase + mi * 32 + shift;                                                          \
+          arow[mi] = Acur + ar * 128;                                                                      \
+          asw[mi] = (ar >> 1) & 7;                                                                         \
+        }                                                                                                  \
+        _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks) {                                            \
+          Frag<T> a[MI], b[NI];                                                                            \
+          _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) ld_frag_at(a[mi], arow[mi], asw[mi], ks, h);   \
+          _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) ld_frag_at(b[ni], Bcur + brow[ni], bsw, ks, h); \
+          _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], b[ni], a[mi]);         \
+        }                                                                                                  \
+        if constexpr (TRACE) {                                                                             \
+          /* stamp after the last MFMA has been ISSUED (issue blocks while the pipe is busy) */            \
+          asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[MI - 1][NI - 1][15]));                             \
+          const unsigned long long tr3_ = __builtin_amdgcn_s_memtime();                                    \
+          if (blockIdx.x == 0 && (wave == 0 || wave == 5) && lane == 0 && p.trace != nullptr) {            \
+            unsigned long long* o_ = p.trace + ((size_t)(wave ? 1 : 0) * 4096 + (size_t)trace_it * 4);     \
+            if (trace_it < 1024) { o_[0] = tr0_; o_[1] = tr1_; o_[2] = tr2_; o_[3] = tr3_; }                \
+          }                                                                                                \
+          ++trace_it;                                                                                      \
+        }                                                                                                  \
+        cur = (cur + 1 == NBST) ? 0 : cur + 1;                                                             \
+        fill = (fill + 1 == NBST) ? 0 : fill + 1;                                                          \
+      }
+      K22_TAP(0) K22_TAP(1) K22_TAP(2) K22_TAP(3) K22_TAP(4) K22_TAP(5) K22_TAP(6) K22_TAP(7) K22_TAP(8)
+#undef K22_TAP
+    }
+  }
+#undef K22_ISSUE_A
+#undef K22_ISSUE_B
+  halo_tail<T, BM>(p, acc, smem, bx, bz, img, v0, n0);
+}
+
+// ================================================================================================================
+// conv3_halo3_kernel: the same LDS-resident halo scheme on 64-BYTE rows.  The K loop walks HALF slabs (32 bf16 / 16 fp32
+// channels); one iteration = the three taps of one filter row (ky) of one half slab = 24 MFMAs per wave between
+// barriers (16 before), its weight tiles (3 x 128 rows x 64 B = 24 KB) sit in an RB-deep ring (RB-1 iterations in
+// flight: 1-3 us of prefetch even where the weights stream from HBM) and the halo buffers shrink to half
+// (2 x 29 KB at 96x96 instead of 2 x 57 KB), which is what makes room for the deeper ring at the wide levels.
+//   per wave per iteration: <= 3 halo LDS-DMA pieces (16 rows x 64 B each, first two iterations of a half slab) + 3 weight
+//   pieces, 24 ds_read_b128 (swizzle keyed on row >> 2: conflict-free for 64-byte rows), 24 MFMAs.
+// ================================================================================================================
+namespace {
+__device__ __forceinline__ void ld_frag64(Frag<bf16_t>& f, const char* rowp, int sw, int ks, int h) {
+  f.v = *reinterpret_cast<const u32x4_t*>(rowp + (((2 * ks + h) ^ sw) << 4));
+}
+__device__ __forceinline__ void ld_frag64(Frag<float>& f, const char* rowp, int sw, int /*ks == 0*/, int h) {
+  const float4 a = *reinterpret_cast<const float4*>(rowp + (((2 * h) ^ sw) << 4));
+  const float4 b = *reinterpret_cast<const float4*>(rowp + (((2 * h + 1) ^ sw) << 4));
+  f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
+  f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+}
+// loads a wave may leave in flight at the top of iteration KY (see the derivation next to K22_IT3 below)
+template <int RB> constexpr int halo3_wait(int ky) { return RB == 2 ? 0 : (RB == 3 ? (ky == 0 ? 3 : 6) : (ky == 0 ? 6 : (ky == 1 ? 9 : 12))); }
+constexpr int HALO3_ASLOTS = 6;   // halo LDS-DMA slots per wave per half slab (3 in each of its first two iterations)
+}  // namespace
+
+template <typename T, int BM, int RB>
+__global__ __launch_bounds__(512) void conv3_halo3_kernel(const IgemmParams p) {
+  constexpr int EPH = 64 / (int)sizeof(T);   // channels per 64-byte half-slab row
+  constexpr int EPC = TT<T>::EPC;            // channels per 16-byte chunk
+  constexpr int KS_U = EPH / 16;             // MFMA k-steps per tap of a half slab (2 bf16, 1 fp32)
+  constexpr int BN = HALO_BN, NW = HALO_NW, WM = 4, WN = 2;
+  constexpr int MI = BM / (WM * 32), NI = BN / (WN * 32);
+  constexpr int BT_BYTES = 3 * BN * 64;      // weight tiles of one iteration (three taps)
+  constexpr int GM = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int h = lane >> 5, l31 = lane & 31;
+
+  const int W2 = p.W + 2;
+  const int VR = p.H * W2;
+  const int TPI = (VR + BM - 1) / BM;
+  const int HR16 = (BM + 2 * W2 + 2 + 15) & ~15;   // halo rows, whole 16-row LDS-DMA pieces
+  const int NPA = HR16 >> 4;
+  const int A_BYTES = HR16 * 64;
+  const int PR_MAX = (p.H + 2) * W2 - 1;
+  const int B = p.M / (p.H * p.W);
+
+  const int gx = B * TPI, gy = (p.N + BN - 1) / BN;
+  int L = p.xcd_remap ? xcd_remap_h(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int per_z = gx * gy;
+  const int bz = L / per_z;
+  L -= bz * per_z;
+  const int grp = L / (GM * gy);
+  const int first_m = grp * GM;
+  const int gsz = gx - first_m < GM ? gx - first_m : GM;
+  const int lin = L - grp * GM * gy;
+  const int bx = first_m + lin % gsz, by = lin / gsz;
+  const int img = bx / TPI, v0 = (bx - img * TPI) * BM;
+  const int n0 = by * BN;
+
+  const T* __restrict__ Aimg = reinterpret_cast<const T*>(p.A0) + (int64_t)img * (p.H + 2) * W2 * p.Kc;
+  const T* __restrict__ Wp = reinterpret_cast<const T*>(p.Wp);
+
+  // loader geometry: a piece = 16 rows x 64 B; lane -> (row 16*piece + lane/4, position lane%4)
+  int aoff[HALO3_ASLOTS];
+#pragma unroll
+  for (int q = 0; q < HALO3_ASLOTS; ++q) {
+    int j = q * NW + wave;
+    if (j > NPA - 1) j = NPA - 1;   // surplus slots re-load the last piece (same bytes, same place): uniform counting
+    const int hr = 16 * j + (lane >> 2);
+    int pr = v0 + hr;
+    if (pr > PR_MAX) pr = PR_MAX;
+    aoff[q] = pr * p.Kc + ((lane & 3) ^ ((hr >> 2) & 3)) * EPC;
+  }
+  int boff;
+  {
+    const int row = 16 * wave + (lane >> 2);
+    int n = n0 + row;
+    if (n > p.Npad - 1) n = p.Npad - 1;
+    boff = n * 9 * p.Kc + ((lane & 3) ^ ((row >> 2) & 3)) * EPC;
+  }
+  const int nhs = p.Kc / EPH;
+  int h0 = 0, h1 = nhs;
+  if (p.splitk > 1) {
+    const int per = (nhs + p.splitk - 1) / p.splitk;
+    h0 = bz * per;
+    h1 = h0 + per < nhs ? h0 + per : nhs;
+  }
+
+  f32x16_t acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  char* const Bring = smem + 2 * A_BYTES;
+  const int abase = wm * (BM / WM) + l31;
+  int brow[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) brow[ni] = (wn * (BN / WN) + ni * 32 + l31) * 64;
+  const int bsw = (l31 >> 2) & 3;
+
+#define K22_ISSUE_A3(Q, HS, DST)                                                                           \
+  {                                                                                                        \
+    int j_ = (Q) * NW + wave;                                                                              \
+    if (j_ > NPA - 1) j_ = NPA - 1;                                                                        \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Aimg + aoff[Q] + (HS) * EPH), \
+                                     (__attribute__((address_space(3))) void*)((DST) + j_ * 1024), 16, 0, 0); \
+  }
+  // weight tiles of iteration (HS, KY): taps KY*3 + {0,1,2}; this wave's piece = rows [16*wave, +16) of each
+#define K22_ISSUE_B3(HS, KY, SLOT)                                                                         \
+  {                                                                                                        \
+    const int kofs_ = (KY) * 3 * p.Kc + (HS) * EPH;                                                        \
+    char* dst_ = Bring + (SLOT) * BT_BYTES + wave * 1024;                                                  \
+    _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                       \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wp + boff + kofs_ + kx * p.Kc), \
+                                         (__attribute__((address_space(3))) void*)(dst_ + kx * BN * 64), 16, 0, 0); \
+  }
+
+  if (h0 < h1) {
+    // prologue: the whole halo of the first half slab, then the weight tiles of iterations 0 .. RB-2
+#pragma unroll
+    for (int q = 0; q < HALO3_ASLOTS; ++q) K22_ISSUE_A3(q, h0, smem);
+#pragma unroll
+    for (int j = 0; j < RB - 1; ++j) {
+      const int hs_ = h0 + j / 3 < h1 ? h0 + j / 3 : h1 - 1;
+      K22_ISSUE_B3(hs_, j % 3, j);
+    }
+    int cur = 0, fill = RB - 1;
+    for (int hs = h0; hs < h1; ++hs) {
+      char* const Acur = smem + ((hs - h0) & 1) * A_BYTES;
+      char* const Anext = smem + (((hs - h0) & 1) ^ 1) * A_BYTES;
+      const int hn = hs + 1 < h1 ? hs + 1 : h1 - 1;   // past-the-end loads re-read the last half slab (uniform counting)
+      // VMEM queue of a wave, per iteration: [3 halo pieces (KY < 2)] then [3 weight pieces of iteration it+RB-1].
+      // At the top of iteration KY the weight tiles issued RB-1 iterations ago must have landed, and at KY == 0 also the
+      // halo issued in the previous half slab's iterations 0 and 1; everything younger may stay in flight:
+      //   RB = 2: 0 / 0 / 0     RB = 3: 3 / 6 / 6     RB = 4: 6 (halo!) / 9 / 12        (KY = 0 / 1 / 2)
+#define K22_IT3(KY)                                                                                        \
+      {                                                                                                    \
+        wait_vmcnt<halo3_wait<RB>(KY)>();                                                                  \
+        __builtin_amdgcn_s_barrier();                                                                      \
+        if constexpr ((KY) < 2) {                                                                          \
+          K22_ISSUE_A3(3 * ((KY) < 2 ? (KY) : 0) + 0, hn, Anext);                                          \
+          K22_ISSUE_A3(3 * ((KY) < 2 ? (KY) : 0) + 1, hn, Anext);                                          \
+          K22_ISSUE_A3(3 * ((KY) < 2 ? (KY) : 0) + 2, hn, Anext);                                          \
+        }                                                                                                  \
+        {                                                                                                  \
+          constexpr int kya_ = ((KY) + RB - 1) % 3;                                                        \
+          int hsa_ = hs + ((KY) + RB - 1) / 3;                                                             \
+          if (hsa_ > h1 - 1) hsa_ = h1 - 1;                                                                \
+          K22_ISSUE_B3(hsa_, kya_, fill);                                                                  \
+        }                                                                                                  \
+        const char* Bcur = Bring + cur * BT_BYTES;                                                         \
+        _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) {                                                 \
+          const int shift = (KY) * W2 + kx;                                                                \
+          const char* arow[MI];                                                                            \
+          int asw[MI];                                                                                     \
+          _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                              \
+            const int ar = abase + mi * 32 + shift;                                                        \
+            arow[mi] = Acur + ar * 64;                                                                     \
+            asw[mi] = (ar >> 2) & 3;                                                                       \
+          }                                                                                                \
+          _Pragma("unroll") for (int ks = 0; ks < KS_U; ++ks) {                                            \
+            Frag<T> a[MI], b[NI];                                                                          \
+            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) ld_frag64(a[mi], arow[mi], asw[mi], ks, h);  \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) ld_frag64(b[ni], Bcur + kx * BN * 64 + brow[ni], bsw, ks, h); \
+            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                              \
+              _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], b[ni], a[mi]);       \
+          }                                                                                                \
+        }                                                                                                  \
+        cur = (cur + 1 == RB) ? 0 : cur + 1;                                                               \
+        fill = (fill + 1 == RB) ? 0 : fill + 1;                                                            \
+      }
+      K22_IT3(0) K22_IT3(1) K22_IT3(2)
+#undef K22_IT3
+    }
+  }
+#undef K22_ISSUE_A3
+#undef K22_ISSUE_B3
+  halo_tail<T, BM>(p, acc, smem, bx, bz, img, v0, n0);
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 static int halo_rows(const IgemmParams& p, int bm) { return (bm + 2 * (p.W + 2) + 2 + 7) & ~7; }
 
@@ -450,6 +680,21 @@ static int halo_pick_nbst(const IgemmParams& p, int bm) {
   return 0;
 }
 
+static int halo3_rows(const IgemmParams& p, int bm) { return (bm + 2 * (p.W + 2) + 2 + 15) & ~15; }
+static size_t halo3_smem_bytes(const IgemmParams& p, int bm, int rb) {
+  const size_t main_loop = (size_t)2 * halo3_rows(p, bm) * 64 + (size_t)rb * 3 * HALO_BN * 64;
+  const size_t epi = (size_t)bm * (HALO_BN * 4 + 16);
+  const size_t skip = p.S0 ? (size_t)2 * (bm * 128 + HALO_BN * 128) : 0;
+  size_t m = main_loop > epi ? main_loop : epi;
+  return m > skip ? m : skip;
+}
+static int halo3_pick_rb(const IgemmParams& p, int bm) {
+  if (halo3_rows(p, bm) / 16 > HALO3_ASLOTS * HALO_NW) return 0;
+  for (int rb : {4, 3, 2})
+    if (halo3_smem_bytes(p, bm, rb) <= 160 * 1024) return rb;
+  return 0;
+}
+
 bool conv3_halo_supported(const IgemmParams& p, int dtype, int bm) {
   const int BK = (dtype == K22_BF16) ? 64 : 32;
   if (p.taps != 9 || (bm != 256 && bm != 128)) return false;
@@ -460,7 +705,7 @@ bool conv3_halo_supported(const IgemmParams& p, int dtype, int bm) {
     if (!p.Ws || p.SK0 % BK || p.SK1 % BK || (p.SK1 > 0 && !p.S1) || p.SK0 <= 0) return false;
     if ((int64_t)p.M * (p.SK0 > p.SK1 ? p.SK0 : p.SK1) >= (1ll << 31) || (int64_t)p.Npad * (p.SK0 + p.SK1) >= (1ll << 31)) return false;
   }
-  if (halo_pick_nbst(p, bm) == 0) return false;
+  if ((p.algo == 3 ? halo3_pick_rb(p, bm) : halo_pick_nbst(p, bm)) == 0) return false;
   if ((int64_t)(p.H + 2) * (p.W + 2) * p.Kc >= (1ll << 31) || (int64_t)p.Npad * 9 * p.Kc >= (1ll << 31)) return false;
   return true;
 }
@@ -493,9 +738,61 @@ static int launch_halo_nbst(const IgemmParams& p, int nbst, int splitk, hipStrea
   return launch_halo_cfg<T, BM, 6>(p, splitk, stream);
 }
 
+template <typename T, int BM, int RB>
+static int launch_halo3_cfg(const IgemmParams& p, int splitk, hipStream_t stream) {
+  const size_t smem = halo3_smem_bytes(p, BM, RB);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo3_kernel<T, BM, RB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+    attr_set = true;
+  }
+  IgemmParams q = p;
+  q.splitk = splitk;
+  const int B = p.M / (p.H * p.W);
+  const int nblocks = B * conv3_halo_tiles_per_image(p, BM) * ((p.N + HALO_BN - 1) / HALO_BN) * splitk;
+  hipLaunchKernelGGL((conv3_halo3_kernel<T, BM, RB>), dim3(nblocks), dim3(512), smem, stream, q);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+template <typename T, int BM>
+static int launch_halo3_rb(const IgemmParams& p, int rb, int splitk, hipStream_t stream) {
+  if (rb == 2) return launch_halo3_cfg<T, BM, 2>(p, splitk, stream);
+  if (rb == 3) return launch_halo3_cfg<T, BM, 3>(p, splitk, stream);
+  return launch_halo3_cfg<T, BM, 4>(p, splitk, stream);
+}
+
+// developer tool: conv3_halo_kernel<bf16, 256, NBST> with per-tap s_memtime stamps (wave 0 and wave 5 of block 0):
+// trace[w][tap][4] = (before the counted vmcnt wait, after it, after the barrier, after the last MFMA was issued)
+int launch_conv3_halo_trace(const IgemmParams& p, int dtype, hipStream_t stream) {
+  if (dtype != K22_BF16 || !conv3_halo_supported(p, dtype, 256) || p.trace == nullptr) return k22_set_error(K22_EINVAL, "conv3_halo_trace: bf16, BM = 256 only");
+  const int nbst = halo_pick_nbst(p, 256) >= 4 ? 4 : 2;
+  const size_t smem = halo_smem_bytes(p, 256, nbst);
+  IgemmParams q = p;
+  q.splitk = 1; q.xcd_remap = 1;
+  const int B = p.M / (p.H * p.W);
+  const int nblocks = B * conv3_halo_tiles_per_image(p, 256) * ((p.N + HALO_BN - 1) / HALO_BN);
+  if (nbst == 4) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_kernel<bf16_t, 256, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((conv3_halo_kernel<bf16_t, 256, 4, true>), dim3(nblocks), dim3(512), smem, stream, q);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_kernel<bf16_t, 256, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((conv3_halo_kernel<bf16_t, 256, 2, true>), dim3(nblocks), dim3(512), smem, stream, q);
+  }
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+
 // Launches the halo kernel only (the split-K reduction, if any, is the caller's: launch_igemm).
+// p.algo == 3 selects the 64-byte-row kernel (conv3_halo3_kernel), anything else the 128-byte-row one.
 int launch_conv3_halo(const IgemmParams& p, int dtype, int bm, int splitk, hipStream_t stream) {
   if (!conv3_halo_supported(p, dtype, bm)) return k22_set_error(K22_EINVAL, "conv3_halo: unsupported problem");
+  if (p.algo == 3) {
+    int rb = halo3_pick_rb(p, bm);
+    if (p.stages >= 2 && p.stages < rb) rb = p.stages;
+    if (dtype == K22_BF16) return bm == 256 ? launch_halo3_rb<bf16_t, 256>(p, rb, splitk, stream) : launch_halo3_rb<bf16_t, 128>(p, rb, splitk, stream);
+    return bm == 256 ? launch_halo3_rb<float, 256>(p, rb, splitk, stream) : launch_halo3_rb<float, 128>(p, rb, splitk, stream);
+  }
   int nbst = halo_pick_nbst(p, bm);
   if (p.stages >= 2 && p.stages < nbst) nbst = p.stages == 5 ? 4 : p.stages;  // tuning knob: shallower ring on request
   if (dtype == K22_BF16) return bm == 256 ? launch_halo_nbst<bf16_t, 256>(p, nbst, splitk, stream) : launch_halo_nbst<bf16_t, 128>(p, nbst, splitk, stream);

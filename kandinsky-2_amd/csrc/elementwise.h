@@ -52,6 +52,9 @@ struct AttentionParams {
   void* out; int64_t ldo;       // [B*T][ldo], head h at column h*64
   int B, H, T, Tk, Tkp;
   float scale;                  // applied to q.k (reference: ch^-0.25 on both q and k => 1/8)
+  int causal;                   // 1: key j attends only to queries t >= j (prior transformer, prior.py:326-334)
+  const float* key_valid;       // optional [B][kv_ld]: 0 = padding key (masked for every query); keys >= kv_n are valid
+  int kv_ld, kv_n;
 };
 struct SamplerParams {
   const float* x;          // [N][4][HW] current latent (fp32 NCHW)

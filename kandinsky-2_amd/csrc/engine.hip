@@ -12,6 +12,7 @@
 #include "kernels.h"
 #include "elementwise.h"
 #include "../../include/k22.h"
+#include "tuning.h"
 
 #include <deque>
 #include <functional>
@@ -44,22 +45,6 @@ struct Op {
   int operator()(hipStream_t st) const { return fn(st); }
 };
 typedef std::vector<Op> OpList;
-
-// One tile configuration of launch_igemm: algo 1 = generic implicit GEMM (bm x bn tile, LDS-DMA depth `stages`),
-// algo 2 = LDS-resident halo kernel for 3x3 convolutions (bm = 256 / 128); splitk >= 1.
-struct Cfg { int algo = 0, bm = 0, bn = 0, splitk = 0, stages = 0; };
-
-// A conv / GEMM launch whose configuration is chosen by measurement on the device (k22_unet_forward, first call).
-struct Tuned {
-  IgemmParams p = {};          // problem; device pointers are filled in at launch time
-  std::vector<Cfg> cands;
-  Cfg cfg;                     // current choice (heuristic until tuned)
-  bool want_stats = false;     // epilogue also emits the GroupNorm partial sums of its output
-  int rpi = 0;                 // stats rows per image under cfg
-  float best_us = 0.f;
-  Slot* aux0 = nullptr; Slot* aux1 = nullptr;  // IG_OUT_QKV: this block's K_all / V^T_all
-  std::function<int(hipStream_t)> run;
-};
 
 struct Act {  // unpadded NHWC activation, optionally a virtual channel concat of two tensors
   Slot* s0 = nullptr; int C0 = 0;
@@ -168,80 +153,12 @@ struct K22UNet {
     }, OP_GN, 0.0, gn_bytes, fused ? 2 : 3));
   }
 
-  // ---- tile-configuration candidates of one conv / GEMM problem ----------------------------------
-  static void apply_cfg(IgemmParams& q, const Cfg& c) {
-    q.algo = c.algo; q.force_bm = c.bm; q.force_bn = c.bn; q.splitk = c.splitk; q.stages = c.stages;
-  }
-  void make_candidates(Tuned& t) {
-    const IgemmParams& p = t.p;
-    const int BK = dtype == K22_BF16 ? 64 : 32;
-    const int nkt = p.taps * (p.Kc / BK);
-    std::vector<Cfg> all;
-    if (p.taps == 9) {
-      const int nslab = p.Kc / BK;
-      for (int bm : {256, 128}) {
-        if (!conv3_halo_supported(p, dtype, bm) || p.N < 128) continue;
-        const int nb = B * conv3_halo_tiles_per_image(p, bm) * ((p.N + 127) / 128);
-        for (int sk : {1, 2, 3, 4, 5, 6, 8, 10, 12}) {
-          if (sk > nslab || (sk > 1 && nb * sk > 800) || (sk > 1 && nb >= 256)) continue;
-          Cfg c; c.algo = 2; c.bm = bm; c.bn = 0; c.splitk = sk; c.stages = 0;
-          all.push_back(c);
-        }
-      }
-    }
-    const int tiles[3][2] = {{128, 128}, {128, 64}, {64, 64}};
-    for (auto& tl : tiles) {
-      if (p.S0 != nullptr) break;  // a fused skip connection rides on the halo kernel only
-      if (tl[1] == 128 && p.N <= 64) continue;
-      if (tl[0] == 128 && p.M <= 64) continue;
-      const int nb = ((p.M + tl[0] - 1) / tl[0]) * ((p.N + tl[1] - 1) / tl[1]);
-      for (int sk : {1, 2, 4, 8, 16}) {
-        if (sk > 1 && (nkt / sk < 4 || nb * sk > 1536 || nb >= 384 || p.out_mode == IG_OUT_QKV)) continue;
-        Cfg c; c.algo = 1; c.bm = tl[0]; c.bn = tl[1]; c.splitk = sk; c.stages = 2;
-        all.push_back(c);
-      }
-    }
-    // keep what can deliver the requested side output and whose split-K scratch stays reasonable
-    t.cands.clear();
-    for (auto& c : all) {
-      IgemmParams q = p;
-      apply_cfg(q, c);
-      if ((size_t)c.splitk * p.M * p.N * sizeof(float) > ((size_t)96 << 20) && c.splitk > 1) continue;
-      if (t.want_stats && igemm_stats_rows_per_image(q, dtype) <= 0) continue;
-      t.cands.push_back(c);
-    }
-  }
-  // heuristic starting point (also the final choice when auto-tuning is off)
-  void default_cfg(Tuned& t) {
-    IgemmParams q = t.p;
-    q.algo = 0; q.force_bm = 0; q.force_bn = 0; q.splitk = 0; q.stages = 0;
-    Cfg c; c.algo = 0; c.bm = 0; c.bn = 0; c.splitk = igemm_choose_splitk(q, dtype); c.stages = 0;
-    if (q.out_mode == IG_OUT_QKV) c.splitk = 1;
-    apply_cfg(q, c);
-    if (t.want_stats && igemm_stats_rows_per_image(q, dtype) <= 0) {
-      if (t.cands.empty()) { t.want_stats = false; }
-      else c = t.cands[0];
-    }
-    t.cfg = c;
-    finish_cfg(t);
-  }
-  void finish_cfg(Tuned& t) {
-    IgemmParams q = t.p;
-    apply_cfg(q, t.cfg);
-    t.rpi = t.want_stats ? igemm_stats_rows_per_image(q, dtype) : 0;
-  }
-  size_t max_splitk_bytes(const Tuned& t) const {
-    size_t m = 0;
-    auto upd = [&](const Cfg& c) { if (c.splitk > 1) m = std::max(m, (size_t)c.splitk * t.p.M * t.p.N * sizeof(float)); };
-    upd(t.cfg);
-    if (autotune) for (auto& c : t.cands) upd(c);
-    return m;
-  }
-  int max_rpi(const Tuned& t) const {
-    int m = t.rpi;
-    if (autotune) for (auto& c : t.cands) { IgemmParams q = t.p; apply_cfg(q, c); m = std::max(m, igemm_stats_rows_per_image(q, dtype)); }
-    return m;
-  }
+  static void apply_cfg(IgemmParams& q, const Cfg& c) { tuned_apply_cfg(q, c); }
+  void make_candidates(Tuned& t) { tuned_make_candidates(t, dtype); }
+  void default_cfg(Tuned& t) { tuned_default_cfg(t, dtype); }
+  void finish_cfg(Tuned& t) { tuned_finish_cfg(t, dtype); }
+  size_t max_splitk_bytes(const Tuned& t) const { return tuned_max_splitk_bytes(t, autotune != 0); }
+  int max_rpi(const Tuned& t) const { return tuned_max_rpi(t, dtype, autotune != 0); }
 
   // conv3x3 over a zero-bordered slot `src` [B][Hc+2][Wc+2][Cin].  `stats` (optional) receives the GroupNorm
   // partial sums of the output; returns the launch descriptor (null when the output is not a tunable T tensor).
@@ -308,91 +225,14 @@ struct K22UNet {
       apply_cfg(q, t->cfg);
       q.A0 = ptr(a.s0); q.A1 = a.s1 ? ptr(a.s1) : nullptr;
       q.residual = rs ? ptr(rs) : nullptr; q.out = ptr(dst); q.partial = ptr<float>(s_splitk);
-      if (t->aux0) { q.kall = ptr(t->aux0); q.vtall = ptr(t->aux1); }
+      if (t->aux0) { q.kall = ptr(reinterpret_cast<Slot*>(t->aux0)); q.vtall = ptr(reinterpret_cast<Slot*>(t->aux1)); }
       return launch_igemm(q, dt, st);
     };
     L.push_back(Op([=](hipStream_t st) { return t->run(st); }, OP_GEMM, 2.0 * p.M * (double)p.N * p.Kc, 0.0, 1));
     return t;
   }
 
-  // Measures every candidate of every distinct problem on the device (weights evicted from the Infinity Cache
-  // between runs: in a real step they stream from HBM) and keeps the fastest.  Outputs written meanwhile are
-  // garbage; the caller runs the real forward afterwards.
-  int tune_all(hipStream_t st) {
-    typedef std::tuple<int, int, int, int, int, int, int, int, bool, bool> Key;
-    std::map<Key, std::pair<Cfg, float>> cache;
-    // optional persistent cache (env K22_TUNE_CACHE=<file>): one line per problem, reused by later processes
-    const char* cache_path = getenv("K22_TUNE_CACHE");
-    size_t loaded = 0;
-    if (cache_path) {
-      if (FILE* f = fopen(cache_path, "r")) {
-        int dtp, taps, M, N, Kc, K0, H, W, om, ws, algo, bm, bn, sk, stg; float us;
-        while (fscanf(f, "%d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %f", &dtp, &taps, &M, &N, &Kc, &K0, &H, &W, &om, &ws,
-                      &algo, &bm, &bn, &sk, &stg, &us) == 16) {
-          if (dtp != dtype) continue;
-          Cfg c; c.algo = algo; c.bm = bm; c.bn = bn; c.splitk = sk; c.stages = stg;
-          cache[Key(taps, M, N, Kc, K0, H, W, om, ws != 0, false)] = std::make_pair(c, us * 1e-3f);
-        }
-        fclose(f);
-        loaded = cache.size();
-      }
-    }
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return k22_set_error(K22_EHIP, "tune: hipEventCreate");
-    int rc = K22_OK;
-    for (auto& t : tuned) {
-      if (!t.run || t.cands.size() < 2) continue;
-      const IgemmParams& p = t.p;
-      if (p.M < 64) continue;  // conditioning-head GEMMs: not worth it
-      const Key key(p.taps, p.M, p.N, p.Kc, p.K0, p.H, p.W, p.out_mode, t.want_stats, false);
-      auto it = cache.find(key);
-      if (it == cache.end()) {
-        Cfg best = t.cfg; float best_ms = 1e30f;
-        for (auto& c : t.cands) {
-          t.cfg = c;
-          finish_cfg(t);
-          float tmin = 1e30f;
-          for (int rep = 0; rep < 3 && rc == K22_OK; ++rep) {
-            if (s_flush->bytes) (void)hipMemsetAsync(ptr(s_flush), 0, s_flush->bytes, st);
-            (void)hipEventRecord(e0, st);
-            rc = t.run(st);
-            (void)hipEventRecord(e1, st);
-            if (hipStreamSynchronize(st) != hipSuccess) rc = k22_set_error(K22_EHIP, "tune: kernel failed");
-            float ms = 0.f;
-            (void)hipEventElapsedTime(&ms, e0, e1);
-            if (rep > 0 && ms < tmin) tmin = ms;  // rep 0 = warm-up (code load, function attributes)
-          }
-          if (rc) break;
-          if (tmin < best_ms) { best_ms = tmin; best = c; }
-        }
-        if (rc) break;
-        it = cache.emplace(key, std::make_pair(best, best_ms)).first;
-      }
-      {
-        // a cached line from an older build may name a configuration this build would not generate: check it
-        const Cfg& c = it->second.first;
-        bool ok = false;
-        for (auto& k : t.cands) ok = ok || (k.algo == c.algo && k.bm == c.bm && k.bn == c.bn && k.splitk == c.splitk);
-        if (ok) { t.cfg = c; t.best_us = it->second.second * 1e3f; }
-      }
-      finish_cfg(t);
-    }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if (rc == K22_OK && cache_path && cache.size() > loaded) {
-      if (FILE* f = fopen(cache_path, "a")) {
-        size_t i = 0;
-        for (auto& kv : cache) {
-          (void)i;
-          const Key& k = kv.first; const Cfg& c = kv.second.first;
-          fprintf(f, "%d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %.2f\n", dtype, std::get<0>(k), std::get<1>(k), std::get<2>(k),
-                  std::get<3>(k), std::get<4>(k), std::get<5>(k), std::get<6>(k), std::get<7>(k), std::get<8>(k) ? 1 : 0,
-                  c.algo, c.bm, c.bn, c.splitk, c.stages, kv.second.second * 1e3f);
-        }
-        fclose(f);
-      }
-    }
-    return rc;
-  }
+  int tune_all(hipStream_t st) { return tune_igemm_ops(tuned, dtype, s_flush->bytes ? ptr(s_flush) : nullptr, s_flush->bytes, st); }
 
   // ResBlock (unet.py:110-220) with use_scale_shift_norm=True; updown: 0 none, 1 down, 2 up.
   Act resblock(const std::string& pfx, const Act& in, int Cout, int updown, int64_t& film_cursor, Slot* dst, Slot* dst_stats) {
@@ -476,7 +316,7 @@ struct K22UNet {
     }
     need(s_ATT, (size_t)B * T * C * esz);
     ops.push_back(Op([=](hipStream_t st) {
-      AttentionParams ap;
+      AttentionParams ap = {};
       ap.q = ptr(s_QKV); ap.ldq = C; ap.kall = ptr(kall); ap.vtall = ptr(vtall); ap.out = ptr(s_ATT); ap.ldo = C;
       ap.B = Bn; ap.H = Hh; ap.T = T; ap.Tk = Tk; ap.Tkp = Tkp; ap.scale = 0.125f;
       return launch_attention(ap, dt, st);
@@ -837,18 +677,7 @@ int k22_unet_set_autotune(K22UNet* u, int on) {
 // Text table of the chosen tile configurations (one line per distinct conv / GEMM problem of the plan).
 int k22_unet_tuning_report(const K22UNet* u, char* buf, size_t cap) {
   if (!u || !buf || cap == 0) return k22_set_error(K22_EINVAL, "unet_tuning_report: null argument");
-  std::string out = "taps      M     N     K    H    W stats | algo  bm  bn splitk |  time_us  count\n";
-  std::map<std::string, int> seen;
-  std::vector<std::string> order;
-  for (auto& t : u->tuned) {
-    char line[256];
-    snprintf(line, sizeof line, "%4d %6d %5d %5d %4d %4d %5d | %4s %3d %3d %6d | %8.1f", t.p.taps, t.p.M, t.p.N, t.p.Kc,
-             t.p.H, t.p.W, t.want_stats ? 1 : 0, t.cfg.algo == 2 ? "halo" : (t.cfg.algo == 1 ? "gen" : "auto"), t.cfg.bm, t.cfg.bn,
-             t.cfg.splitk, t.best_us);
-    if (!seen.count(line)) order.push_back(line);
-    seen[line]++;
-  }
-  for (auto& l : order) { out += l; out += "  x" + std::to_string(seen[l]) + "\n"; }
+  const std::string out = tuning_report_text(u->tuned);
   snprintf(buf, cap, "%s", out.c_str());
   return K22_OK;
 }

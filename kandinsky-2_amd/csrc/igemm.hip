@@ -420,7 +420,7 @@ static int g_xcd_remap = 1;
 static int g_conv_algo = 0;
 void igemm_set_default_stages(int v) { g_stages_override = (v >= 2 && v <= 4) ? v : -1; }
 void igemm_set_xcd_remap(int v) { g_xcd_remap = v ? 1 : 0; }
-void igemm_set_conv_algo(int v) { g_conv_algo = (v >= 0 && v <= 2) ? v : 0; }
+void igemm_set_conv_algo(int v) { g_conv_algo = (v >= 0 && v <= 3) ? v : 0; }
 
 static int g_default_stages() {
   static int v = -1;
@@ -440,26 +440,28 @@ static IgemmPlan igemm_plan(const IgemmParams& p, int dtype) {
   pl.halo = 0;
   pl.stages = (p.stages >= 2 && p.stages <= 4) ? p.stages : g_default_stages();
   auto blocks = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
-  // ---- 3x3 convolution: LDS-resident halo kernel when it applies --------------------------------
+  // ---- 3x3 convolution: LDS-resident halo kernels when they apply (algo 2 = 128-byte rows, 3 = 64-byte rows) -----
   const int algo = p.algo ? p.algo : g_conv_algo;
   if (p.taps == 9 && algo != 1 && p.N >= 128) {
+    IgemmParams ph = p;
+    ph.algo = (algo == 3) ? 3 : 2;
     int bm = 0;
     if (p.force_bm == 256 || p.force_bm == 128) {
-      if (conv3_halo_supported(p, dtype, p.force_bm) && (algo == 2 || p.force_bn == 0)) bm = p.force_bm;
+      if (conv3_halo_supported(ph, dtype, p.force_bm) && (algo >= 2 || p.force_bn == 0)) bm = p.force_bm;
     } else if (p.force_bm == 0) {
-      if (conv3_halo_supported(p, dtype, 256)) bm = 256;
-      else if (conv3_halo_supported(p, dtype, 128)) bm = 128;
+      if (conv3_halo_supported(ph, dtype, 256)) bm = 256;
+      else if (conv3_halo_supported(ph, dtype, 128)) bm = 128;
     }
     if (bm) {
-      const int nslab = p.Kc / BK;
-      pl.halo = 1; pl.bm = bm; pl.bn = 128;
+      const int nslab = (p.Kc / BK) * (ph.algo == 3 ? 2 : 1);   // split-K granularity: slabs / half slabs
+      pl.halo = ph.algo; pl.bm = bm; pl.bn = 128;
       if (p.splitk > 0) {
         pl.splitk = p.splitk;
       } else {
         const int B = p.M / (p.H * p.W);
         const int nb = B * conv3_halo_tiles_per_image(p, bm) * ((p.N + 127) / 128);
         int sk = 1;
-        while (nb * sk < 200 && sk < 16 && nslab / (sk * 2) >= 2) sk *= 2;
+        while (nb * sk < 200 && sk < 16 && (p.Kc / BK) / (sk * 2) >= 2) sk *= 2;
         pl.splitk = sk;
       }
       if (pl.splitk > nslab) pl.splitk = nslab;
@@ -585,6 +587,7 @@ int launch_igemm(const IgemmParams& p, int dtype, hipStream_t stream) {
     IgemmParams q = p;
     q.splitk = pl.splitk;
     q.xcd_remap = g_xcd_remap;
+    q.algo = pl.halo;
     int rc = launch_conv3_halo(q, dtype, pl.bm, pl.splitk, stream);
     if (rc || pl.splitk == 1) return rc;
     return dtype == K22_BF16 ? launch_reduce<bf16_t>(q, stream) : launch_reduce<float>(q, stream);

@@ -51,6 +51,7 @@ struct IgemmParams {
   int SK0, SK1;
   void* kall; void* vtall;                 // IG_OUT_QKV only
   int att_T, att_S, att_Tkp;               // IG_OUT_QKV only: tokens per image, context keys, padded key count
+  unsigned long long* trace;  // developer tool (k22_debug_conv_trace): per-tap s_memtime stamps of two waves of block 0
   int res_f32;           // residual is fp32 (generic kernel / split-K finish only)
   float* stats;          // optional GroupNorm side output: per-row-block, per-channel (sum, sumsq) of the STORED
                          // values, [stats_rows][N][2] fp32 (see IgemmStatsInfo); null = not wanted
@@ -67,6 +68,7 @@ int launch_igemm(const IgemmParams& p, int dtype, hipStream_t stream);
 bool conv3_halo_supported(const IgemmParams& p, int dtype, int bm);
 int conv3_halo_tiles_per_image(const IgemmParams& p, int bm);
 int launch_conv3_halo(const IgemmParams& p, int dtype, int bm, int splitk, hipStream_t stream);
+int launch_conv3_halo_trace(const IgemmParams& p, int dtype, hipStream_t stream);
 void igemm_set_conv_algo(int v);       // tuning knob: 0 auto, 1 generic, 2 halo
 void igemm_set_default_stages(int v);  // tuning knob: 2..4 LDS-DMA stages, -1 env/default
 void igemm_set_xcd_remap(int v);       // tuning knob: XCD-aware block renumbering (default on)

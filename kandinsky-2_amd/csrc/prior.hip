@@ -13,6 +13,7 @@
 #include "kernels.h"
 #include "elementwise.h"
 #include "../../include/k22.h"
+#include "tuning.h"
 
 #include <deque>
 #include <functional>
@@ -53,56 +54,6 @@ __global__ void prior_finish_input_kernel(float* inp, const float* pos, const fl
   }
 }
 
-// additive attention mask (prior.py:262-263): mask[b][t][s] = (key s valid ? 0 : -inf) + (s > t ? -inf : 0);
-// key_valid [B][n_text] (1 = token, 0 = padding); the 4 extra positions are always valid (F.pad(..., value=True)).
-__global__ void prior_mask_kernel(const float* key_valid, float* mask, int B, int n_text, int n_ctx) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * n_ctx * n_ctx) return;
-  const int s = i % n_ctx, t = (i / n_ctx) % n_ctx, b = i / (n_ctx * n_ctx);
-  const bool valid = s >= n_text || key_valid[(int64_t)b * n_text + s] != 0.f;
-  mask[i] = (valid && s <= t) ? 0.f : -INFINITY;
-}
-
-// ---- attention, one workgroup per (head, batch): n_ctx <= 128 tokens, 64 channels per head ----------------------
-// qkv rows [B*n_ctx][3*W] as planes Q | K | V x [heads][64]; out rows [B*n_ctx][W].  fp32 math
-// (softmax in fp32 like the reference, prior.py:96-101); scale = 64^-1/4 on q and on k = 1/8 on the product.
-template <typename T>
-__global__ __launch_bounds__(256) void prior_attention_kernel(const T* qkv, const float* mask, T* out, int n_ctx, int W) {
-  __shared__ float Ks[96][65];   // +1 column: the score loop reads one row per lane
-  __shared__ float Vs[96][65];
-  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t ld = 3 * (int64_t)W;
-  const T* base = qkv + (int64_t)b * n_ctx * ld + h * 64;
-  for (int i = tid; i < n_ctx * 64; i += 256) {
-    const int s = i >> 6, d = i & 63;
-    Ks[s][d] = to_f32(base[(int64_t)s * ld + W + d]);
-    Vs[s][d] = to_f32(base[(int64_t)s * ld + 2 * W + d]);
-  }
-  __syncthreads();
-  for (int t = wave; t < n_ctx; t += 4) {
-    const float qv = to_f32(base[(int64_t)t * ld + lane]);  // lane d holds q[d]; broadcast by readlane below
-    // scores for keys lane and lane + 64
-    float sc[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int s = lane + 64 * u;
-      const int sr = s < n_ctx ? s : 0;
-      float a = 0.f;
-#pragma unroll 16
-      for (int d = 0; d < 64; ++d) a += __shfl(qv, d, 64) * Ks[sr][d];
-      sc[u] = s < n_ctx ? a * 0.125f + mask[((int64_t)b * n_ctx + t) * n_ctx + s] : -INFINITY;
-    }
-    const float m = wave_max(fmaxf(sc[0], sc[1]));
-    const float e0 = expf(sc[0] - m), e1 = expf(sc[1] - m);
-    const float inv = 1.f / wave_sum(e0 + e1);
-    const float p0 = e0 * inv, p1 = e1 * inv;
-    // out[d = lane] = sum_s P[s] V[s][d]
-    float o = 0.f;
-    for (int s = 0; s < n_ctx; ++s) o += (s < 64 ? __shfl(p0, s, 64) : __shfl(p1, s - 64, 64)) * Vs[s][lane];
-    out[((int64_t)b * n_ctx + t) * W + h * 64 + lane] = from_f32<T>(o);
-  }
-}
-
 // ---- one ancestral step of the prior (START_X mean, FIXED_SMALL variance) with classifier-free guidance -------------
 // x, model_out, noise, x_out: [2*bs][D] with halves [cond | uncond]; scales [bs]; tab = (coef1, coef2, log_var, nonzero)
 __global__ void prior_sampler_step_kernel(const float* x, const float* model_out, const float* noise, const float* scales,
@@ -129,11 +80,20 @@ struct K22Prior {
   int B = 0;
   std::deque<PSlot> slots;
   std::vector<POp> ops;
+  std::deque<Tuned> tuned;   // every transformer Linear: tile configuration picked by measurement at the first forward
+  bool tuned_done = false;
+  int autotune = 1;
+  hipGraphExec_t graph_exec = nullptr;   // the ~250 launches of one forward, replayed as one graph
+  hipStream_t cap_stream = nullptr;
+  ~K22Prior() {
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    if (cap_stream) (void)hipStreamDestroy(cap_stream);
+  }
   size_t ws_bytes = 0;
   char* ws = nullptr;
   std::string err;
   PSlot *s_x, *s_t, *s_temb, *s_te1, *s_txtemb, *s_txtenc, *s_txtencT, *s_valid, *s_mask, *s_inp, *s_ln, *s_qkv, *s_att, *s_fc,
-      *s_lnlast, *s_out, *s_splitk;
+      *s_lnlast, *s_out, *s_splitk, *s_flush, *s_kall, *s_vtall;
 
   PSlot* new_slot(size_t bytes = 0) { slots.emplace_back(); slots.back().bytes = bytes; return &slots.back(); }
   static void need(PSlot* s, size_t bytes) { if (bytes > s->bytes) s->bytes = bytes; }
@@ -148,20 +108,25 @@ struct K22Prior {
   // out (+)= A[M][K] . W[N][K]^T + bias; A is T; out T, or fp32 with an fp32 residual (in-place residual stream)
   void op_linear(PSlot* a, size_t a_off, int M, int N, int K, const std::string& pfx, int act, PSlot* dst, size_t dst_off, int ldo,
                  bool f32_out_residual) {
-    IgemmParams p = {};
+    tuned.emplace_back();
+    Tuned* t = &tuned.back();
+    IgemmParams& p = t->p;
     p.stages = -1;
     p.M = M; p.N = N; p.Npad = (N + 63) / 64 * 64; p.Kc = K; p.K0 = K; p.taps = 1; p.lda0 = K; p.ldo = ldo; p.ldr = ldo;
     p.out_mode = f32_out_residual ? IG_OUT_ROWMAJOR_F32 : IG_OUT_ROWMAJOR; p.act = act; p.res_f32 = f32_out_residual ? 1 : 0;
     p.Wp = W_(pfx + ".weight"); p.bias = Wf(pfx + ".bias");
-    p.splitk = igemm_choose_splitk(p, dtype);
-    if (p.splitk > 1) need(s_splitk, (size_t)p.splitk * M * N * sizeof(float));
+    tuned_make_candidates(*t, dtype);
+    tuned_default_cfg(*t, dtype);
+    need(s_splitk, tuned_max_splitk_bytes(*t, autotune != 0));
     const int dt = dtype;
-    ops.push_back([=](hipStream_t st) {
-      IgemmParams q = p;
+    t->run = [=](hipStream_t st) {
+      IgemmParams q = t->p;
+      tuned_apply_cfg(q, t->cfg);
       q.A0 = ptr(a) + a_off; q.out = ptr(dst) + dst_off; q.partial = ptr<float>(s_splitk);
       q.residual = f32_out_residual ? (ptr(dst) + dst_off) : nullptr;
       return launch_igemm(q, dt, st);
-    });
+    };
+    ops.push_back([=](hipStream_t st) { return t->run(st); });
   }
   void op_ln(PSlot* x, size_t x_off, int64_t ldx, int rows, const std::string& pfx, PSlot* y, bool to_f32) {
     const float* g = Wf(pfx + ".weight"); const float* b = Wf(pfx + ".bias");
@@ -178,10 +143,11 @@ struct K22Prior {
 
   int plan(int nB) {
     B = nB;
-    slots.clear(); ops.clear(); err.clear(); ws = nullptr;
+    slots.clear(); ops.clear(); err.clear(); ws = nullptr; tuned.clear(); tuned_done = false;
+    if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
     const int D = cfg.xf_width, nt = cfg.text_ctx, nc = nt + 4, cd = cfg.clip_dim, cw = cfg.clip_xf_width, M = B * nc;
     if (B < 1 || B > 8) return k22_set_error(K22_EINVAL, "prior: batch (2*bs) must be in 1..8 per engine call");
-    if (nc > 96 || D % 64 || D / cfg.xf_heads != 64) return k22_set_error(K22_EINVAL, "prior: text_ctx + 4 <= 96, 64 channels per head");
+    if (D % 64 || D / cfg.xf_heads != 64) return k22_set_error(K22_EINVAL, "prior: 64 channels per head");
     s_x = new_slot((size_t)B * cd * 4); s_t = new_slot((size_t)B * 4 + 64);
     s_temb = new_slot((size_t)B * D * 4); s_te1 = new_slot((size_t)B * D * 4);
     s_txtemb = new_slot((size_t)B * cd * 4); s_txtenc = new_slot((size_t)B * nt * cw * 4); s_txtencT = new_slot((size_t)B * nt * cw * esz);
@@ -189,6 +155,8 @@ struct K22Prior {
     s_inp = new_slot((size_t)M * D * 4); s_ln = new_slot((size_t)M * D * esz); s_qkv = new_slot((size_t)M * 3 * D * esz);
     s_att = new_slot((size_t)M * D * esz); s_fc = new_slot((size_t)M * 4 * D * esz);
     s_lnlast = new_slot((size_t)B * D * 4); s_out = new_slot((size_t)B * cd * 4); s_splitk = new_slot(256);
+    s_flush = new_slot(autotune ? ((size_t)320 << 20) : 0);
+    s_kall = new_slot(); s_vtall = new_slot();
     const int Bn = B, dt = dtype;
     const size_t es = esz;
 
@@ -236,8 +204,6 @@ struct K22Prior {
       ops.push_back([=](hipStream_t st) {
         hipLaunchKernelGGL(prior_finish_input_kernel, dim3(256), dim3(256), 0, st, ptr<float>(s_inp), pos, prd, Bn, nc, D);
         K22_CHECK_LAUNCH();
-        hipLaunchKernelGGL(prior_mask_kernel, dim3((Bn * nc * nc + 255) / 256), dim3(256), 0, st, ptr<float>(s_valid), ptr<float>(s_mask), Bn, nt, nc);
-        K22_CHECK_LAUNCH();
         return K22_OK;
       });
     }
@@ -246,13 +212,22 @@ struct K22Prior {
       const std::string pfx = "transformer.resblocks." + std::to_string(l);
       op_ln(s_inp, 0, D, M, pfx + ".ln_1", s_ln, false);
       op_linear(s_ln, 0, M, 3 * D, D, pfx + ".attn.c_qkv", K22_ACT_NONE, s_qkv, 0, 3 * D, false);
-      const int heads = cfg.xf_heads;
+      // attention: the UNet's flash kernel (attention.hip) with the prior's mask (prior.py:262-263) — the additive
+      // mask is -inf exactly for padding keys and for keys after the query, the 4 extra positions are always valid
+      const int heads = cfg.xf_heads, Tkp = (nc + 63) / 64 * 64;
+      need(s_kall, (size_t)B * heads * Tkp * 64 * esz);
+      need(s_vtall, (size_t)B * heads * Tkp * 64 * esz);
       ops.push_back([=](hipStream_t st) {
-        dim3 grid(heads, Bn);
-        if (dt == K22_BF16) hipLaunchKernelGGL(prior_attention_kernel<bf16_t>, grid, dim3(256), 0, st, ptr<bf16_t>(s_qkv), ptr<float>(s_mask), ptr<bf16_t>(s_att), nc, D);
-        else hipLaunchKernelGGL(prior_attention_kernel<float>, grid, dim3(256), 0, st, ptr<float>(s_qkv), ptr<float>(s_mask), ptr<float>(s_att), nc, D);
-        K22_CHECK_LAUNCH();
-        return K22_OK;
+        KvPackParams kp;
+        kp.qkv = ptr(s_qkv); kp.ctxkv = nullptr; kp.kall = ptr(s_kall); kp.vtall = ptr(s_vtall);
+        kp.B = Bn; kp.H = heads; kp.T = nc; kp.S = 0; kp.Tkp = Tkp;
+        int rc = launch_kv_pack(kp, dt, st);
+        if (rc) return rc;
+        AttentionParams ap = {};
+        ap.q = ptr(s_qkv); ap.ldq = 3 * D; ap.kall = ptr(s_kall); ap.vtall = ptr(s_vtall); ap.out = ptr(s_att); ap.ldo = D;
+        ap.B = Bn; ap.H = heads; ap.T = nc; ap.Tk = nc; ap.Tkp = Tkp; ap.scale = 0.125f;
+        ap.causal = 1; ap.key_valid = ptr<float>(s_valid); ap.kv_ld = nt; ap.kv_n = nt;
+        return launch_attention(ap, dt, st);
       });
       op_linear(s_att, 0, M, D, D, pfx + ".attn.c_proj", K22_ACT_NONE, s_inp, 0, D, true);
       op_ln(s_inp, 0, D, M, pfx + ".ln_2", s_ln, false);
@@ -294,7 +269,16 @@ int k22_prior_create(const K22PriorConfig* cfg, const K22Weight* weights, int n_
   K22Prior* m = new K22Prior();
   m->cfg = *cfg; m->dtype = cfg->dtype; m->esz = cfg->dtype == K22_BF16 ? 2 : 4;
   for (int i = 0; i < n_weights; ++i) m->w[weights[i].name] = weights[i].ptr;
+  {
+    const char* e = getenv("K22_AUTOTUNE");
+    m->autotune = e ? (atoi(e) != 0) : 1;
+  }
   *out = m;
+  return K22_OK;
+}
+int k22_prior_tuning_report(const K22Prior* m, char* buf, size_t cap) {
+  if (!m || !buf || cap == 0) return k22_set_error(K22_EINVAL, "prior_tuning_report: null argument");
+  snprintf(buf, cap, "%s", tuning_report_text(m->tuned).c_str());
   return K22_OK;
 }
 void k22_prior_destroy(K22Prior* m) { delete m; }
@@ -312,6 +296,7 @@ int k22_prior_bind(K22Prior* m, void* workspace, size_t workspace_bytes) {
   if (workspace_bytes < m->ws_bytes) return k22_set_error(K22_ENOMEM, "prior_bind: workspace too small");
   if ((uintptr_t)workspace % 256) return k22_set_error(K22_EINVAL, "prior_bind: workspace must be 256-byte aligned");
   m->ws = reinterpret_cast<char*>(workspace);
+  if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
   return K22_OK;
 }
 int k22_prior_forward(K22Prior* m, const float* x, const float* timesteps, const float* text_emb, const float* text_enc,
@@ -329,7 +314,34 @@ int k22_prior_forward(K22Prior* m, const float* x, const float* timesteps, const
   K22_CPY(m->ptr(m->s_txtemb), text_emb, (size_t)m->B * c.clip_dim * 4);
   K22_CPY(m->ptr(m->s_txtenc), text_enc, (size_t)m->B * c.text_ctx * c.clip_xf_width * 4);
   K22_CPY(m->ptr(m->s_valid), key_valid, (size_t)m->B * c.text_ctx * 4);
-  for (auto& op : m->ops) { int rc = op(st); if (rc) return rc; }
+  if (m->autotune && !m->tuned_done) {
+    // the in-place residual GEMMs make the tuning runs accumulate garbage into the sequence buffer: harmless, the
+    // real forward below rebuilds it from the inputs
+    int rc = tune_igemm_ops(m->tuned, m->dtype, m->s_flush->bytes ? m->ptr(m->s_flush) : nullptr, m->s_flush->bytes, st);
+    if (rc) return rc;
+    m->tuned_done = true;
+  }
+  if (!m->graph_exec) {
+    // first forward: run eagerly once (function attributes, code load), then capture the launch list
+    for (auto& op : m->ops) { int rc = op(st); if (rc) return rc; }
+    if (!m->cap_stream) {
+      e = hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking);
+      if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+    }
+    hipGraph_t g = nullptr;
+    e = hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+    int rc = K22_OK;
+    for (auto& op : m->ops) { rc = op(m->cap_stream); if (rc) break; }
+    e = hipStreamEndCapture(m->cap_stream, &g);
+    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+    e = hipGraphInstantiate(&m->graph_exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) { m->graph_exec = nullptr; return k22_set_error_hip(e, __FILE__, __LINE__); }
+  }
+  e = hipGraphLaunch(m->graph_exec, st);
+  if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
   K22_CPY(out, m->ptr(m->s_out), (size_t)m->B * c.clip_dim * 4);
 #undef K22_CPY
   return K22_OK;

@@ -1,0 +1,215 @@
+// k22 — on-device selection of conv / GEMM tile configurations, shared by the UNet, MoVQ and prior engines.
+//
+// A Tuned describes one launch_igemm problem plus the list of configurations worth trying; tune_igemm_ops() times
+// every candidate of every DISTINCT problem on the device (with the Infinity Cache flushed between runs: in a real
+// step the weights stream from HBM) and keeps the fastest.  Optional persistent cache: env K22_TUNE_CACHE=<file>.
+#pragma once
+#include "kernels.h"
+
+#include <deque>
+#include <functional>
+#include <map>
+#include <tuple>
+#include <vector>
+#include <stdio.h>
+#include <stdlib.h>
+
+// One tile configuration of launch_igemm: algo 1 = generic implicit GEMM (bm x bn tile, LDS-DMA depth `stages`),
+// algo 2 = LDS-resident halo kernel for 3x3 convolutions (bm = 256 / 128); splitk >= 1.
+struct Cfg { int algo = 0, bm = 0, bn = 0, splitk = 0, stages = 0; };
+
+struct TunedSlot;  // engine-specific workspace slot (opaque here)
+
+// A conv / GEMM launch whose configuration is chosen by measurement on the device (first forward of a plan).
+struct Tuned {
+  IgemmParams p = {};          // problem; device pointers are filled in at launch time
+  std::vector<Cfg> cands;
+  Cfg cfg;                     // current choice (heuristic until tuned)
+  bool want_stats = false;     // epilogue also emits the GroupNorm partial sums of its output
+  int rpi = 0;                 // stats rows per image under cfg
+  float best_us = 0.f;
+  void* aux0 = nullptr; void* aux1 = nullptr;  // engine-specific (IG_OUT_QKV: this block's K_all / V^T_all slots)
+  std::function<int(hipStream_t)> run;
+};
+
+inline void tuned_apply_cfg(IgemmParams& q, const Cfg& c) {
+  q.algo = c.algo; q.force_bm = c.bm; q.force_bn = c.bn; q.splitk = c.splitk; q.stages = c.stages;
+}
+
+inline void tuned_make_candidates(Tuned& t, int dtype) {
+  const IgemmParams& p = t.p;
+  const int BK = dtype == K22_BF16 ? 64 : 32;
+  const int nkt = p.taps * (p.Kc / BK);
+  std::vector<Cfg> all;
+  if (p.taps == 9) {
+    const int B = p.M / (p.H * p.W);
+    for (int algo : {2, 3}) {
+      IgemmParams ph = p;
+      ph.algo = algo;
+      const int nsplit_max = (p.Kc / BK) * (algo == 3 ? 2 : 1);
+      for (int bm : {256, 128}) {
+        if (!conv3_halo_supported(ph, dtype, bm) || p.N < 128) continue;
+        const int nb = B * conv3_halo_tiles_per_image(p, bm) * ((p.N + 127) / 128);
+        for (int sk : {1, 2, 3, 4, 5, 6, 8, 10, 12}) {
+          if (sk > nsplit_max || (sk > 1 && nb * sk > 800) || (sk > 1 && nb >= 256)) continue;
+          Cfg c; c.algo = algo; c.bm = bm; c.bn = 0; c.splitk = sk; c.stages = 0;
+          all.push_back(c);
+        }
+      }
+    }
+  }
+  const int tiles[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+  // skinny problems (a few hundred rows against a big weight matrix) are HBM-latency bound: also try deeper rings
+  const bool skinny = p.taps == 1 && p.M <= 512 && (int64_t)p.N * p.Kc >= (1 << 21);
+  for (auto& tl : tiles) {
+    if (p.S0 != nullptr) break;  // a fused skip connection rides on the halo kernel only
+    if (tl[1] == 128 && p.N <= 64) continue;
+    if (tl[0] == 128 && p.M <= 64) continue;
+    const int nb = ((p.M + tl[0] - 1) / tl[0]) * ((p.N + tl[1] - 1) / tl[1]);
+    for (int sk : {1, 2, 4, 8, 16}) {
+      if (sk > 1 && (nkt / sk < 4 || nb * sk > 1536 || nb >= 384 || p.out_mode == IG_OUT_QKV)) continue;
+      for (int stg : {2, 3, 4}) {
+        if (stg > 2 && !skinny) continue;
+        if (stg * (tl[0] + tl[1]) * 128 > 160 * 1024) continue;
+        Cfg c; c.algo = 1; c.bm = tl[0]; c.bn = tl[1]; c.splitk = sk; c.stages = stg;
+        all.push_back(c);
+      }
+    }
+  }
+  // keep what can deliver the requested side output and whose split-K scratch stays reasonable
+  t.cands.clear();
+  for (auto& c : all) {
+    IgemmParams q = p;
+    tuned_apply_cfg(q, c);
+    if ((size_t)c.splitk * p.M * p.N * sizeof(float) > ((size_t)96 << 20) && c.splitk > 1) continue;
+    if (t.want_stats && igemm_stats_rows_per_image(q, dtype) <= 0) continue;
+    t.cands.push_back(c);
+  }
+}
+
+inline void tuned_finish_cfg(Tuned& t, int dtype) {
+  IgemmParams q = t.p;
+  tuned_apply_cfg(q, t.cfg);
+  t.rpi = t.want_stats ? igemm_stats_rows_per_image(q, dtype) : 0;
+}
+
+// heuristic starting point (also the final choice when auto-tuning is off)
+inline void tuned_default_cfg(Tuned& t, int dtype) {
+  IgemmParams q = t.p;
+  q.algo = 0; q.force_bm = 0; q.force_bn = 0; q.splitk = 0; q.stages = 0;
+  Cfg c; c.algo = 0; c.bm = 0; c.bn = 0; c.splitk = igemm_choose_splitk(q, dtype); c.stages = 0;
+  if (q.out_mode == IG_OUT_QKV) c.splitk = 1;
+  tuned_apply_cfg(q, c);
+  if (t.want_stats && igemm_stats_rows_per_image(q, dtype) <= 0) {
+    if (t.cands.empty()) { t.want_stats = false; }
+    else c = t.cands[0];
+  }
+  t.cfg = c;
+  tuned_finish_cfg(t, dtype);
+}
+
+inline size_t tuned_max_splitk_bytes(const Tuned& t, bool autotune) {
+  size_t m = 0;
+  auto upd = [&](const Cfg& c) { if (c.splitk > 1) m = std::max(m, (size_t)c.splitk * t.p.M * t.p.N * sizeof(float)); };
+  upd(t.cfg);
+  if (autotune) for (auto& c : t.cands) upd(c);
+  return m;
+}
+
+inline int tuned_max_rpi(const Tuned& t, int dtype, bool autotune) {
+  int m = t.rpi;
+  if (autotune) for (auto& c : t.cands) { IgemmParams q = t.p; tuned_apply_cfg(q, c); m = std::max(m, igemm_stats_rows_per_image(q, dtype)); }
+  return m;
+}
+
+// Measures every candidate of every distinct problem (outputs written meanwhile are garbage; the caller runs the
+// real forward afterwards).  flush / flush_bytes: a scratch region memset between runs to evict the Infinity Cache.
+inline int tune_igemm_ops(std::deque<Tuned>& tuned, int dtype, void* flush, size_t flush_bytes, hipStream_t st) {
+  typedef std::tuple<int, int, int, int, int, int, int, int, bool, bool> Key;
+  std::map<Key, std::pair<Cfg, float>> cache;
+  // optional persistent cache (env K22_TUNE_CACHE=<file>): one line per problem, reused by later processes
+  const char* cache_path = getenv("K22_TUNE_CACHE");
+  size_t loaded = 0;
+  if (cache_path) {
+    if (FILE* f = fopen(cache_path, "r")) {
+      int dtp, taps, M, N, Kc, K0, H, W, om, ws, algo, bm, bn, sk, stg; float us;
+      while (fscanf(f, "%d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %f", &dtp, &taps, &M, &N, &Kc, &K0, &H, &W, &om, &ws,
+                    &algo, &bm, &bn, &sk, &stg, &us) == 16) {
+        if (dtp != dtype) continue;
+        Cfg c; c.algo = algo; c.bm = bm; c.bn = bn; c.splitk = sk; c.stages = stg;
+        cache[Key(taps, M, N, Kc, K0, H, W, om, ws != 0, false)] = std::make_pair(c, us * 1e-3f);
+      }
+      fclose(f);
+      loaded = cache.size();
+    }
+  }
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return k22_set_error(K22_EHIP, "tune: hipEventCreate");
+  int rc = K22_OK;
+  for (auto& t : tuned) {
+    if (!t.run || t.cands.size() < 2) continue;
+    const IgemmParams& p = t.p;
+    if (p.M < 64) continue;
+    const Key key(p.taps, p.M, p.N, p.Kc, p.K0 + (p.S0 ? 100000 * (p.SK0 + p.SK1) : 0), p.H, p.W, p.out_mode + 16 * p.res_f32 + 32 * p.act, t.want_stats, false);
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+      Cfg best = t.cfg; float best_ms = 1e30f;
+      for (auto& c : t.cands) {
+        t.cfg = c;
+        tuned_finish_cfg(t, dtype);
+        float tmin = 1e30f;
+        for (int rep = 0; rep < 3 && rc == K22_OK; ++rep) {
+          if (flush && flush_bytes) (void)hipMemsetAsync(flush, 0, flush_bytes, st);
+          (void)hipEventRecord(e0, st);
+          rc = t.run(st);
+          (void)hipEventRecord(e1, st);
+          if (hipStreamSynchronize(st) != hipSuccess) rc = k22_set_error(K22_EHIP, "tune: kernel failed");
+          float ms = 0.f;
+          (void)hipEventElapsedTime(&ms, e0, e1);
+          if (rep > 0 && ms < tmin) tmin = ms;  // rep 0 = warm-up (code load, function attributes)
+        }
+        if (rc) break;
+        if (tmin < best_ms) { best_ms = tmin; best = c; }
+      }
+      if (rc) break;
+      it = cache.emplace(key, std::make_pair(best, best_ms)).first;
+    }
+    {
+      // a cached line from an older build may name a configuration this build would not generate: check it
+      const Cfg& c = it->second.first;
+      bool ok = false;
+      for (auto& k : t.cands) ok = ok || (k.algo == c.algo && k.bm == c.bm && k.bn == c.bn && k.splitk == c.splitk && (k.stages == c.stages || c.algo >= 2));
+      if (ok) { t.cfg = c; t.best_us = it->second.second * 1e3f; }
+    }
+    tuned_finish_cfg(t, dtype);
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (rc == K22_OK && cache_path && cache.size() > loaded) {
+    if (FILE* f = fopen(cache_path, "w")) {
+      for (auto& kv : cache) {
+        const Key& k = kv.first; const Cfg& c = kv.second.first;
+        fprintf(f, "%d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %.2f\n", dtype, std::get<0>(k), std::get<1>(k), std::get<2>(k),
+                std::get<3>(k), std::get<4>(k), std::get<5>(k), std::get<6>(k), std::get<7>(k), std::get<8>(k) ? 1 : 0,
+                c.algo, c.bm, c.bn, c.splitk, c.stages, kv.second.second * 1e3f);
+      }
+      fclose(f);
+    }
+  }
+  return rc;
+}
+
+inline std::string tuning_report_text(const std::deque<Tuned>& tuned) {
+  std::string out = "taps      M     N     K    H    W stats | algo  bm  bn splitk stg |  time_us  count\n";
+  std::map<std::string, int> seen;
+  std::vector<std::string> order;
+  for (auto& t : tuned) {
+    char line[256];
+    snprintf(line, sizeof line, "%4d %6d %5d %5d %4d %4d %5d | %4s %3d %3d %6d %3d | %8.1f", t.p.taps, t.p.M, t.p.N, t.p.Kc,
+             t.p.H, t.p.W, t.want_stats ? 1 : 0, t.cfg.algo == 2 ? "halo" : (t.cfg.algo == 3 ? "hal3" : (t.cfg.algo == 1 ? "gen" : "auto")), t.cfg.bm, t.cfg.bn,
+             t.cfg.splitk, t.cfg.stages, t.best_us);
+    if (!seen.count(line)) order.push_back(line);
+    seen[line]++;
+  }
+  for (auto& l : order) { out += l; out += "  x" + std::to_string(seen[l]) + "\n"; }
+  return out;
+}

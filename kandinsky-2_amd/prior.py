@@ -242,6 +242,11 @@ class PriorDiffusionModelHIP(nn.Module):
             _lib.check(_lib.lib().k22_prior_bind(self._handle, al, nbytes.value))
             self._plan_key = B
 
+    def tuning_report(self) -> str:
+        buf = C.create_string_buffer(1 << 14)
+        _lib.check(_lib.lib().k22_prior_tuning_report(self._handle, buf, len(buf)))
+        return buf.value.decode()
+
     @torch.no_grad()
     def transformer(self, x, timesteps, text_emb, text_enc, mask):
         """PriorTransformer.forward (prior.py:226-270); mask [B, text_ctx] bool; the causal mask is built in."""

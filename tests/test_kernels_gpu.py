@@ -77,11 +77,13 @@ def test_conv3x3(dtype, B, Cin, Cout, H, W, bm, bn, splitk):
     (2, 128, 128, 16, 16, 256, 1), (1, 64, 192, 9, 13, 128, 1), (2, 256, 128, 8, 8, 256, 3), (3, 192, 256, 6, 10, 128, 2),
     (2, 384, 384, 24, 24, 256, 1), (1, 128, 256, 96, 96, 256, 1), (2, 128, 128, 12, 12, 0, 0), (1, 128, 136, 48, 48, 128, 1),
 ])
-def test_conv3x3_halo(dtype, B, Cin, Cout, H, W, bm, splitk):
-    """LDS-resident halo kernel (conv3_halo.hip): junk columns, image boundaries, ragged last tile, split-K."""
+@pytest.mark.parametrize("algo", [2, 3])
+def test_conv3x3_halo(dtype, B, Cin, Cout, H, W, bm, splitk, algo):
+    """LDS-resident halo kernels (conv3_halo.hip; algo 2 = 128-byte rows, 3 = 64-byte rows / filter-row iterations):
+    junk columns, image boundaries, ragged last tile, split-K."""
     x, w = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
     bias, res = rnd(Cout, seed=3), rnd(B, Cout, H, W, seed=4)
-    out, ref = hp.conv3x3(x, w, bias, res, dtype=dtype, splitk=splitk, bm=bm, bn=0, algo=2)
+    out, ref = hp.conv3x3(x, w, bias, res, dtype=dtype, splitk=splitk, bm=bm, bn=0, algo=algo)
     close(out, ref, dtype, f"halo conv {B}x{Cin}->{Cout}@{H}x{W}")
 
 
@@ -89,11 +91,12 @@ def test_conv3x3_halo(dtype, B, Cin, Cout, H, W, bm, splitk):
 @pytest.mark.parametrize("B,Cin,Cout,H,W,bm,splitk", [
     (2, 128, 128, 16, 16, 256, 1), (2, 128, 256, 24, 24, 128, 1), (2, 256, 128, 12, 12, 256, 2), (1, 128, 128, 48, 48, 256, 1),
 ])
-def test_conv3x3_groupnorm_partial_sums(dtype, B, Cin, Cout, H, W, bm, splitk):
+@pytest.mark.parametrize("algo", [2, 3])
+def test_conv3x3_groupnorm_partial_sums(dtype, B, Cin, Cout, H, W, bm, splitk, algo):
     """The conv epilogue's GroupNorm side output = per-image, per-channel sum / sum of squares of the STORED tensor."""
     x, w = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
     bias, res = rnd(Cout, seed=3), rnd(B, Cout, H, W, seed=4)
-    out, ref, st = hp.conv3x3(x, w, bias, res, dtype=dtype, splitk=splitk, bm=bm, bn=0, algo=2, stats=True)
+    out, ref, st = hp.conv3x3(x, w, bias, res, dtype=dtype, splitk=splitk, bm=bm, bn=0, algo=algo, stats=True)
     close(out, ref, dtype, "halo conv with stats")
     o = out.double()
     s_ref, q_ref = o.sum((2, 3)), (o * o).sum((2, 3))
@@ -107,7 +110,8 @@ def test_conv3x3_groupnorm_partial_sums(dtype, B, Cin, Cout, H, W, bm, splitk):
     (2, 128, 128, 64, 0, 16, 16, 256, 1), (1, 128, 256, 128, 64, 24, 24, 128, 1), (2, 256, 128, 192, 128, 12, 12, 256, 2),
     (2, 128, 128, 320, 0, 8, 8, 128, 4),
 ])
-def test_conv3x3_with_fused_skip_connection(dtype, B, Cin, Cout, SK0, SK1, H, W, bm, splitk):
+@pytest.mark.parametrize("algo", [2, 3])
+def test_conv3x3_with_fused_skip_connection(dtype, B, Cin, Cout, SK0, SK1, H, W, bm, splitk, algo):
     """out = conv3x3(h) + conv1x1(cat(x0, x1)): the channel-changing ResBlock tail in one halo-kernel launch."""
     import torch.nn.functional as F
     T = hp.tdt(dtype)
@@ -121,9 +125,13 @@ def test_conv3x3_with_fused_skip_connection(dtype, B, Cin, Cout, SK0, SK1, H, W,
     wsp = hp.pad_rows(ws.to(T))
     out = torch.empty(B, H, W, Cout, dtype=T, device="cuda")
     partial = torch.empty(max(1, splitk) * B * H * W * Cout + 64, device="cuda")
-    _lib.check(_lib.lib().k22_conv3x3_skip(hpad.data_ptr(), w3p.data_ptr(), b3.data_ptr(), x0n.data_ptr(), _lib.ptr(x1n), SK0, SK1,
-                                           wsp.data_ptr(), bs.data_ptr(), out.data_ptr(), partial.data_ptr(), B, H, W, Cin, Cout,
-                                           w3p.shape[0], splitk, bm, dtype, hp.stream()))
+    _lib.check(_lib.lib().k22_set_option(b"conv_algo", algo))
+    try:
+        _lib.check(_lib.lib().k22_conv3x3_skip(hpad.data_ptr(), w3p.data_ptr(), b3.data_ptr(), x0n.data_ptr(), _lib.ptr(x1n), SK0, SK1,
+                                               wsp.data_ptr(), bs.data_ptr(), out.data_ptr(), partial.data_ptr(), B, H, W, Cin, Cout,
+                                               w3p.shape[0], splitk, bm, dtype, hp.stream()))
+    finally:
+        _lib.check(_lib.lib().k22_set_option(b"conv_algo", 0))
     xin = x0.to(T).float() if x1 is None else torch.cat([x0.to(T).float(), x1.to(T).float()], 1)
     ref = F.conv2d(h.to(T).float(), w3.to(T).float(), b3, padding=1) + F.conv2d(xin, ws.to(T).float()[:, :, None, None], bs)
     close(out.float().permute(0, 3, 1, 2), ref, dtype, "conv3x3 + fused 1x1 skip")

@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--stages", type=int, default=-1, help="igemm_stages option (2..4 LDS-DMA pipeline depth)")
     ap.add_argument("--xcd", type=int, default=1, help="XCD-aware block renumbering on/off")
+    ap.add_argument("--filter", default="", help="only these conv shapes: 'cin,cout,h;cin,cout,h'")
     ap.add_argument("--cold", type=int, default=1, help="rotate weight copies so weights come from HBM, not the Infinity Cache")
     ap.add_argument("--gemm", action="store_true", help="benchmark the GEMM shapes (1x1 skip, qkv, proj) instead of the 3x3 convs")
     a = ap.parse_args()
@@ -74,13 +75,16 @@ def main():
     if a.gemm:
         return bench_gemm(a, arch, L, dt, T)
     shapes = conv_shapes(arch, a.B, a.lat)
+    if a.filter:
+        want = {tuple(int(v) for v in f.split(",")) for f in a.filter.split(";")}
+        shapes = OrderedDict((k, v) for k, v in shapes.items() if k in want)
     cfgs = []
     for c in a.configs.split(","):
         if c == "auto":
             cfgs.append((0, 0, 0, 0))
-        elif c.startswith("h"):          # h256 / h128x2 : halo kernel, BM, split-K (0 = heuristic)
+        elif c.startswith("h") or c.startswith("g"):   # h256 / h128x2 : halo kernel (g = 64-byte-row variant), BM, split-K
             parts = c[1:].split("x")
-            cfgs.append((int(parts[0]), 0, int(parts[1]) if len(parts) > 1 else 0, 2))
+            cfgs.append((int(parts[0]), 0, int(parts[1]) if len(parts) > 1 else 0, 2 if c[0] == "h" else 3))
         else:                            # 128x64x8 : generic implicit GEMM
             parts = c.split("x")
             cfgs.append((int(parts[0]), int(parts[1]), int(parts[2]) if len(parts) > 2 else 1, 1))

@@ -22,6 +22,7 @@ torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / n * 1e3
 wbytes = sum(v.numel() for k, v in m.state_dict().items() if k.startswith("model.transformer") and k.endswith("weight") and v.dim() == 2) * 2
 print(f"prior forward bs=1 (2x81 tokens) bf16: {ms:.3f} ms  ({wbytes / ms / 1e6:.0f} GB/s of transformer weights, finite={bool(torch.isfinite(out).all())})")
+print(m.tuning_report())
 t0 = time.perf_counter()
 s = m(te, tq, mask, torch.tensor([4.0], device="cuda"), timestep_respacing="25")
 torch.cuda.synchronize()
