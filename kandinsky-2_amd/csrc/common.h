@@ -92,6 +92,14 @@ __device__ __forceinline__ void mma_atom(f32x16_t& acc, const Frag<float>& a, co
 
 __device__ __forceinline__ int c_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
+// Raw workgroup barrier (no implied vmcnt/lgkmcnt drain: LDS-DMA stays in flight across it) that the COMPILER may not
+// move LDS accesses across: the builtin alone is not a memory barrier for the optimiser.
+__device__ __forceinline__ void raw_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // ---- 64-lane reductions --------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -55,17 +55,16 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnStatsParams p) {
       const T* src = c < p.C0 ? x0 + c : x1 + (c - p.C0);
       const int64_t ld = c < p.C0 ? p.C0 : p.C1;
       int pix = pix0 + pl;
-      // 4 independent loads in flight per thread (latency-bound otherwise)
-      for (; pix + 3 * PL < pix1; pix += 4 * PL) {
-        float f0[4], f1[4], f2[4], f3[4];
-        load4(src + (int64_t)pix * ld, f0);
-        load4(src + (int64_t)(pix + PL) * ld, f1);
-        load4(src + (int64_t)(pix + 2 * PL) * ld, f2);
-        load4(src + (int64_t)(pix + 3 * PL) * ld, f3);
+      // 8 independent loads in flight per thread (a block's pixel range is short: latency-bound otherwise)
+      for (; pix + 7 * PL < pix1; pix += 8 * PL) {
+        float f[8][4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) load4(src + (int64_t)(pix + u * PL) * ld, f[u]);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          sum[j][k] += (f0[k] + f1[k]) + (f2[k] + f3[k]);
-          sq[j][k] += (f0[k] * f0[k] + f1[k] * f1[k]) + (f2[k] * f2[k] + f3[k] * f3[k]);
+          sum[j][k] += ((f[0][k] + f[1][k]) + (f[2][k] + f[3][k])) + ((f[4][k] + f[5][k]) + (f[6][k] + f[7][k]));
+          sq[j][k] += ((f[0][k] * f[0][k] + f[1][k] * f[1][k]) + (f[2][k] * f[2][k] + f[3][k] * f[3][k])) +
+                      ((f[4][k] * f[4][k] + f[5][k] * f[5][k]) + (f[6][k] * f[6][k] + f[7][k] * f[7][k]));
         }
       }
       for (; pix < pix1; pix += PL) {
@@ -111,6 +110,17 @@ __global__ __launch_bounds__(256) void gn_coeff_kernel(GnCoeffParams p) {
   __shared__ float ms[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = blockIdx.x, b = blockIdx.y;
   const int cg = p.C / p.groups;
+  // the affine / FiLM operands do not depend on the statistics: fetch them first so that their latency overlaps
+  // the partial-sum reduction (this kernel is a chain of dependent round trips, not a bandwidth problem)
+  float pg = 0.f, pb = 0.f, psc = 1.f, psh = 0.f;
+  if (tid < cg) {
+    const int c = g * cg + tid;
+    pg = p.gamma[c]; pb = p.beta[c];
+    if (p.film != nullptr) {
+      psc = 1.f + p.film[(int64_t)b * p.film_ld + c];
+      psh = p.film[(int64_t)b * p.film_ld + p.C + c];
+    }
+  }
   double s = 0.0, q = 0.0;
   int off = 0;
 #pragma unroll
@@ -162,14 +172,13 @@ __global__ __launch_bounds__(256) void gn_coeff_kernel(GnCoeffParams p) {
   }
   __syncthreads();
   const float mean_f = ms[0], rstd_f = ms[1];
-  for (int c = g * cg + tid; c < (g + 1) * cg; c += 256) {
-    float A = rstd_f * p.gamma[c];
-    float Bc = p.beta[c] - mean_f * A;
+  if (tid < cg) {  // cg <= 96 (C <= 3072)
+    const int c = g * cg + tid;
+    float A = rstd_f * pg;
+    float Bc = pb - mean_f * A;
     if (p.film != nullptr) {
-      const float sc = 1.f + p.film[(int64_t)b * p.film_ld + c];
-      const float sh = p.film[(int64_t)b * p.film_ld + p.C + c];
-      A *= sc;
-      Bc = Bc * sc + sh;
+      A *= psc;
+      Bc = Bc * psc + psh;
     }
     *reinterpret_cast<float2*>(p.coeff + ((int64_t)b * p.C + c) * 2) = make_float2(A, Bc);
   }
@@ -470,6 +479,7 @@ int launch_gn_stats(const GnStatsParams& p, int dtype, hipStream_t s) {
   return K22_OK;
 }
 int launch_gn_coeff(const GnCoeffParams& p, int B, hipStream_t s) {
+  if (p.C / p.groups > 256) return k22_set_error(K22_EINVAL, "gn_coeff: more than 256 channels per group");
   hipLaunchKernelGGL(gn_coeff_kernel, dim3(p.groups, B), dim3(256), 0, s, p);
   K22_CHECK_LAUNCH();
   return K22_OK;

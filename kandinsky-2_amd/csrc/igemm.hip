@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     int cur = 0, fill = STAGES - 1;
     for (int kt = kt0; kt < kt1; ++kt) {
       wait_vmcnt<(STAGES - 2) * CH>();
-      __builtin_amdgcn_s_barrier();
+      raw_barrier();
       K22_ISSUE(kt + STAGES - 1, fill);
       {
         const char* As = smem + cur * BUF;
@@ -420,7 +420,7 @@ static int g_xcd_remap = 1;
 static int g_conv_algo = 0;
 void igemm_set_default_stages(int v) { g_stages_override = (v >= 2 && v <= 4) ? v : -1; }
 void igemm_set_xcd_remap(int v) { g_xcd_remap = v ? 1 : 0; }
-void igemm_set_conv_algo(int v) { g_conv_algo = (v >= 0 && v <= 3) ? v : 0; }
+void igemm_set_conv_algo(int v) { g_conv_algo = (v >= 0 && v <= 4) ? v : 0; }
 
 static int g_default_stages() {
   static int v = -1;
@@ -444,7 +444,7 @@ static IgemmPlan igemm_plan(const IgemmParams& p, int dtype) {
   const int algo = p.algo ? p.algo : g_conv_algo;
   if (p.taps == 9 && algo != 1 && p.N >= 128) {
     IgemmParams ph = p;
-    ph.algo = (algo == 3) ? 3 : 2;
+    ph.algo = (algo == 3 || algo == 4) ? algo : 2;
     int bm = 0;
     if (p.force_bm == 256 || p.force_bm == 128) {
       if (conv3_halo_supported(ph, dtype, p.force_bm) && (algo >= 2 || p.force_bn == 0)) bm = p.force_bm;

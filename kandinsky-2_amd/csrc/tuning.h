@@ -43,7 +43,10 @@ inline void tuned_make_candidates(Tuned& t, int dtype) {
   std::vector<Cfg> all;
   if (p.taps == 9) {
     const int B = p.M / (p.H * p.W);
+    // algo 2 = lock-step halo kernel; 3 = 64-byte rows / filter-row iterations (only ever wins at the smallest level,
+    // deep split-K); 4 = two-phase kernel (measured 12-20 % slower than 2 on every shape: not a candidate)
     for (int algo : {2, 3}) {
+      if (algo == 3 && p.H > 16) continue;
       IgemmParams ph = p;
       ph.algo = algo;
       const int nsplit_max = (p.Kc / BK) * (algo == 3 ? 2 : 1);
@@ -59,8 +62,9 @@ inline void tuned_make_candidates(Tuned& t, int dtype) {
     }
   }
   const int tiles[3][2] = {{128, 128}, {128, 64}, {64, 64}};
-  // skinny problems (a few hundred rows against a big weight matrix) are HBM-latency bound: also try deeper rings
-  const bool skinny = p.taps == 1 && p.M <= 512 && (int64_t)p.N * p.Kc >= (1 << 21);
+  // GEMMs whose weights stream from HBM are latency bound per workgroup (one 8-16 KB tile per round trip with a
+  // 2-deep ring): also try deeper rings
+  const bool skinny = p.taps == 1;
   for (auto& tl : tiles) {
     if (p.S0 != nullptr) break;  // a fused skip connection rides on the halo kernel only
     if (tl[1] == 128 && p.N <= 64) continue;
@@ -205,7 +209,7 @@ inline std::string tuning_report_text(const std::deque<Tuned>& tuned) {
   for (auto& t : tuned) {
     char line[256];
     snprintf(line, sizeof line, "%4d %6d %5d %5d %4d %4d %5d | %4s %3d %3d %6d %3d | %8.1f", t.p.taps, t.p.M, t.p.N, t.p.Kc,
-             t.p.H, t.p.W, t.want_stats ? 1 : 0, t.cfg.algo == 2 ? "halo" : (t.cfg.algo == 3 ? "hal3" : (t.cfg.algo == 1 ? "gen" : "auto")), t.cfg.bm, t.cfg.bn,
+             t.p.H, t.p.W, t.want_stats ? 1 : 0, t.cfg.algo == 2 ? "halo" : (t.cfg.algo == 3 ? "hal3" : (t.cfg.algo == 4 ? "hal4" : (t.cfg.algo == 1 ? "gen" : "auto"))), t.cfg.bm, t.cfg.bn,
              t.cfg.splitk, t.cfg.stages, t.best_us);
     if (!seen.count(line)) order.push_back(line);
     seen[line]++;
