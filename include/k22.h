@@ -123,6 +123,12 @@ int k22_unet_profile(K22UNet* u, int reps, double* ms, double* flops, double* by
  *   scratch: device, >= k22_sampler_scratch_bytes(N,HW).
  */
 size_t k22_sampler_scratch_bytes(int N, int HW);
+/* DDIM step (DDIMSampler.p_sample_ddim, kandinsky2/model/samplers.py:290-331) with model_fn's guidance folded in:
+ * e = u + g (c - u) on channels 0-3 of model_out [N][8][HW]; x0 = (x - sqrt(1-a_t) e) / sqrt(a_t);
+ * x_out = sqrt(a_prev) x0 + sqrt(1 - a_prev - sigma^2) e + sigma * noise.   table_row: device fp32[4] =
+ * (a_t, a_prev, sigma_t, sqrt(1 - a_t)); noise may be NULL (eta = 0); x0_out may be NULL. */
+int k22_ddim_step(const float* x, const float* model_out, const float* noise, const float* table_row, float guidance, int use_cfg,
+                  float* x_out, float* x0_out, int N, int HW, void* stream);
 int k22_sampler_step(const float* x, const float* model_out, const float* noise, const float* init_img,
                      const float* mask, const float* table, int step_index, float guidance, int use_cfg,
                      float clamp_lo, float clamp_hi, int pct_index, double pct_gamma, void* scratch,

@@ -171,6 +171,45 @@ __global__ __launch_bounds__(256) void sampler_final_kernel(SamplerParams p) {
   }
 }
 
+// ---- DDIM step (kandinsky2/model/samplers.py:290-331, eta-general) with model_fn's classifier-free guidance folded in ----
+// tab = (alpha_t, alpha_prev, sigma_t, sqrt(1 - alpha_t)) as fp32 (the reference builds them with torch.full from the fp64
+// numpy schedule, i.e. rounded to fp32); e_t = u + g (c - u) on channels 0-3 of the raw UNet output.
+__global__ __launch_bounds__(256) void ddim_step_kernel(const float* x, const float* model_out, const float* noise, const float* tab,
+                                                        float guidance, int use_cfg, float* x_out, float* x0_out, int N, int HW) {
+  const float a_t = tab[0], a_prev = tab[1], sigma = tab[2], s1m = tab[3];
+  const float sq_at = sqrtf(a_t), sq_ap = sqrtf(a_prev);
+  const float dirc = sqrtf(__fsub_rn(__fsub_rn(1.0f, a_prev), __fmul_rn(sigma, sigma)));
+  const int64_t total = (int64_t)N * 4 * HW;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int pix = (int)(i % HW);
+    const int c = (int)((i / HW) % 4), n = (int)(i / (4 * (int64_t)HW));
+    float e;
+    if (use_cfg) {
+      const int bs = N / 2, j = n % bs;
+      const float ce = model_out[((int64_t)j * 8 + c) * HW + pix], ue = model_out[((int64_t)(j + bs) * 8 + c) * HW + pix];
+      e = ue + guidance * (ce - ue);
+    } else {
+      e = model_out[((int64_t)n * 8 + c) * HW + pix];
+    }
+    const float x0 = __fdiv_rn(__fsub_rn(x[i], __fmul_rn(s1m, e)), sq_at);
+    float xp = __fadd_rn(__fmul_rn(sq_ap, x0), __fmul_rn(dirc, e));
+    if (noise != nullptr) xp = __fadd_rn(xp, __fmul_rn(sigma, noise[i]));
+    x_out[i] = xp;
+    if (x0_out != nullptr) x0_out[i] = x0;
+  }
+}
+
+int launch_ddim_step(const float* x, const float* model_out, const float* noise, const float* tab, float guidance, int use_cfg,
+                     float* x_out, float* x0_out, int N, int HW, hipStream_t s) {
+  if (N <= 0 || HW <= 0 || (use_cfg && (N & 1))) return k22_set_error(K22_EINVAL, "ddim_step: bad batch");
+  const int64_t total = (int64_t)N * 4 * HW;
+  int nb = (int)((total + 255) / 256);
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(ddim_step_kernel, dim3(nb), dim3(256), 0, s, x, model_out, noise, tab, guidance, use_cfg, x_out, x0_out, N, HW);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+
 // advances the device step counter (one thread); used when a whole step is replayed as a graph.
 __global__ void step_advance_kernel(int* step, int delta) { *step += delta; }
 

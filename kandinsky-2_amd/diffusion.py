@@ -179,6 +179,65 @@ class SpacedDiffusionHIP:
         return x
 
 
+class DDIMSamplerHIP:
+    """DDIMSampler (kandinsky2/model/samplers.py:68-331) for the decoder UNet with the step arithmetic and model_fn's
+    classifier-free guidance (kandinsky2_1_model.py:222-233, the non-p_sampler branch) fused into k22_ddim_step.
+
+        sampler = DDIMSamplerHIP(model, old_diffusion, guidance_scale)   # old_diffusion: the UN-respaced 1000-step schedule
+        samples, _ = sampler.sample(num_steps, batch_size * 2, (4, h, w), conditioning=model_kwargs, x_T=noise, init_step=None)
+
+    `model` is the Text2ImUNetHIP itself (not model_fn); it receives the raw ddim timestep (1 .. 981) like the reference.
+    """
+
+    def __init__(self, model, old_diffusion: SpacedDiffusionHIP, guidance_scale: float, schedule: str = "linear"):
+        if old_diffusion.num_timesteps != 1000:
+            raise ValueError("DDIM needs the un-respaced 1000-step diffusion (the reference asserts the same, samplers.py:98-100)")
+        self.model, self.old_diffusion, self.guidance_scale = model, old_diffusion, float(guidance_scale)
+        self.ddpm_num_timesteps = 1000
+
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0.0, init_step=None):
+        if ddim_discretize != "uniform":
+            raise NotImplementedError("only the 'uniform' discretisation (the reference default)")
+        c = self.ddpm_num_timesteps // ddim_num_steps
+        steps = np.asarray(list(range(0, self.ddpm_num_timesteps, c))) + 1          # make_ddim_timesteps
+        if init_step is not None:
+            steps = np.array([i for i in steps if i <= init_step])                    # apply_init_step
+        self.ddim_timesteps = steps
+        ac = self.old_diffusion.alphas_cumprod
+        alphas = ac[steps]
+        alphas_prev = np.asarray([ac[0]] + ac[steps[:-1]].tolist())
+        sigmas = ddim_eta * np.sqrt((1 - alphas_prev) / (1 - alphas) * (1 - alphas / alphas_prev))
+        tab = np.zeros((len(steps), 4), dtype=np.float32)
+        tab[:, 0], tab[:, 1], tab[:, 2], tab[:, 3] = alphas, alphas_prev, sigmas, np.sqrt(1.0 - alphas)
+        self.table, self.eta = tab, float(ddim_eta)
+
+    @torch.no_grad()
+    def sample(self, S, batch_size, shape, conditioning=None, eta=0.0, x_T=None, init_step=None, noise_seq=None, device="cuda", **_unused):
+        self.make_schedule(S, ddim_eta=eta, init_step=init_step)
+        L = _lib.lib()
+        C, H, W = shape
+        if C != 4 or batch_size % 2:
+            raise ValueError("shape must be (4, h, w) and batch_size = 2*bs")
+        dev = torch.device(device)
+        N, HW, bs = batch_size, H * W, batch_size // 2
+        x = x_T.to(dev).float().contiguous().clone() if x_T is not None else torch.randn(N, C, H, W, device=dev)
+        x_next, x0 = torch.empty_like(x), torch.empty_like(x)
+        table = torch.from_numpy(self.table).to(dev)
+        total = len(self.ddim_timesteps)
+        for i, step in enumerate(np.flip(self.ddim_timesteps)):
+            index = total - i - 1
+            ts = torch.full((N,), float(step), device=dev)
+            half = x[:bs]
+            out = self.model(torch.cat([half, half], 0), ts, **(conditioning or {}))
+            nz = None
+            if self.eta > 0.0:
+                nz = noise_seq[i].to(dev).float().contiguous() if noise_seq is not None else torch.randn_like(x)
+            _lib.check(L.k22_ddim_step(x.data_ptr(), out.data_ptr(), _lib.ptr(nz), table[index].data_ptr(), self.guidance_scale, 1,
+                                       x_next.data_ptr(), x0.data_ptr(), N, HW, _lib.current_stream()))
+            x, x_next = x_next, x
+        return x, {"pred_x0": [x0]}
+
+
 def create_gaussian_diffusion(**kw) -> SpacedDiffusionHIP:
     """Keyword-compatible with the reference's create_gaussian_diffusion (model_creation.py:86-128)."""
     return SpacedDiffusionHIP(**kw)

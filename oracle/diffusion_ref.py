@@ -84,3 +84,35 @@ class RefDiffusion:
             out = unet_fn(torch.cat([half, half], 0), torch.full((len(x),), self.model_t(i), dtype=torch.float32))
             x, _ = self.p_sample(out, x, i, noise_seq[k], guidance, init_img, img_mask)
         return x
+
+
+def ddim_sample_loop(unet_fn, x_T, num_steps, guidance, eta=0.0, noise_seq=None, init_step=None, steps=1000,
+                     linear_start=0.00085, linear_end=0.012):
+    """DDIMSampler.sample / ddim_sampling / p_sample_ddim (kandinsky2/model/samplers.py:82-331, 'uniform' discretisation)
+    driven by Kandinsky2_1.generate_img's model_fn in its DDIM branch (kandinsky2_1_model.py:222-233: guided eps only).
+    unet_fn(x_combined, t [2bs] float) -> [2bs,8,h,w]."""
+    ac = np.cumprod(1.0 - linear_betas(steps, linear_start, linear_end))
+    c = steps // num_steps
+    ts = np.asarray(list(range(0, steps, c))) + 1
+    if init_step is not None:
+        ts = np.array([i for i in ts if i <= init_step])
+    alphas = ac[ts]
+    alphas_prev = np.asarray([ac[0]] + ac[ts[:-1]].tolist())
+    sigmas = eta * np.sqrt((1 - alphas_prev) / (1 - alphas) * (1 - alphas / alphas_prev))
+    x = x_T.clone()
+    total = len(ts)
+    f = lambda v: torch.tensor(float(v), dtype=torch.float32)  # noqa: E731  (torch.full(..., python float) rounds to fp32)
+    for i, step in enumerate(np.flip(ts)):
+        index = total - i - 1
+        half = x[: len(x) // 2]
+        out = unet_fn(torch.cat([half, half], 0), torch.full((len(x),), float(step)))
+        eps = out[:, :4]
+        cond, uncond = torch.split(eps, len(eps) // 2, dim=0)
+        he = uncond + guidance * (cond - uncond)
+        e_t = torch.cat([he, he], dim=0)
+        a_t, a_prev, sigma_t, s1m = f(alphas[index]), f(alphas_prev[index]), f(sigmas[index]), f(np.sqrt(1.0 - alphas)[index])
+        pred_x0 = (x - s1m * e_t) / a_t.sqrt()
+        dir_xt = (1.0 - a_prev - sigma_t ** 2).sqrt() * e_t
+        noise = sigma_t * (noise_seq[i] if noise_seq is not None else torch.zeros_like(x))
+        x = a_prev.sqrt() * pred_x0 + dir_xt + noise
+    return x

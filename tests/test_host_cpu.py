@@ -215,3 +215,26 @@ def test_prior_schedule_matches_oracle_tables():
         tab = a.step_table()
         assert np.array_equal(tab[:, 0], b.c1.astype(np.float32)) and np.array_equal(tab[:, 2], b.logvar.astype(np.float32))
         assert tab[0, 3] == 0 and (tab[1:, 3] == 1).all()
+
+
+def test_ddim_oracle_matches_reference_golden(golden_dir):
+    fx = _load(golden_dir, "tiny_ddim")
+    arch = k22.make_arch(fx["model_config"])
+    sd = k22.init_unet_state_dict(arch, seed=fx["seed_w"])
+    full, pooled, image = k22.make_conditioning(arch, fx["B"], seed=2)
+    g = torch.Generator().manual_seed(42)
+    x_T = torch.randn(fx["B"], 4, fx["h"], fx["w"], generator=g)
+    out = diffusion_ref.ddim_sample_loop(lambda xc, tt: unet_ref.unet_forward(sd, arch, xc, tt, full, pooled, image), x_T, fx["steps"], fx["guidance"])
+    assert (out - fx["final"]).abs().max().item() <= 1e-4 * fx["final"].abs().max().item()
+
+
+def test_ddim_schedule_matches_oracle():
+    old = k22.create_gaussian_diffusion(**k22.DIFFUSION_CONFIG_2_1)
+    s = k22.DDIMSamplerHIP(None, old, 4.0)
+    s.make_schedule(50)
+    assert list(s.ddim_timesteps[:3]) == [1, 21, 41] and len(s.ddim_timesteps) == 50
+    ac = np.cumprod(1.0 - diffusion_ref.linear_betas(1000, 0.00085, 0.012))
+    assert np.array_equal(s.table[:, 0], ac[s.ddim_timesteps].astype(np.float32))
+    assert s.table[0, 1] == np.float32(ac[0]) and (s.table[:, 2] == 0).all()
+    s.make_schedule(50, init_step=500)
+    assert s.ddim_timesteps.max() <= 500

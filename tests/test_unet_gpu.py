@@ -127,3 +127,49 @@ def test_forward_matches_oracle_on_fresh_seed():
     o_new = m(x.cuda(), t.cuda(), full_emb=full2.cuda(), pooled_emb=pooled.cuda(), image_emb=image.cuda()).cpu()
     ref2 = unet_ref.unet_forward(sd, arch, x, t, full2, pooled, image)
     assert (o_new - ref2).abs().max().item() <= 2e-4 * ref2.abs().max().item()
+
+
+def test_ddim_sampler_final_latent_vs_reference_golden_fp32(golden_dir):
+    """the reference's default sampler (DDIMSampler, eta = 0) with the fused k22_ddim_step; fp32 engine,
+    5 steps, final latent within 1e-3 of the reference's (relative to its scale: the un-clamped DDIM latent of a
+    random-weight UNet grows to ~50)."""
+    fx = _load(golden_dir, "tiny_ddim")
+    arch = k22.make_arch(fx["model_config"])
+    sd = k22.init_unet_state_dict(arch, seed=fx["seed_w"])
+    m = k22.Text2ImUNetHIP(arch, backend_dtype=torch.float32, use_graph=True)
+    m.load_state_dict(sd)
+    m = m.to("cuda").eval()
+    full, pooled, image = k22.make_conditioning(arch, fx["B"], seed=2)
+    kw = dict(full_emb=full.cuda(), pooled_emb=pooled.cuda(), image_emb=image.cuda())
+    g = torch.Generator().manual_seed(42)
+    x_T = torch.randn(fx["B"], 4, fx["h"], fx["w"], generator=g)
+    old = k22.create_gaussian_diffusion(**k22.DIFFUSION_CONFIG_2_1)  # un-respaced 1000 steps, as the reference builds it for DDIM
+    sampler = k22.DDIMSamplerHIP(m, old, fx["guidance"])
+    out, _ = sampler.sample(fx["steps"], fx["B"], (4, fx["h"], fx["w"]), conditioning=kw, x_T=x_T.cuda())
+    ref = fx["final"]
+    scale = ref.abs().max().item()
+    err = (out.cpu() - ref).abs().max().item()
+    print(f"DDIM {fx['steps']} steps fp32: max|d|={err:.3e} scale={scale:.2f}")
+    assert err <= 1e-3 * max(1.0, scale)
+
+
+def test_rank_nonzero_path_adopts_a_broadcast_arena():
+    """What ranks != 0 do in bench.py / INTEGRATION.md E: a parameter-less (meta) module adopts the packed arena
+    received over RCCL.  Same bits as the rank that packed it."""
+    arch = k22.make_arch(k22.tiny_model_config())
+    sd = k22.init_unet_state_dict(arch, seed=0)
+    m0 = k22.Text2ImUNetHIP(arch, backend_dtype=torch.bfloat16, use_graph=False)
+    m0.load_state_dict(sd)
+    m0 = m0.to("cuda")
+    m0.prepare(free_params=True)
+    assert m0._arena.numel() == m0.arena_bytes()
+    m1 = k22.Text2ImUNetHIP(arch, backend_dtype=torch.bfloat16, use_graph=False, meta_params=True)
+    assert m1.arena_bytes() == m0.arena_bytes()
+    m1.prepare(arena=m0._arena.clone())
+    for m in (m0, m1):  # every engine measures its own tile table; heuristics only => same split-K => same bits
+        k22._lib.check(k22._lib.lib().k22_unet_set_autotune(m._handle, 0))
+    full, pooled, image = k22.make_conditioning(arch, 2, seed=2)
+    kw = dict(full_emb=full.cuda(), pooled_emb=pooled.cuda(), image_emb=image.cuda())
+    x = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(1)).cuda()
+    t = torch.tensor([500.0, 500.0]).cuda()
+    assert torch.equal(m0(x, t, **kw), m1(x, t, **kw))
