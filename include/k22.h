@@ -34,7 +34,8 @@ int k22_version(void);
 const char* k22_last_error(void);
 /* Tuning knobs (process-wide): "igemm_stages" = 2..4 LDS-DMA pipeline depth (-1 default);
  * "igemm_xcd_remap" = 0/1 XCD-aware workgroup renumbering; "conv_algo" = 0 auto, 1 generic implicit GEMM,
- * 2 LDS-resident halo kernel for the 3x3 convolutions. */
+ * 2 LDS-resident halo kernel for the 3x3 convolutions (3-7: its variants, see conv3_halo.hip; 8-9: measurement only);
+ * "gemm_algo" = 0 generic implicit-GEMM kernel, 10 = 8-wave BM x 128 tile kernel where it applies. */
 int k22_set_option(const char* name, int value);
 
 /* ---- UNet engine --------------------------------------------------------------------------
@@ -155,6 +156,12 @@ int k22_conv3x3_skip(const void* x_padded, const void* Wp, const float* bias, co
 int k22_conv3x3_gnstats(const void* x_padded, const void* Wp, const float* bias, const void* residual, void* out,
                         void* partial, int B, int H, int W, int Cin, int Cout, int Npad, int splitk, int bm, int bn,
                         float* stats, int stats_capacity_rows, int* rows_per_image, int dtype, void* stream);
+/* Same for a 1x1 convolution over unpadded rows [B*H*W][K] (AttentionBlock proj_out, unet.py:244-268, whose output the
+ * next ResBlock's GroupNorm32 normalises): out = A W^T + bias (+ residual) through the 8-wave BM x 128 GEMM kernel
+ * (bm = 256 / 128 / 0 = auto), with the per-tile (sum, sum of squares) rows as above. */
+int k22_gemm_gnstats(const void* A, const void* Wp, const float* bias, const void* residual, void* out, void* partial,
+                     int B, int H, int W, int N, int Npad, int K, int splitk, int bm, float* stats,
+                     int stats_capacity_rows, int* rows_per_image, int dtype, void* stream);
 /* Developer tool: runs the 256-row bf16 halo kernel once with s_memtime stamps; trace = device u64 [2][1024][4]
  * (wave 0 / wave 5 of workgroup 0; per tap: before the counted vmcnt wait, after it, after the barrier, after the last
  * MFMA was issued).  tools/conv_trace.py prints the per-phase cycle budget. */

@@ -24,6 +24,7 @@ int k22_set_option(const char* name, int value) {
   if (name && !strcmp(name, "igemm_stages")) { igemm_set_default_stages(value); return K22_OK; }
   if (name && !strcmp(name, "igemm_xcd_remap")) { igemm_set_xcd_remap(value); return K22_OK; }
   if (name && !strcmp(name, "conv_algo")) { igemm_set_conv_algo(value); return K22_OK; }
+  if (name && !strcmp(name, "gemm_algo")) { igemm_set_gemm_algo(value); return K22_OK; }
   return k22_set_error(K22_EINVAL, "k22_set_option: unknown option");
 }
 const char* k22_last_error(void) { return g_err; }
@@ -69,6 +70,23 @@ int k22_conv3x3_gnstats(const void* x_padded, const void* Wp, const float* bias,
   if (rows_per_image) *rows_per_image = rpi;
   if (rpi <= 0) return k22_set_error(K22_EINVAL, "conv3x3_gnstats: this configuration cannot produce GroupNorm partial sums");
   if (rpi * B > stats_capacity_rows) return k22_set_error(K22_ENOMEM, "conv3x3_gnstats: stats buffer too small");
+  p.stats = stats;
+  return launch_igemm(p, dtype, reinterpret_cast<hipStream_t>(stream));
+}
+
+int k22_gemm_gnstats(const void* A, const void* Wp, const float* bias, const void* residual, void* out, void* partial,
+                     int B, int H, int W, int N, int Npad, int K, int splitk, int bm, float* stats,
+                     int stats_capacity_rows, int* rows_per_image, int dtype, void* stream) {
+  IgemmParams p = {};
+  p.stages = -1;
+  p.A0 = A; p.Wp = Wp; p.bias = bias; p.residual = residual; p.out = out; p.partial = reinterpret_cast<float*>(partial);
+  p.M = B * H * W; p.N = N; p.Npad = Npad; p.Kc = K; p.K0 = K; p.taps = 1; p.H = H; p.W = W; p.lda0 = K;
+  p.ldo = N; p.ldr = N; p.out_mode = IG_OUT_ROWMAJOR; p.act = K22_ACT_NONE; p.splitk = splitk > 0 ? splitk : 1;
+  p.force_bm = bm; p.algo = 10;
+  const int rpi = igemm_stats_rows_per_image(p, dtype);
+  if (rows_per_image) *rows_per_image = rpi;
+  if (rpi <= 0) return k22_set_error(K22_EINVAL, "gemm_gnstats: this configuration cannot produce GroupNorm partial sums");
+  if (rpi * B > stats_capacity_rows) return k22_set_error(K22_ENOMEM, "gemm_gnstats: stats buffer too small");
   p.stats = stats;
   return launch_igemm(p, dtype, reinterpret_cast<hipStream_t>(stream));
 }
@@ -146,7 +164,7 @@ int k22_qkv_project(const void* x, const void* Wp, const float* bias, void* q_ou
   p.A0 = x; p.Wp = Wp; p.bias = bias; p.out = q_out; p.kall = kall; p.vtall = vtall;
   p.M = B * T; p.N = 3 * C; p.Npad = 3 * C; p.Kc = K; p.K0 = K; p.taps = 1; p.lda0 = K; p.lda1 = 0;
   p.ldo = C; p.ldr = 3 * C; p.out_mode = IG_OUT_QKV; p.act = K22_ACT_NONE; p.splitk = 1; p.force_bm = bm; p.force_bn = bn;
-  p.att_T = T; p.att_S = S; p.att_Tkp = Tkp;
+  p.att_T = T; p.att_S = S; p.att_Tkp = Tkp; p.H = 1; p.W = T;   /* rows per image */
   return launch_igemm(p, dtype, reinterpret_cast<hipStream_t>(stream));
 }
 

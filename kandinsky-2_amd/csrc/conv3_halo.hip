@@ -76,6 +76,17 @@ __device__ __forceinline__ int xcd_remap_h(int bid, int nblocks) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
+// LDS-DMA issued from inline asm: 16 bytes per lane from `g` to LDS byte address `lds_dst` (wave-uniform) + 16*lane.
+// hipcc books a __builtin_amdgcn_global_load_lds as a FLAT access pending on BOTH counters, and because the counted
+// vmcnt waits of this file are invisible to it, every later wait for a ds_read becomes lgkmcnt(0) - also for fragments
+// read a whole MFMA group ago, with younger reads still in flight.  An asm statement is absent from its bookkeeping:
+// the compiler then emits exact lgkmcnt(N) for the fragment reads; completion of the DMA is counted by hand anyway.
+__device__ __forceinline__ void glds16_asm(const void* g, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
+}
+
 constexpr int HALO_BN = 128;
 constexpr int HALO_NW = 8;        // waves per workgroup
 constexpr int HALO_MAXA = 8;      // halo LDS-DMA slots per wave per slab: taps 0 .. 9-NBST carry one each
@@ -98,7 +109,9 @@ template <int NBST> constexpr int halo_count_a(int t) {
 
 // Everything after the 3x3 K loop, shared by the halo kernels: optional fused 1x1 skip connection (a plain-GEMM K loop
 // on 128-byte rows), then the epilogue through LDS (bias, residual, one rounding, 16-byte stores, GroupNorm partials).
-template <typename T, int BM>
+// PLAIN = false: rows are positions v of the padded plane (3x3 convolution); PLAIN = true: rows are the pixels
+// v < H*W of image `img` themselves (gemm8_kernel), and the qkv-projection output mode is available.
+template <typename T, int BM, bool PLAIN = false>
 __device__ __forceinline__ void halo_tail(const IgemmParams& p, f32x16_t (&acc)[BM / 128][2], char* smem, int bx, int bz, int img, int v0, int n0) {
   using TR = TT<T>;
   constexpr int BK = TR::BK, EPC = TR::EPC, KSTEPS = TR::KSTEPS;
@@ -111,8 +124,8 @@ __device__ __forceinline__ void halo_tail(const IgemmParams& p, f32x16_t (&acc)[
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int h = lane >> 5, l31 = lane & 31;
-  const int W2 = p.W + 2;
-  const int VR = p.H * W2;
+  const int W2 = PLAIN ? 1 : p.W + 2;
+  const int VR = PLAIN ? (p.H > 0 ? p.H * p.W : p.M) : p.H * W2;
   const int abase = wm * (BM / WM) + l31;
   int brow[NI];
 #pragma unroll
@@ -212,6 +225,34 @@ __device__ __forceinline__ void halo_tail(const IgemmParams& p, f32x16_t (&acc)[
   }
   __syncthreads();
 
+  // ---- qkv projection, n-tile inside v (an n-tile never straddles q / k / v): V^T_all wants the tile transposed.
+  // lane = token (consecutive lanes -> consecutive addresses of one V^T row), 4 channels per LDS read
+  if constexpr (PLAIN) {
+    if (p.out_mode == IG_OUT_QKV && n0 >= 2 * (p.N / 3)) {
+      const int C = p.N / 3, heads = C >> 6;
+      constexpr int CPG = BN / (512 / BM);   // channels per thread group
+      const int r = tid % BM, cg = tid / BM;
+      const int v = v0 + r;
+      if (v < VR) {
+#pragma unroll 4
+        for (int c4 = 0; c4 < CPG; c4 += 4) {
+          const int col = cg * CPG + c4, n = n0 + col;
+          if (n >= p.N) break;
+          const float4 t = *reinterpret_cast<const float4*>(smem + r * TS + col * 4);
+          float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (p.bias != nullptr) b = *reinterpret_cast<const float4*>(p.bias + n);
+          const int c = n - 2 * C, head = c >> 6, d = c & 63;
+          T* vt = reinterpret_cast<T*>(p.vtall) + ((int64_t)(img * heads + head) * 64 + d) * p.att_Tkp + p.att_S + v;
+          vt[0] = from_f32<T>(t.x + b.x);
+          vt[(int64_t)p.att_Tkp] = from_f32<T>(t.y + b.y);
+          vt[(int64_t)2 * p.att_Tkp] = from_f32<T>(t.z + b.z);
+          vt[(int64_t)3 * p.att_Tkp] = from_f32<T>(t.w + b.w);
+        }
+      }
+      return;
+    }
+  }
+
   // ---- epilogue 2: thread = 8 channels x RPT consecutive rows -------------------------------------------
   constexpr int SEGS = BN / 8;            // 16 column segments
   constexpr int RGS = 512 / SEGS;         // 32 row groups
@@ -242,9 +283,15 @@ __device__ __forceinline__ void halo_tail(const IgemmParams& p, f32x16_t (&acc)[
   for (int k = 0; k < RPT; ++k) {
     const int row = rg * RPT + k;
     const int v = v0 + row;
-    const int y = v / W2, x = v - y * W2;
-    if (!n_ok || v >= VR || x >= p.W) continue;
-    const int64_t m = ((int64_t)img * p.H + y) * p.W + x;
+    int64_t m;
+    if constexpr (PLAIN) {
+      if (!n_ok || v >= VR) continue;
+      m = (int64_t)img * VR + v;
+    } else {
+      const int y = v / W2, x = v - y * W2;
+      if (!n_ok || v >= VR || x >= p.W) continue;
+      m = ((int64_t)img * p.H + y) * p.W + x;
+    }
     const float4 t0 = *reinterpret_cast<const float4*>(smem + row * TS + cs * 32);
     const float4 t1 = *reinterpret_cast<const float4*>(smem + row * TS + cs * 32 + 16);
     float val[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
@@ -263,6 +310,22 @@ __device__ __forceinline__ void halo_tail(const IgemmParams& p, f32x16_t (&acc)[
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) val[e] = apply_act(val[e], p.act);
+    if (PLAIN && p.out_mode == IG_OUT_QKV) {
+      // columns [q | k | v] x [heads][64]: q row-major, k behind the context keys of K_all, v transposed into V^T_all
+      const int C = p.N / 3, heads = C >> 6;
+      const int which = n / C, c = n - which * C;
+      const int head = c >> 6, d = c & 63;
+      if (which == 0) {
+        store8<T>(reinterpret_cast<T*>(p.out) + m * p.ldo + c, val);
+      } else if (which == 1) {
+        store8<T>(reinterpret_cast<T*>(p.kall) + ((int64_t)(img * heads + head) * p.att_Tkp + p.att_S + v) * 64 + d, val);
+      } else {
+        T* vt = reinterpret_cast<T*>(p.vtall) + ((int64_t)(img * heads + head) * 64 + d) * p.att_Tkp + p.att_S + v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vt[(int64_t)e * p.att_Tkp] = from_f32<T>(val[e]);
+      }
+      continue;
+    }
     if (p.out_mode == IG_OUT_ROWMAJOR) store8<T>(reinterpret_cast<T*>(p.out) + m * p.ldo + n, val);
     else store8<float>(reinterpret_cast<float*>(p.out) + m * p.ldo + n, val);
     if (p.stats != nullptr) {
@@ -293,15 +356,30 @@ __device__ __forceinline__ void halo_tail(const IgemmParams& p, f32x16_t (&acc)[
   }
 }
 
-template <typename T, int BM, int NBST, bool TRACE = false>
+// LW = number of waves that issue the LDS-DMA (the "loader" waves 0 .. LW-1):
+//   LW = 8: every wave loads its share right after the barrier (3 pieces per wave per tap);
+//   LW = 4: waves 0-3 load everything (6 pieces per tap), waves 4-7 go straight from the barrier into their fragments
+//           and MFMAs.  A workgroup's waves w and w+4 share a SIMD (waves are dealt to the SIMDs cyclically), so
+//           on every SIMD one wave pays the ~100-cycle-per-piece issue cost WHILE its partner owns the matrix pipe,
+//           instead of both issuing first (pipe idle) and then both wanting the pipe (p.algo == 5).
+// PIPE: explicit fragment pipeline across the per-tap barrier.  The fragments of k-step ks+1 are read from LDS BEFORE
+// the MFMAs of k-step ks are issued (two register sets), and the last k-step of a tap is multiplied after the NEXT
+// tap's barrier, where it covers the LDS-DMA issue and the first fragment reads of that tap: a wave never parks on
+// lgkmcnt with an empty matrix pipe behind it (the compiler's own schedule reads one MFMA ahead of the use).
+template <typename T, int BM, int NBST, bool TRACE = false, int LW = 8, int MODE = 0>
 __global__ __launch_bounds__(512) void conv3_halo_kernel(const IgemmParams p) {
+  constexpr bool PIPE = MODE == 1;      // explicit fragment pipeline (above)
+  constexpr bool GASM = MODE == 1 || MODE == 2;  // LDS-DMA from inline asm (glds16_asm): exact lgkmcnt(N) for the fragment reads
+  constexpr bool DBG_NOLOAD = MODE == 3;  // measurement only (wrong results): no LDS-DMA inside the tap loop
+  constexpr bool DBG_NOMMA = MODE == 4;   // measurement only (wrong results): fragments are read but not multiplied
   using TR = TT<T>;
   constexpr int BK = TR::BK, EPC = TR::EPC, KSTEPS = TR::KSTEPS;
-  constexpr int BN = HALO_BN, NW = HALO_NW, WM = 4, WN = 2;
+  constexpr int BN = HALO_BN, NW = LW, WM = 4, WN = 2;
   constexpr int MI = BM / (WM * 32), NI = BN / (WN * 32);
-  constexpr int B_SLOTS = BN / 8 / NW;  // weight LDS-DMA instructions per wave per tap
+  constexpr int B_SLOTS = BN / 8 / NW;  // weight LDS-DMA instructions per loader wave per tap
   constexpr int B_BYTES = BN * 128;
-  constexpr int A_SLOTS = 10 - NBST;    // taps 0 .. 9-NBST issue one halo piece per wave
+  constexpr int APT = HALO_NW / LW;     // halo pieces per loader wave per tap
+  constexpr int A_SLOTS = (10 - NBST) * APT;  // taps 0 .. 9-NBST issue APT halo pieces per loader wave
   constexpr int GM = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -309,6 +387,7 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const IgemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int h = lane >> 5, l31 = lane & 31;
+  const bool loader = LW == HALO_NW || wave < LW;   // wave-uniform
 
   const int W2 = p.W + 2;
   const int VR = p.H * W2;                     // virtual output rows per image
@@ -374,6 +453,13 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const IgemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
+  Frag<T> pa[MI], pb[NI];   // PIPE: fragments read but not yet multiplied (zero = a no-op group before the first tap)
+  if constexpr (PIPE) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) pa[mi] = Frag<T>{};
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) pb[ni] = Frag<T>{};
+  }
   char* const Bst = smem + 2 * A_BYTES;
   // fragment rows: A row = wm*(BM/4) + mi*32 + l31 + tap shift ; B row = wn*(BN/2) + ni*32 + l31
   const int abase = wm * (BM / WM) + l31;
@@ -382,10 +468,15 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const IgemmParams p) {
   for (int ni = 0; ni < NI; ++ni) brow[ni] = (wn * (BN / WN) + ni * 32 + l31) * 128;
   const int bsw = (l31 >> 1) & 7;  // (row >> 1) & 7 with row = multiple of 32 + l31
 
+  // LDS byte address of the dynamic shared segment (wave-uniform), for the asm LDS-DMA path
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
 #define K22_ISSUE_A(Q, SLAB, DST)                                                                          \
   {                                                                                                        \
     int j_ = (Q) * NW + wave;                                                                              \
     if (j_ > NP - 1) j_ = NP - 1;                                                                          \
+    if constexpr (GASM)                                                                                    \
+      glds16_asm(Aimg + aoff[Q] + (SLAB) * BK, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((DST) - smem) + j_ * 1024)); \
+    else                                                                                                   \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Aimg + aoff[Q] + (SLAB) * BK), \
                                      (__attribute__((address_space(3))) void*)((DST) + j_ * 1024), 16, 0, 0); \
   }
@@ -393,17 +484,23 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const IgemmParams p) {
   {                                                                                                        \
     const int kofs_ = (TAP) * p.Kc + (SLAB) * BK;                                                          \
     char* dst_ = Bst + (STAGE) * B_BYTES + wave * 1024;                                                    \
-    _Pragma("unroll") for (int i = 0; i < B_SLOTS; ++i)                                                    \
+    _Pragma("unroll") for (int i = 0; i < B_SLOTS; ++i) {                                                  \
+      if constexpr (GASM)                                                                                  \
+        glds16_asm(Wp + boff[i] + kofs_, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(dst_ - smem) + i * NW * 1024)); \
+      else                                                                                                 \
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wp + boff[i] + kofs_), \
                                          (__attribute__((address_space(3))) void*)(dst_ + i * NW * 1024), 16, 0, 0); \
+    }                                                                                                      \
   }
 
   if (s0 < s1) {
     // prologue: the whole halo of the first slab, then the weight tiles of taps 0 .. NBST-2
+    if (loader) {
 #pragma unroll
-    for (int q = 0; q < A_SLOTS; ++q) K22_ISSUE_A(q, s0, smem);
+      for (int q = 0; q < A_SLOTS; ++q) K22_ISSUE_A(q, s0, smem);
 #pragma unroll
-    for (int t = 0; t < NBST - 1; ++t) K22_ISSUE_B(s0, t, t);
+      for (int t = 0; t < NBST - 1; ++t) K22_ISSUE_B(s0, t, t);
+    }
     int trace_it = 0;
     (void)trace_it;
     int cur = 0;               // ring slot of the current tap's weights
@@ -418,17 +515,22 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const IgemmParams p) {
       {                                                                                                    \
         unsigned long long tr0_ = 0, tr1_ = 0, tr2_ = 0;                                                   \
         if constexpr (TRACE) tr0_ = __builtin_amdgcn_s_memtime();                                          \
-        wait_vmcnt<B_SLOTS * (NBST - 2) + halo_count_a<NBST>(TAP)>();                                      \
+        if (loader && !DBG_NOLOAD) wait_vmcnt<B_SLOTS * (NBST - 2) + APT * halo_count_a<NBST>(TAP)>();     \
         if constexpr (TRACE) tr1_ = __builtin_amdgcn_s_memtime();                                          \
         raw_barrier();                                                                      \
         if constexpr (TRACE) tr2_ = __builtin_amdgcn_s_memtime();                                          \
-        /* the weight tile NBST-1 taps ahead, then one piece of the next slab's halo */                    \
-        {                                                                                                  \
+        /* the weight tile NBST-1 taps ahead, then the next piece(s) of the next slab's halo */            \
+        if (loader && !DBG_NOLOAD) {                                                                       \
           constexpr int ta_ = ((TAP) + NBST - 1) % 9;                                                      \
           const int sa_ = ((TAP) + NBST - 1 >= 9) ? sn : s;                                                \
           K22_ISSUE_B(sa_, ta_, fill);                                                                     \
+          if constexpr ((TAP) <= 9 - NBST) {                                                               \
+            _Pragma("unroll") for (int a_ = 0; a_ < APT; ++a_) {                                           \
+              constexpr int qb_ = ((TAP) <= 9 - NBST ? (TAP) : 0) * APT;                                   \
+              K22_ISSUE_A(qb_ + a_, sn, Anext);                                                            \
+            }                                                                                              \
+          }                                                                                                \
         }                                                                                                  \
-        if constexpr ((TAP) < A_SLOTS) K22_ISSUE_A(((TAP) < A_SLOTS ? (TAP) : 0), sn, Anext);              \
         const char* Bcur = Bst + cur * B_BYTES;                                                            \
         const int shift = ((TAP) / 3) * W2 + ((TAP) % 3);                                                  \
         const char* arow[MI];                                                                              \
@@ -438,12 +540,37 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const IgemmParams p) {
           arow[mi] = Acur + ar * 128;                                                                      \
           asw[mi] = (ar >> 1) & 7;                                                                         \
         }                                                                                                  \
+        if constexpr (PIPE) {                                                                              \
+          Frag<T> ca[MI], cb[NI];                                                                          \
+          _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ks += 2) {                                       \
+            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) ld_frag_at(ca[mi], arow[mi], asw[mi], ks, h); \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) ld_frag_at(cb[ni], Bcur + brow[ni], bsw, ks, h); \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                              \
+              _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], pb[ni], pa[mi]);     \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) ld_frag_at(pa[mi], arow[mi], asw[mi], ks + 1, h); \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) ld_frag_at(pb[ni], Bcur + brow[ni], bsw, ks + 1, h); \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                              \
+              _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], cb[ni], ca[mi]);     \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+          }                                                                                                \
+          /* the reads of the last k-step are complete before the slot can be refilled (after the next barrier) */ \
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
+        } else {                                                                                           \
         _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks) {                                            \
           Frag<T> a[MI], b[NI];                                                                            \
           _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) ld_frag_at(a[mi], arow[mi], asw[mi], ks, h);   \
           _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) ld_frag_at(b[ni], Bcur + brow[ni], bsw, ks, h); \
+          if constexpr (DBG_NOMMA) {                                                                       \
+            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(a[mi].v));             \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(b[ni].v));             \
+          } else {                                                                                         \
           _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                \
             _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], b[ni], a[mi]);         \
+          }                                                                                                \
+        }                                                                                                  \
         }                                                                                                  \
         if constexpr (TRACE) {                                                                             \
           /* stamp after the last MFMA has been ISSUED (issue blocks while the pipe is busy) */            \
@@ -464,7 +591,134 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const IgemmParams p) {
   }
 #undef K22_ISSUE_A
 #undef K22_ISSUE_B
+  if constexpr (PIPE) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], pb[ni], pa[mi]);
+  }
   halo_tail<T, BM>(p, acc, smem, bx, bz, img, v0, n0);
+}
+
+// ================================================================================================================
+// gemm8_kernel: plain GEMM  out[m][n] = sum_k A[m][k] W[n][k]  (1x1 convolutions: qkv / proj_out of the AttentionBlocks,
+// kandinsky2/model/unet.py:244-268) on the frame of the halo kernel: 8 waves (4 x 2), BM x 128 tile, BM in {256, 128},
+// both operands through an NST-deep LDS-DMA ring (one 128-byte-row K slab of A and of W per stage, counted vmcnt, one
+// raw barrier per slab) and the same epilogue through LDS (halo_tail): 16-byte stores, bias + residual, GroupNorm
+// partial sums of the stored values, or the qkv-projection layout.  Against igemm_kernel (4 waves, <= 128 x 128):
+// twice the FLOPs per L2->LDS byte at 256 x 128 and two waves per SIMD; m-tiles never straddle an image (rows of a
+// tile past the image are masked), so the per-tile statistics are per-image statistics.
+// ================================================================================================================
+template <typename T, int BM, int NST>
+__global__ __launch_bounds__(512) void gemm8_kernel(const IgemmParams p) {
+  using TR = TT<T>;
+  constexpr int BK = TR::BK, EPC = TR::EPC, KSTEPS = TR::KSTEPS;
+  constexpr int BN = HALO_BN, NW = HALO_NW, WM = 4, WN = 2;
+  constexpr int MI = BM / (WM * 32), NI = BN / (WN * 32);
+  constexpr int A_SLOTS = BM / 8 / NW, B_SLOTS = BN / 8 / NW, CH = A_SLOTS + B_SLOTS;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;
+  constexpr int GM = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int h = lane >> 5, l31 = lane & 31;
+
+  const int HW = p.H > 0 ? p.H * p.W : p.M;   // rows per image
+  const int TPI = (HW + BM - 1) / BM;
+  const int B = p.M / HW;
+  const int gx = B * TPI, gy = (p.N + BN - 1) / BN;
+  int L = p.xcd_remap ? xcd_remap_h(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int per_z = gx * gy;
+  const int bz = L / per_z;
+  L -= bz * per_z;
+  const int grp = L / (GM * gy);
+  const int first_m = grp * GM;
+  const int gsz = gx - first_m < GM ? gx - first_m : GM;
+  const int lin = L - grp * GM * gy;
+  const int bx = first_m + lin % gsz, by = lin / gsz;
+  const int img = bx / TPI, v0 = (bx - img * TPI) * BM;
+  const int n0 = by * BN;
+
+  const T* __restrict__ A = reinterpret_cast<const T*>(p.A0) + (int64_t)img * HW * p.lda0;
+  const T* __restrict__ Wp = reinterpret_cast<const T*>(p.Wp);
+  int aoff[A_SLOTS], boff[B_SLOTS];
+#pragma unroll
+  for (int i = 0; i < A_SLOTS; ++i) {
+    const int row = 8 * (wave + NW * i) + (lane >> 3);
+    int v = v0 + row;
+    if (v > HW - 1) v = HW - 1;                 // rows past the image re-read its last pixel; they are never stored
+    aoff[i] = v * (int)p.lda0 + ((lane & 7) ^ ((row >> 1) & 7)) * EPC;
+  }
+#pragma unroll
+  for (int i = 0; i < B_SLOTS; ++i) {
+    const int row = 8 * (wave + NW * i) + (lane >> 3);
+    int n = n0 + row;
+    if (n > p.Npad - 1) n = p.Npad - 1;
+    boff[i] = n * p.Kc + ((lane & 7) ^ ((row >> 1) & 7)) * EPC;
+  }
+  const int nslab = p.Kc / BK;
+  int s0 = 0, s1 = nslab;
+  if (p.splitk > 1) {
+    const int per = (nslab + p.splitk - 1) / p.splitk;
+    s0 = bz * per;
+    s1 = s0 + per < nslab ? s0 + per : nslab;
+  }
+
+  f32x16_t acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
+#define K22_ISSUE_G(SLAB, STAGE)                                                                           \
+  {                                                                                                        \
+    int sl_ = (SLAB);                                                                                      \
+    if (sl_ > s1 - 1) sl_ = s1 - 1;   /* past-the-end stages re-read the last slab: uniform counting */    \
+    const unsigned d_ = lds0 + (STAGE) * BUF + wave * 1024;                                                \
+    _Pragma("unroll") for (int i = 0; i < A_SLOTS; ++i)                                                    \
+        glds16_asm(A + aoff[i] + sl_ * BK, __builtin_amdgcn_readfirstlane(d_ + i * NW * 1024));            \
+    _Pragma("unroll") for (int i = 0; i < B_SLOTS; ++i)                                                    \
+        glds16_asm(Wp + boff[i] + sl_ * BK, __builtin_amdgcn_readfirstlane(d_ + A_BYTES + i * NW * 1024)); \
+  }
+  int arow[MI], brow[NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) arow[mi] = (wm * (BM / WM) + mi * 32 + l31) * 128;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) brow[ni] = A_BYTES + (wn * (BN / WN) + ni * 32 + l31) * 128;
+  const int sw = (l31 >> 1) & 7;
+
+  if (s0 < s1) {
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t) K22_ISSUE_G(s0 + t, t);
+    int cur = 0, fill = NST - 1;
+    for (int s = s0; s < s1; ++s) {
+      wait_vmcnt<(NST - 2) * CH>();
+      raw_barrier();
+      K22_ISSUE_G(s + NST - 1, fill);
+      const char* St = smem + cur * BUF;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        Frag<T> a[MI], b[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) ld_frag_at(a[mi], St + arow[mi], sw, ks, h);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) ld_frag_at(b[ni], St + brow[ni], sw, ks, h);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], b[ni], a[mi]);
+      }
+      cur = (cur + 1 == NST) ? 0 : cur + 1;
+      fill = (fill + 1 == NST) ? 0 : fill + 1;
+    }
+  }
+#undef K22_ISSUE_G
+  halo_tail<T, BM, true>(p, acc, smem, bx, bz, img, v0, n0);
 }
 
 // ================================================================================================================
@@ -911,6 +1165,61 @@ static int halo4_pick_nbst(const IgemmParams& p, int bm) {
   return 0;
 }
 
+// ---- gemm8_kernel ---------------------------------------------------------------------------------------------------
+// ring depth: 3 stages of 48 KB at BM = 256; at BM = 128 (32 KB per stage) either 4 stages (one workgroup per CU) or,
+// on request (p.stages == 2), 2 stages = 68 KB with the epilogue tile, so that TWO workgroups share a CU and one's
+// prologue / epilogue overlaps the other's K loop (short-K GEMMs: K = 768 is 12 slabs).
+static int gemm8_nst(int bm, int stages) { return bm == 256 ? 3 : (stages == 2 ? 2 : 4); }
+static size_t gemm8_smem_bytes(int bm, int nst) {
+  const size_t main_loop = (size_t)nst * (bm + HALO_BN) * 128;
+  const size_t epi = (size_t)bm * (HALO_BN * 4 + 16);
+  return main_loop > epi ? main_loop : epi;
+}
+int gemm8_tiles_per_image(const IgemmParams& p, int bm) { return ((p.H > 0 ? p.H * p.W : p.M) + bm - 1) / bm; }
+
+bool gemm8_supported(const IgemmParams& p, int dtype, int bm) {
+  const int BK = (dtype == K22_BF16) ? 64 : 32;
+  if (p.taps != 1 || (bm != 256 && bm != 128) || p.N < 128) return false;
+  if (p.K0 != p.Kc || p.S0 != nullptr || p.res_f32) return false;          // one A operand, no fused skip, T residual
+  if (p.out_mode != IG_OUT_ROWMAJOR && p.out_mode != IG_OUT_ROWMAJOR_F32 && p.out_mode != IG_OUT_QKV) return false;
+  if (p.N % 8 || p.ldo % 8 || (p.residual && p.ldr % 8) || p.Kc % BK || p.lda0 % 8) return false;
+  const int hw = p.H > 0 ? p.H * p.W : p.M;
+  if (hw <= 0 || p.M % hw) return false;
+  if (p.out_mode == IG_OUT_QKV && (p.att_T != hw || p.N % 384)) return false;  // an n-tile stays inside q, k or v
+  if ((int64_t)p.M * p.lda0 >= (1ll << 31) || (int64_t)p.Npad * p.Kc >= (1ll << 31)) return false;
+  return true;
+}
+
+template <typename T, int BM, int NST>
+static int launch_gemm8_cfg(const IgemmParams& p, int splitk, hipStream_t stream) {
+  const size_t smem = gemm8_smem_bytes(BM, NST);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_kernel<T, BM, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+    attr_set = true;
+  }
+  IgemmParams q = p;
+  q.splitk = splitk;
+  const int hw = p.H > 0 ? p.H * p.W : p.M;
+  const int nblocks = (p.M / hw) * gemm8_tiles_per_image(p, BM) * ((p.N + HALO_BN - 1) / HALO_BN) * splitk;
+  hipLaunchKernelGGL((gemm8_kernel<T, BM, NST>), dim3(nblocks), dim3(512), smem, stream, q);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+
+// Launches gemm8_kernel only (a split-K reduction, if any, is the caller's: launch_igemm).
+int launch_gemm8(const IgemmParams& p, int dtype, int bm, int splitk, hipStream_t stream) {
+  if (!gemm8_supported(p, dtype, bm)) return k22_set_error(K22_EINVAL, "gemm8: unsupported problem");
+  const int nst = gemm8_nst(bm, p.stages);
+  if (dtype == K22_BF16) {
+    if (bm == 256) return launch_gemm8_cfg<bf16_t, 256, 3>(p, splitk, stream);
+    return nst == 2 ? launch_gemm8_cfg<bf16_t, 128, 2>(p, splitk, stream) : launch_gemm8_cfg<bf16_t, 128, 4>(p, splitk, stream);
+  }
+  if (bm == 256) return launch_gemm8_cfg<float, 256, 3>(p, splitk, stream);
+  return nst == 2 ? launch_gemm8_cfg<float, 128, 2>(p, splitk, stream) : launch_gemm8_cfg<float, 128, 4>(p, splitk, stream);
+}
+
 bool conv3_halo_supported(const IgemmParams& p, int dtype, int bm) {
   const int BK = (dtype == K22_BF16) ? 64 : 32;
   if (p.taps != 9 || (bm != 256 && bm != 128)) return false;
@@ -928,12 +1237,12 @@ bool conv3_halo_supported(const IgemmParams& p, int dtype, int bm) {
 
 int conv3_halo_tiles_per_image(const IgemmParams& p, int bm) { return (p.H * (p.W + 2) + bm - 1) / bm; }
 
-template <typename T, int BM, int NBST>
+template <typename T, int BM, int NBST, int LW, int MODE>
 static int launch_halo_cfg(const IgemmParams& p, int splitk, hipStream_t stream) {
   const size_t smem = halo_smem_bytes(p, BM, NBST);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_kernel<T, BM, NBST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_kernel<T, BM, NBST, false, LW, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
     attr_set = true;
   }
@@ -941,17 +1250,17 @@ static int launch_halo_cfg(const IgemmParams& p, int splitk, hipStream_t stream)
   q.splitk = splitk;
   const int B = p.M / (p.H * p.W);
   const int nblocks = B * conv3_halo_tiles_per_image(p, BM) * ((p.N + HALO_BN - 1) / HALO_BN) * splitk;
-  hipLaunchKernelGGL((conv3_halo_kernel<T, BM, NBST>), dim3(nblocks), dim3(512), smem, stream, q);
+  hipLaunchKernelGGL((conv3_halo_kernel<T, BM, NBST, false, LW, MODE>), dim3(nblocks), dim3(512), smem, stream, q);
   K22_CHECK_LAUNCH();
   return K22_OK;
 }
 
-template <typename T, int BM>
+template <typename T, int BM, int LW, int MODE>
 static int launch_halo_nbst(const IgemmParams& p, int nbst, int splitk, hipStream_t stream) {
-  if (nbst == 2) return launch_halo_cfg<T, BM, 2>(p, splitk, stream);
-  if (nbst == 3) return launch_halo_cfg<T, BM, 3>(p, splitk, stream);
-  if (nbst <= 5) return launch_halo_cfg<T, BM, 4>(p, splitk, stream);
-  return launch_halo_cfg<T, BM, 6>(p, splitk, stream);
+  if (nbst == 2) return launch_halo_cfg<T, BM, 2, LW, MODE>(p, splitk, stream);
+  if (nbst == 3) return launch_halo_cfg<T, BM, 3, LW, MODE>(p, splitk, stream);
+  if (nbst <= 5) return launch_halo_cfg<T, BM, 4, LW, MODE>(p, splitk, stream);
+  return launch_halo_cfg<T, BM, 6, LW, MODE>(p, splitk, stream);
 }
 
 template <typename T, int BM, int RB>
@@ -1025,7 +1334,7 @@ int launch_conv3_halo_trace(const IgemmParams& p, int dtype, hipStream_t stream)
 
 // Launches the halo kernel only (the split-K reduction, if any, is the caller's: launch_igemm).
 // p.algo == 3 selects the 64-byte-row kernel (conv3_halo3_kernel), 4 the two-phase kernel (conv3_halo4_kernel),
-// anything else the lock-step 128-byte-row one.
+// 5 the 128-byte-row kernel with loader-wave specialisation, anything else the symmetric 128-byte-row one.
 int launch_conv3_halo(const IgemmParams& p, int dtype, int bm, int splitk, hipStream_t stream) {
   if (!conv3_halo_supported(p, dtype, bm)) return k22_set_error(K22_EINVAL, "conv3_halo: unsupported problem");
   if (p.algo == 4) {
@@ -1042,6 +1351,22 @@ int launch_conv3_halo(const IgemmParams& p, int dtype, int bm, int splitk, hipSt
   }
   int nbst = halo_pick_nbst(p, bm);
   if (p.stages >= 2 && p.stages < nbst) nbst = p.stages == 5 ? 4 : p.stages;  // tuning knob: shallower ring on request
-  if (dtype == K22_BF16) return bm == 256 ? launch_halo_nbst<bf16_t, 256>(p, nbst, splitk, stream) : launch_halo_nbst<bf16_t, 128>(p, nbst, splitk, stream);
-  return bm == 256 ? launch_halo_nbst<float, 256>(p, nbst, splitk, stream) : launch_halo_nbst<float, 128>(p, nbst, splitk, stream);
+  if (p.algo == 5) {  // loader-wave specialisation (waves 0-3 issue all LDS-DMA)
+    if (dtype == K22_BF16) return bm == 256 ? launch_halo_nbst<bf16_t, 256, 4, 0>(p, nbst, splitk, stream) : launch_halo_nbst<bf16_t, 128, 4, 0>(p, nbst, splitk, stream);
+    return bm == 256 ? launch_halo_nbst<float, 256, 4, 0>(p, nbst, splitk, stream) : launch_halo_nbst<float, 128, 4, 0>(p, nbst, splitk, stream);
+  }
+  if (p.algo == 6) {  // explicit fragment pipeline across the barrier + asm LDS-DMA
+    if (dtype == K22_BF16) return bm == 256 ? launch_halo_nbst<bf16_t, 256, 8, 1>(p, nbst, splitk, stream) : launch_halo_nbst<bf16_t, 128, 8, 1>(p, nbst, splitk, stream);
+    return bm == 256 ? launch_halo_nbst<float, 256, 8, 1>(p, nbst, splitk, stream) : launch_halo_nbst<float, 128, 8, 1>(p, nbst, splitk, stream);
+  }
+  if (p.algo == 8 || p.algo == 9) {  // measurement-only variants (wrong results): 8 = no LDS-DMA in the loop, 9 = no MFMA
+    if (dtype != K22_BF16 || bm != 256) return k22_set_error(K22_EINVAL, "conv3_halo: debug variants are bf16, BM = 256 only");
+    return p.algo == 8 ? launch_halo_nbst<bf16_t, 256, 8, 3>(p, nbst, splitk, stream) : launch_halo_nbst<bf16_t, 256, 8, 4>(p, nbst, splitk, stream);
+  }
+  if (p.algo == 7) {  // compiler schedule + asm LDS-DMA
+    if (dtype == K22_BF16) return bm == 256 ? launch_halo_nbst<bf16_t, 256, 8, 2>(p, nbst, splitk, stream) : launch_halo_nbst<bf16_t, 128, 8, 2>(p, nbst, splitk, stream);
+    return bm == 256 ? launch_halo_nbst<float, 256, 8, 2>(p, nbst, splitk, stream) : launch_halo_nbst<float, 128, 8, 2>(p, nbst, splitk, stream);
+  }
+  if (dtype == K22_BF16) return bm == 256 ? launch_halo_nbst<bf16_t, 256, 8, 0>(p, nbst, splitk, stream) : launch_halo_nbst<bf16_t, 128, 8, 0>(p, nbst, splitk, stream);
+  return bm == 256 ? launch_halo_nbst<float, 256, 8, 0>(p, nbst, splitk, stream) : launch_halo_nbst<float, 128, 8, 0>(p, nbst, splitk, stream);
 }

@@ -203,8 +203,10 @@ struct K22UNet {
   }
 
   // GEMM over unpadded rows (1x1 conv / linear); `in` may be a virtual concat.
+  // `stats` (optional) receives the GroupNorm partial sums of the output (image-shaped inputs only: in.H * in.W rows
+  // per image); whether a configuration that can deliver them exists is reported by the returned want_stats.
   Tuned* op_gemm(OpList& L, const Act& in, int M, int N, const std::string& pfx,
-                 const Act* residual, Slot* dst, int ldo = 0, int out_mode = IG_OUT_ROWMAJOR) {
+                 const Act* residual, Slot* dst, int ldo = 0, int out_mode = IG_OUT_ROWMAJOR, Slot* stats = nullptr) {
     tuned.emplace_back();
     Tuned* t = &tuned.back();
     IgemmParams& p = t->p;
@@ -212,10 +214,15 @@ struct K22UNet {
     p.M = M; p.N = N; p.Npad = (N + 63) / 64 * 64; p.Kc = in.C(); p.K0 = in.C0; p.taps = 1;
     p.lda0 = in.C0; p.lda1 = in.C1; p.ldo = ldo ? ldo : N; p.ldr = N; p.out_mode = out_mode;
     p.act = K22_ACT_NONE;
+    if (in.H > 0 && in.W > 0 && M % (in.H * in.W) == 0 && M / (in.H * in.W) == B) { p.H = in.H; p.W = in.W; }  // rows per image
+    if (out_mode == IG_OUT_QKV) p.att_T = in.H * in.W;
     p.Wp = W_(pfx + ".weight"); p.bias = Wf(pfx + ".bias");
+    t->want_stats = stats != nullptr && p.H > 0;
     make_candidates(*t);
+    if (t->want_stats && t->cands.empty()) { t->want_stats = false; make_candidates(*t); }
     default_cfg(*t);
     need(s_splitk, max_splitk_bytes(*t));
+    if (t->want_stats) need(stats, (size_t)B * max_rpi(*t) * N * 2 * sizeof(float));
     need(dst, (size_t)M * p.ldo * esz);
     const Act a = in;
     Slot* rs = residual ? residual->s0 : nullptr;
@@ -226,6 +233,7 @@ struct K22UNet {
       q.A0 = ptr(a.s0); q.A1 = a.s1 ? ptr(a.s1) : nullptr;
       q.residual = rs ? ptr(rs) : nullptr; q.out = ptr(dst); q.partial = ptr<float>(s_splitk);
       if (t->aux0) { q.kall = ptr(reinterpret_cast<Slot*>(t->aux0)); q.vtall = ptr(reinterpret_cast<Slot*>(t->aux1)); }
+      q.stats = t->want_stats ? ptr<float>(stats) : nullptr;
       return launch_igemm(q, dt, st);
     };
     L.push_back(Op([=](hipStream_t st) { return t->run(st); }, OP_GEMM, 2.0 * p.M * (double)p.N * p.Kc, 0.0, 1));
@@ -285,7 +293,7 @@ struct K22UNet {
   // AttentionBlock (unet.py:223-269) + QKVAttention (:272-340).  The qkv projection writes q row-major and k / v
   // straight into this block's attention operands (K_all, V^T_all) behind the context keys, which were projected
   // (encoder_kv) and packed once per conditioning: no per-step packing kernel.
-  Act attnblock(const std::string& pfx, const Act& in, Slot* dst) {
+  Act attnblock(const std::string& pfx, const Act& in, Slot* dst, Slot* dst_stats = nullptr) {
     const int C = in.C0, T = in.H * in.W, Hh = C / 64, S = cfg.ctx_len;
     const int Tk = S + T, Tkp = (Tk + 63) / 64 * 64;
     n_attn++;
@@ -322,8 +330,10 @@ struct K22UNet {
       return launch_attention(ap, dt, st);
     }, OP_ATTN, 4.0 * Bn * Hh * (double)T * Tk * 64.0, 0.0, 1));
     Act a; a.s0 = s_ATT; a.C0 = C; a.H = in.H; a.W = in.W;
-    op_gemm(ops, a, B * T, C, pfx + ".proj_out", &in, dst);
+    // proj_out + residual; its epilogue also delivers the GroupNorm partial sums the next ResBlock needs
+    Tuned* tp = op_gemm(ops, a, B * T, C, pfx + ".proj_out", &in, dst, 0, IG_OUT_ROWMAJOR, dst_stats);
     Act out; out.s0 = dst; out.C0 = C; out.H = in.H; out.W = in.W;
+    if (tp->want_stats) { out.p0 = tp; out.st0 = dst_stats; }
     return out;
   }
 
@@ -438,7 +448,7 @@ struct K22UNet {
         if (has_attn(ds)) {
           Slot* rd = next_h();
           Act r = resblock(pfx + ".0", h, co, 0, film_cursor, rd, cur_hst());
-          h = attnblock(pfx + ".1", r, d);
+          h = attnblock(pfx + ".1", r, d, new_slot());
         } else {
           h = resblock(pfx + ".0", h, co, 0, film_cursor, d, new_slot());
         }
@@ -455,7 +465,8 @@ struct K22UNet {
     {
       Slot* d0 = next_h(); Slot* st0 = cur_hst();
       Act r = resblock("middle_block.0", h, ch, 0, film_cursor, d0, st0);
-      Act a = attnblock("middle_block.1", r, next_h());
+      Slot* da = next_h(); Slot* sta = cur_hst();
+      Act a = attnblock("middle_block.1", r, da, sta);
       Slot* d2 = next_h(); Slot* st2 = cur_hst();
       h = resblock("middle_block.2", a, ch, 0, film_cursor, d2, st2);
     }
@@ -471,7 +482,7 @@ struct K22UNet {
         const std::string pfx = "output_blocks." + std::to_string(blk);
         { Slot* d = next_h(); Slot* dst_st = cur_hst(); h = resblock(pfx + ".0", cat, co, 0, film_cursor, d, dst_st); }
         int sub = 1;
-        if (has_attn(ds)) { h = attnblock(pfx + "." + std::to_string(sub), h, next_h()); ++sub; }
+        if (has_attn(ds)) { Slot* da = next_h(); Slot* sta = cur_hst(); h = attnblock(pfx + "." + std::to_string(sub), h, da, sta); ++sub; }
         if (l && i == cfg.num_res_blocks) {
           { Slot* d = next_h(); Slot* dst_st = cur_hst(); h = resblock(pfx + "." + std::to_string(sub), h, co, 2, film_cursor, d, dst_st); }
           ds /= 2;

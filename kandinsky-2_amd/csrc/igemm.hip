@@ -420,7 +420,9 @@ static int g_xcd_remap = 1;
 static int g_conv_algo = 0;
 void igemm_set_default_stages(int v) { g_stages_override = (v >= 2 && v <= 4) ? v : -1; }
 void igemm_set_xcd_remap(int v) { g_xcd_remap = v ? 1 : 0; }
-void igemm_set_conv_algo(int v) { g_conv_algo = (v >= 0 && v <= 4) ? v : 0; }
+void igemm_set_conv_algo(int v) { g_conv_algo = (v >= 0 && v <= 9) ? v : 0; }
+static int g_gemm_algo = 0;   // 0 = generic igemm_kernel, 10 = gemm8_kernel where it applies (unit tests / kernel benches)
+void igemm_set_gemm_algo(int v) { g_gemm_algo = (v == 10) ? 10 : 0; }
 
 static int g_default_stages() {
   static int v = -1;
@@ -444,7 +446,7 @@ static IgemmPlan igemm_plan(const IgemmParams& p, int dtype) {
   const int algo = p.algo ? p.algo : g_conv_algo;
   if (p.taps == 9 && algo != 1 && p.N >= 128) {
     IgemmParams ph = p;
-    ph.algo = (algo == 3 || algo == 4) ? algo : 2;
+    ph.algo = (algo >= 3 && algo <= 9) ? algo : 2;
     int bm = 0;
     if (p.force_bm == 256 || p.force_bm == 128) {
       if (conv3_halo_supported(ph, dtype, p.force_bm) && (algo >= 2 || p.force_bn == 0)) bm = p.force_bm;
@@ -466,6 +468,22 @@ static IgemmPlan igemm_plan(const IgemmParams& p, int dtype) {
       }
       if (pl.splitk > nslab) pl.splitk = nslab;
       if (pl.splitk < 1) pl.splitk = 1;
+      return pl;
+    }
+  }
+  // ---- plain GEMM on the 8-wave frame (p.algo == 10: tuner candidate; or the "gemm_algo" option) --------------
+  if (p.taps == 1 && (p.algo == 10 || (p.algo == 0 && g_gemm_algo == 10))) {
+    int bm = 0;
+    if (p.force_bm == 256 || p.force_bm == 128) { if (gemm8_supported(p, dtype, p.force_bm)) bm = p.force_bm; }
+    else if (gemm8_supported(p, dtype, 256)) {
+      const int hw = p.H > 0 ? p.H * p.W : p.M;
+      bm = ((p.M / hw) * ((hw + 255) / 256) * ((p.N + 127) / 128) >= 400 || hw % 256 == 0) ? 256 : 128;
+    }
+    if (bm) {
+      pl.halo = 10; pl.bm = bm; pl.bn = 128;
+      pl.splitk = p.splitk > 0 ? p.splitk : 1;
+      if (p.out_mode == IG_OUT_QKV) pl.splitk = 1;
+      if (pl.splitk > p.Kc / BK) pl.splitk = p.Kc / BK;
       return pl;
     }
   }
@@ -501,14 +519,23 @@ int igemm_choose_splitk(const IgemmParams& p, int dtype) {
 }
 
 static bool reduce_rows_ok(const IgemmParams& p) {
-  const int hw = (p.taps == 9) ? p.H * p.W : 0;
+  // 3x3 convolutions always finish through the row-tiled reduction; plain GEMMs only when they owe GroupNorm sums
+  const int hw = (p.taps == 9 || p.stats != nullptr) ? p.H * p.W : 0;
   return hw > 0 && hw % 16 == 0 && (p.N & 3) == 0 && (p.ldo & 3) == 0 && (p.ldr & 3) == 0 &&
          (p.out_mode == IG_OUT_ROWMAJOR || p.out_mode == IG_OUT_ROWMAJOR_F32);
 }
 
 int igemm_stats_rows_per_image(const IgemmParams& p, int dtype) {
-  if (p.taps != 9) return 0;
   const IgemmPlan pl = igemm_plan(p, dtype);
+  if (p.taps == 1) {
+    if (pl.halo != 10 || p.H <= 0 || p.out_mode == IG_OUT_QKV) return 0;
+    if (pl.splitk > 1) {
+      IgemmParams q = p;
+      q.stats = reinterpret_cast<float*>(1);   // "owes GroupNorm sums": the row-tiled reduction
+      return reduce_rows_ok(q) ? p.H * p.W / 16 : 0;
+    }
+    return gemm8_tiles_per_image(p, pl.bm);
+  }
   if (pl.splitk > 1) return reduce_rows_ok(p) ? p.H * p.W / 16 : 0;
   if (pl.halo) return conv3_halo_tiles_per_image(p, pl.bm);
   return 0;
@@ -583,6 +610,15 @@ int launch_igemm(const IgemmParams& p, int dtype, hipStream_t stream) {
   if (p.S0 != nullptr && !pl.halo) return k22_set_error(K22_EINVAL, "igemm: the fused 1x1 skip connection needs the halo kernel");
   if (p.stats != nullptr && pl.splitk == 1 && !pl.halo)
     return k22_set_error(K22_EINVAL, "igemm: GroupNorm partial sums requested from a configuration that cannot produce them");
+  if (pl.halo == 10) {
+    IgemmParams q = p;
+    q.splitk = pl.splitk;
+    q.xcd_remap = g_xcd_remap;
+    if (q.stages < 2 && g_stages_override >= 0) q.stages = g_stages_override;   // "igemm_stages" option (benches / tests)
+    int rc = launch_gemm8(q, dtype, pl.bm, pl.splitk, stream);
+    if (rc || pl.splitk == 1) return rc;
+    return dtype == K22_BF16 ? launch_reduce<bf16_t>(q, stream) : launch_reduce<float>(q, stream);
+  }
   if (pl.halo) {
     IgemmParams q = p;
     q.splitk = pl.splitk;

@@ -69,6 +69,11 @@ bool conv3_halo_supported(const IgemmParams& p, int dtype, int bm);
 int conv3_halo_tiles_per_image(const IgemmParams& p, int bm);
 int launch_conv3_halo(const IgemmParams& p, int dtype, int bm, int splitk, hipStream_t stream);
 int launch_conv3_halo_trace(const IgemmParams& p, int dtype, hipStream_t stream);
+// 8-wave BM x 128 GEMM on the halo kernels' frame (conv3_halo.hip: gemm8_kernel); p.algo == 10 selects it in launch_igemm
+bool gemm8_supported(const IgemmParams& p, int dtype, int bm);
+int gemm8_tiles_per_image(const IgemmParams& p, int bm);
+int launch_gemm8(const IgemmParams& p, int dtype, int bm, int splitk, hipStream_t stream);
+void igemm_set_gemm_algo(int v);
 void igemm_set_conv_algo(int v);       // tuning knob: 0 auto, 1 generic, 2 halo
 void igemm_set_default_stages(int v);  // tuning knob: 2..4 LDS-DMA stages, -1 env/default
 void igemm_set_xcd_remap(int v);       // tuning knob: XCD-aware block renumbering (default on)

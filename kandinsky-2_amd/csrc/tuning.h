@@ -45,7 +45,9 @@ inline void tuned_make_candidates(Tuned& t, int dtype) {
     const int B = p.M / (p.H * p.W);
     // algo 2 = lock-step halo kernel; 3 = 64-byte rows / filter-row iterations (only ever wins at the smallest level,
     // deep split-K); 4 = two-phase kernel (measured 12-20 % slower than 2 on every shape: not a candidate)
-    for (int algo : {2, 3}) {
+    // 5 = loader-wave specialisation (measured 2-5 % slower: not a candidate); 7 = LDS-DMA from inline asm (exact
+    // lgkmcnt for the fragment reads, +1-3 %); 6 = 7 + explicit fragment pipeline across the barrier
+    for (int algo : {2, 7, 6, 3}) {
       if (algo == 3 && p.H > 16) continue;
       IgemmParams ph = p;
       ph.algo = algo;
@@ -56,6 +58,24 @@ inline void tuned_make_candidates(Tuned& t, int dtype) {
         for (int sk : {1, 2, 3, 4, 5, 6, 8, 10, 12}) {
           if (sk > nsplit_max || (sk > 1 && nb * sk > 800) || (sk > 1 && nb >= 256)) continue;
           Cfg c; c.algo = algo; c.bm = bm; c.bn = 0; c.splitk = sk; c.stages = 0;
+          all.push_back(c);
+        }
+      }
+    }
+  }
+  if (p.taps == 1) {
+    // 8-wave BM x 128 tile kernel (gemm8_kernel)
+    const int hw = p.H > 0 ? p.H * p.W : p.M;
+    for (int bm : {256, 128}) {
+      IgemmParams q = p;
+      q.algo = 10; q.force_bm = bm;
+      if (!gemm8_supported(q, dtype, bm)) continue;
+      const int nb = (p.M / hw) * gemm8_tiles_per_image(p, bm) * ((p.N + 127) / 128);
+      for (int sk : {1, 2, 3, 4, 6}) {
+        if (sk > 1 && (nkt / sk < 4 || nb * sk > 800 || nb >= 256 || p.out_mode == IG_OUT_QKV)) continue;
+        for (int stg : {0, 2}) {   // 2: two co-resident workgroups per CU with a 2-deep ring (BM = 128 only)
+          if (stg == 2 && bm != 128) continue;
+          Cfg c; c.algo = 10; c.bm = bm; c.bn = 0; c.splitk = sk; c.stages = stg;
           all.push_back(c);
         }
       }
@@ -182,7 +202,7 @@ inline int tune_igemm_ops(std::deque<Tuned>& tuned, int dtype, void* flush, size
       // a cached line from an older build may name a configuration this build would not generate: check it
       const Cfg& c = it->second.first;
       bool ok = false;
-      for (auto& k : t.cands) ok = ok || (k.algo == c.algo && k.bm == c.bm && k.bn == c.bn && k.splitk == c.splitk && (k.stages == c.stages || c.algo >= 2));
+      for (auto& k : t.cands) ok = ok || (k.algo == c.algo && k.bm == c.bm && k.bn == c.bn && k.splitk == c.splitk && (k.stages == c.stages || (c.algo >= 2 && c.algo != 10)));
       if (ok) { t.cfg = c; t.best_us = it->second.second * 1e3f; }
     }
     tuned_finish_cfg(t, dtype);
@@ -209,7 +229,7 @@ inline std::string tuning_report_text(const std::deque<Tuned>& tuned) {
   for (auto& t : tuned) {
     char line[256];
     snprintf(line, sizeof line, "%4d %6d %5d %5d %4d %4d %5d | %4s %3d %3d %6d %3d | %8.1f", t.p.taps, t.p.M, t.p.N, t.p.Kc,
-             t.p.H, t.p.W, t.want_stats ? 1 : 0, t.cfg.algo == 2 ? "halo" : (t.cfg.algo == 3 ? "hal3" : (t.cfg.algo == 4 ? "hal4" : (t.cfg.algo == 1 ? "gen" : "auto"))), t.cfg.bm, t.cfg.bn,
+             t.p.H, t.p.W, t.want_stats ? 1 : 0, t.cfg.algo == 2 ? "halo" : (t.cfg.algo == 3 ? "hal3" : (t.cfg.algo == 4 ? "hal4" : (t.cfg.algo == 5 ? "hal5" : (t.cfg.algo == 6 ? "hal6" : (t.cfg.algo == 7 ? "hal7" : (t.cfg.algo == 10 ? "gem8" : (t.cfg.algo == 1 ? "gen" : "auto"))))))), t.cfg.bm, t.cfg.bn,
              t.cfg.splitk, t.cfg.stages, t.best_us);
     if (!seen.count(line)) order.push_back(line);
     seen[line]++;

@@ -77,7 +77,7 @@ def test_conv3x3(dtype, B, Cin, Cout, H, W, bm, bn, splitk):
     (2, 128, 128, 16, 16, 256, 1), (1, 64, 192, 9, 13, 128, 1), (2, 256, 128, 8, 8, 256, 3), (3, 192, 256, 6, 10, 128, 2),
     (2, 384, 384, 24, 24, 256, 1), (1, 128, 256, 96, 96, 256, 1), (2, 128, 128, 12, 12, 0, 0), (1, 128, 136, 48, 48, 128, 1),
 ])
-@pytest.mark.parametrize("algo", [2, 3, 4])
+@pytest.mark.parametrize("algo", [2, 3, 4, 5, 6, 7])
 def test_conv3x3_halo(dtype, B, Cin, Cout, H, W, bm, splitk, algo):
     """LDS-resident halo kernels (conv3_halo.hip; algo 2 = 128-byte rows, 3 = 64-byte rows / filter-row iterations):
     junk columns, image boundaries, ragged last tile, split-K."""
@@ -91,7 +91,7 @@ def test_conv3x3_halo(dtype, B, Cin, Cout, H, W, bm, splitk, algo):
 @pytest.mark.parametrize("B,Cin,Cout,H,W,bm,splitk", [
     (2, 128, 128, 16, 16, 256, 1), (2, 128, 256, 24, 24, 128, 1), (2, 256, 128, 12, 12, 256, 2), (1, 128, 128, 48, 48, 256, 1),
 ])
-@pytest.mark.parametrize("algo", [2, 3, 4])
+@pytest.mark.parametrize("algo", [2, 3, 4, 5, 6, 7])
 def test_conv3x3_groupnorm_partial_sums(dtype, B, Cin, Cout, H, W, bm, splitk, algo):
     """The conv epilogue's GroupNorm side output = per-image, per-channel sum / sum of squares of the STORED tensor."""
     x, w = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
@@ -110,7 +110,7 @@ def test_conv3x3_groupnorm_partial_sums(dtype, B, Cin, Cout, H, W, bm, splitk, a
     (2, 128, 128, 64, 0, 16, 16, 256, 1), (1, 128, 256, 128, 64, 24, 24, 128, 1), (2, 256, 128, 192, 128, 12, 12, 256, 2),
     (2, 128, 128, 320, 0, 8, 8, 128, 4),
 ])
-@pytest.mark.parametrize("algo", [2, 3, 4])
+@pytest.mark.parametrize("algo", [2, 3, 4, 5, 6, 7])
 def test_conv3x3_with_fused_skip_connection(dtype, B, Cin, Cout, SK0, SK1, H, W, bm, splitk, algo):
     """out = conv3x3(h) + conv1x1(cat(x0, x1)): the channel-changing ResBlock tail in one halo-kernel launch."""
     import torch.nn.functional as F
@@ -238,3 +238,84 @@ def test_sampler_step_matches_oracle(N, H, W, inpaint, step):
                                   N, H * W, hp.stream()))
     assert (x0o.cpu() - ref_x0).abs().max().item() <= 5e-6
     assert (xo.cpu() - ref).abs().max().item() <= 1e-5
+
+
+# ---- 8-wave BM x 128 GEMM kernel (gemm8_kernel, "gemm_algo" = 10) ------------------------------------------------
+def _with_gemm8(fn):
+    _lib.check(_lib.lib().k22_set_option(b"gemm_algo", 10))
+    try:
+        return fn()
+    finally:
+        _lib.check(_lib.lib().k22_set_option(b"gemm_algo", 0))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K,bm,splitk", [
+    (256, 256, 128, 256, 1), (300, 192, 192, 128, 1), (77, 768, 1024, 128, 1), (1000, 136, 384, 256, 1),
+    (288, 384, 1152, 128, 4), (512, 128, 64, 0, 1), (4608, 768, 768, 256, 2), (150, 1536, 1536, 256, 3),
+])
+@pytest.mark.parametrize("stages", [-1, 2])
+def test_gemm8(dtype, M, N, K, bm, splitk, stages):
+    A, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    _lib.check(_lib.lib().k22_set_option(b"igemm_stages", stages))   # 2: the two-workgroups-per-CU variant of BM = 128
+    try:
+        out, a, w, r = _with_gemm8(lambda: hp.gemm(A, W, bias, res, dtype=dtype, splitk=splitk, bm=bm, bn=0))
+    finally:
+        _lib.check(_lib.lib().k22_set_option(b"igemm_stages", -1))
+    close(out, a @ w.T + bias + r, dtype, f"gemm8 {M}x{N}x{K}")
+
+
+def test_gemm8_asymmetric_layout():
+    K = 128
+    A = torch.eye(K).cuda()
+    W = (torch.arange(128 * K, dtype=torch.float32).reshape(128, K) % 251 - 125).cuda() / 16
+    out, a, w, _ = _with_gemm8(lambda: hp.gemm(A, W, dtype=_lib.K22_F32, bm=128))
+    assert torch.equal(out, w.T.contiguous())
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,H,W_,N,K,bm,splitk", [(2, 12, 12, 384, 256, 256, 1), (2, 12, 12, 256, 512, 128, 2), (3, 24, 24, 128, 128, 256, 1),
+                                                   (2, 48, 48, 768, 768, 256, 1), (1, 20, 12, 136, 192, 128, 1)])
+def test_gemm8_groupnorm_partial_sums(dtype, B, H, W_, N, K, bm, splitk):
+    """proj_out epilogue: per-image, per-channel (sum, sum of squares) of the STORED outputs, reduced over the tile rows."""
+    import ctypes as C
+    T_ = hp.tdt(dtype)
+    M = B * H * W_
+    A, W, bias, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
+    a, w, r = A.to(T_).contiguous(), hp.pad_rows(W.to(T_)), res.to(T_).contiguous()
+    out = torch.empty(M, N, dtype=T_, device="cuda")
+    partial = torch.empty(max(1, splitk) * M * N + 64, dtype=torch.float32, device="cuda")
+    cap = B * (H * W_ // 16 + 2)
+    sbuf = torch.full((cap, N, 2), float("nan"), dtype=torch.float32, device="cuda")
+    rpi = C.c_int(0)
+    _lib.check(_lib.lib().k22_gemm_gnstats(a.data_ptr(), w.data_ptr(), bias.data_ptr(), r.data_ptr(), out.data_ptr(), partial.data_ptr(),
+                                           B, H, W_, N, w.shape[0], K, splitk, bm, sbuf.data_ptr(), cap, C.byref(rpi), dtype, hp.stream()))
+    ref = a.float() @ W.to(T_).float().T + bias + r.float()
+    close(out.float(), ref, dtype, "gemm8+stats out")
+    st = sbuf[: B * rpi.value].view(B, rpi.value, N, 2).double().sum(1)
+    o = out.double().view(B, H * W_, N)
+    assert torch.isfinite(st).all()
+    tol = 1e-3 if dtype == _lib.K22_BF16 else 1e-4
+    assert (st[..., 0] - o.sum(1)).abs().max().item() <= tol * (o.abs().sum(1).max().item() + 1)
+    assert (st[..., 1] - (o * o).sum(1)).abs().max().item() <= tol * ((o * o).sum(1).max().item() + 1)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,H,T,S,K,bm", [(2, 2, 144, 87, 128, 256), (1, 6, 100, 5, 192, 128), (2, 6, 64, 87, 384, 128), (2, 12, 2304, 87, 768, 256)])
+def test_gemm8_qkv_projection_writes_attention_operands(dtype, B, H, T, S, K, bm):
+    T_ = hp.tdt(dtype)
+    C, Tkp = 64 * H, (S + T + 63) // 64 * 64
+    x, W, bias = rnd(B * T, K, seed=1), rnd(3 * C, K, seed=2, scale=K ** -0.5), rnd(3 * C, seed=3)
+    xt, wt = x.to(T_).contiguous(), W.to(T_).contiguous()
+    q = torch.empty(B * T, C, dtype=T_, device="cuda")
+    kall = torch.full((B, H, Tkp, 64), 7.0, dtype=T_, device="cuda")
+    vtall = torch.full((B, H, 64, Tkp), 7.0, dtype=T_, device="cuda")
+    _with_gemm8(lambda: _lib.check(_lib.lib().k22_qkv_project(xt.data_ptr(), wt.data_ptr(), bias.data_ptr(), q.data_ptr(), kall.data_ptr(),
+                                                              vtall.data_ptr(), B, H, T, S, K, bm, 0, dtype, hp.stream())))
+    ref = (xt.float() @ wt.float().T + bias).view(B, T, 3, H, 64)
+    close(q.float().view(B, T, H, 64), ref[:, :, 0], dtype, "q")
+    close(kall.float()[:, :, S:S + T], ref[:, :, 1].permute(0, 2, 1, 3), dtype, "k")
+    close(vtall.float()[:, :, :, S:S + T], ref[:, :, 2].permute(0, 2, 3, 1), dtype, "v^T")
+    assert (kall[:, :, :S] == 7).all() and (kall[:, :, S + T:] == 7).all()
+    assert (vtall[:, :, :, :S] == 7).all() and (vtall[:, :, :, S + T:] == 7).all()

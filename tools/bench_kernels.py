@@ -82,9 +82,9 @@ def main():
     for c in a.configs.split(","):
         if c == "auto":
             cfgs.append((0, 0, 0, 0))
-        elif c[0] in "hgk":   # h256 / h128x2 : halo kernel (g = 64-byte-row variant), BM, split-K
+        elif c[0] in "hgklpaxy":   # h256 / h128x2 : halo kernel (g = 64-byte-row variant), BM, split-K
             parts = c[1:].split("x")
-            cfgs.append((int(parts[0]), 0, int(parts[1]) if len(parts) > 1 else 0, {"h": 2, "g": 3, "k": 4}[c[0]]))
+            cfgs.append((int(parts[0]), 0, int(parts[1]) if len(parts) > 1 else 0, {"h": 2, "g": 3, "k": 4, "l": 5, "p": 6, "a": 7, "x": 8, "y": 9}[c[0]]))
         else:                            # 128x64x8 : generic implicit GEMM
             parts = c.split("x")
             cfgs.append((int(parts[0]), int(parts[1]), int(parts[2]) if len(parts) > 2 else 1, 1))
@@ -143,7 +143,7 @@ def bench_gemm(a, arch, L, dt, T):
         if c == "auto":
             cfgs.append((0, 0, 0))
         else:
-            parts = c.split("x")
+            parts = c.split("x")   # 128x64x1 generic tile; 256x0x1 / 128x0x2 = gemm8_kernel (bn = 0)
             cfgs.append((int(parts[0]), int(parts[1]), int(parts[2]) if len(parts) > 2 else 1))
     st = torch.cuda.current_stream().cuda_stream
     tot = {c: 0.0 for c in cfgs}
@@ -159,6 +159,8 @@ def bench_gemm(a, arch, L, dt, T):
         totfl += fl * cnt
         row = []
         for c in cfgs:
+            _lib.check(L.k22_set_option(b"gemm_algo", 10 if (c[0] and not c[1]) else 0))
+
             def run():
                 _lib.check(L.k22_gemm(x.data_ptr(), None, w.data_ptr(), bias.data_ptr(), None, out.data_ptr(), part.data_ptr(),
                                       M, N, w.shape[0], K, 0, K, 0, N, N, 0, 0, c[2], c[0], c[1], dt, st))
