@@ -52,8 +52,27 @@ template <typename T> __device__ __forceinline__ float exp2_t(float x);
 template <> __device__ __forceinline__ float exp2_t<bf16_t>(float x) { return __builtin_amdgcn_exp2f(x); }
 template <> __device__ __forceinline__ float exp2_t<float>(float x) { return exp2f(x); }
 
+// The online softmax is the issue-bound part of this kernel (measured at T = 2304: waves ISSUING 49 % of their cycles,
+// matrix pipe 18 % busy), so its instruction count is what matters:
+//   * v_max3_f32 from inline asm: fmaxf() costs an extra canonicalising v_max per operand and never fuses to max3;
+//   * the row sum as packed adds (v_pk_add_f32: two scores per instruction);
+//   * __launch_bounds__(256, 2): with two workgroups per CU guaranteed the compiler keeps the S^T accumulators in VGPRs
+//     (VGPR-form MFMA); at the default bound it parks them in AGPRs and every score pays a v_accvgpr_read.
+// Together: 330 -> ~150 VALU instructions per 64-key tile per wave, 96 -> 82 us at T = 2304 (12 heads, batch 2).
+// (Double-buffering the K / V^T tiles for one barrier per tile was measured too: no gain, the kernel is issue-bound.)
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float max2f(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void attention_kernel(AttentionParams p) {
+__global__ __launch_bounds__(256, 2) void attention_kernel(AttentionParams p) {
   using TR = TT<T>;
   constexpr int EPC = TR::EPC, BK = TR::BK, KSTEPS = TR::KSTEPS;
   constexpr int NSUB = 64 / BK;   // 128-byte sub-tiles per 64-element row (1 bf16, 2 fp32)
@@ -140,12 +159,15 @@ __global__ __launch_bounds__(256) void attention_kernel(AttentionParams p) {
           if (dead) s[kb][r] = -INFINITY;
         }
     }
-    float mloc = fmaxf(s[0][0], s[1][0]);
+    float mq[4];   // four independent max3 chains (a single chain is 16 dependent instructions)
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, fmaxf(s[0][r], s[1][r]));
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    for (int c = 0; c < 4; ++c) mq[c] = max2f(s[0][c], s[1][c]);
+#pragma unroll
+    for (int r = 4; r < 16; ++r) mq[r & 3] = max3f(mq[r & 3], s[0][r], s[1][r]);
+    float mloc = max2f(max3f(mq[0], mq[1], mq[2]), mq[3]);
+    mloc = max2f(mloc, __shfl_xor(mloc, 32, 64));
     if (__any(mloc > m_run)) {
-      const float m_new = fmaxf(m_run, mloc);
+      const float m_new = max2f(m_run, mloc);
       const float alpha = exp2_t<T>((m_run - m_new) * cexp);
       l_run *= alpha;
       m_run = m_new;
@@ -153,16 +175,19 @@ __global__ __launch_bounds__(256) void attention_kernel(AttentionParams p) {
       for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
     }
     const float mc = m_run * cexp;
-    float lsum = 0.f;
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    f32x2_t lsum2 = {0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = exp2_t<T>(fmaf(s[kb][r], cexp, -mc));
-        pv[kb][r] = e;
-        lsum += e;
+      for (int r = 0; r < 16; r += 2) {
+        const float e0 = exp2_t<T>(fmaf(s[kb][r], cexp, -mc));
+        const float e1 = exp2_t<T>(fmaf(s[kb][r + 1], cexp, -mc));
+        pv[kb][r] = e0;
+        pv[kb][r + 1] = e1;
+        lsum2 += f32x2_t{e0, e1};
       }
-    l_run += lsum;
+    l_run += lsum2.x + lsum2.y;
 
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
