@@ -125,6 +125,10 @@ def main():
                                       4.0, 1, -2.0, 2.0, lo, gamma, scratch.data_ptr(), x_next.data_ptr(), None, B, HW, stream))
         return x_next, x
 
+    # engine initialisation, outside warm-up and timing whatever W is: the first forward of a plan measures its conv / GEMM
+    # tile table on the device and captures the hipGraph (the equivalent of building the model)
+    m(torch.cat([x[: a.bs], x[: a.bs]], 0), ts_rows[T - 1], **kw)
+    torch.cuda.synchronize()
     k = 0
     for _ in range(a.warmup):
         x, x_next = step(k, x, x_next)
