@@ -112,6 +112,29 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- GroupNorm group sums, accumulated by the producer ------------------------------------------------------------
+// A conv / GEMM epilogue that knows the per-channel (sum, sumsq) of its tile (chs[nc][2] in LDS, channels c0 .. c0+nc-1
+// of image `img`) also adds them, per GroupNorm group of ITS OWN tensor (groups of C/32 channels), into
+// gsum[img][32][2] (doubles, zeroed once per forward): fixed-order fp64 sum over the group's channels inside the tile,
+// then one fp64 atomic add per (group, statistic).  A consumer GroupNorm over exactly this tensor (not a virtual
+// concat) then needs no coefficient kernel: gn_apply3_kernel derives mean / rstd from 64 doubles per image.  The
+// order of the <= ~150 atomic additions per value is not fixed: the doubles may differ in their last bit (2^-53)
+// between runs, far below the fp32 rounding of mean and rstd.
+// Call with all threads of the workgroup after chs[] is complete (__syncthreads() before).
+__device__ __forceinline__ void gn_add_group_sums(const float* chs, double* gsum, int img, int C, int c0, int nc) {
+  const int cpg = C / 32;
+  const int g_lo = c0 / cpg, g_hi = (c0 + nc - 1) / cpg;
+  const int t = threadIdx.x, gi = t >> 1, which = t & 1;
+  if (gi <= g_hi - g_lo) {
+    const int g = g_lo + gi;
+    const int lo = (g * cpg > c0 ? g * cpg : c0) - c0;
+    const int hi = ((g + 1) * cpg < c0 + nc ? (g + 1) * cpg : c0 + nc) - c0;
+    double a = 0.0;
+    for (int c = lo; c < hi; ++c) a += (double)chs[c * 2 + which];
+    __hip_atomic_fetch_add(gsum + ((int64_t)img * 32 + g) * 2 + which, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // ---- vector load/store of 8 (bf16) / 4 (f32) elements = 16 bytes -----------------------
 template <typename T> struct Vec16;
 template <> struct Vec16<bf16_t> {

@@ -27,6 +27,17 @@ struct GnApplyParams {
   const float* coeff;
   void* out;
 };
+// GroupNorm of a tensor whose producer accumulated its per-group sums (common.h: gn_add_group_sums): no statistics pass
+// and no coefficient kernel; every thread derives mean / rstd of its (at most two) groups from gsum and folds gamma, beta
+// and FiLM itself, then applies them to RPT rows of the same channels.
+struct GnApply3Params {
+  GnApplyParams a;                         // a.coeff unused; a.x1 / a.C1 must be null / 0 (no virtual concat)
+  const double* gsum;                      // [B][32][2]
+  double inv_n;                            // 1 / (H*W * C/32)
+  float eps;
+  const float* gamma; const float* beta;   // [C]
+  const float* film; int64_t film_ld;      // optional [B][film_ld]: scale at +c, shift at +C+c
+};
 struct ConvInParams {
   const float* x; const float* img; const float* mask;  // NCHW fp32; img/mask only for Cin == 9
   const float* w; const float* bias;                    // [Cout][Cin][3][3], [Cout] fp32
@@ -79,6 +90,8 @@ int gn_nsplit(int B, int HW);
 int launch_gn_stats(const GnStatsParams& p, int dtype, hipStream_t s);
 int launch_gn_coeff(const GnCoeffParams& p, int B, hipStream_t s);
 int launch_gn_apply(const GnApplyParams& p, int dtype, hipStream_t s);
+bool gn_apply3_supported(int C, int dtype);
+int launch_gn_apply3(const GnApply3Params& p, int dtype, hipStream_t s);
 int launch_resample(const void* x, void* y, int B, int H, int W, int C, int mode, int dtype, hipStream_t s);
 int launch_conv_in(const ConvInParams& p, int dtype, hipStream_t s);
 int launch_timestep_embedding(const float* t, const float* freqs, float* out, int B, int half, hipStream_t s);

@@ -243,6 +243,119 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyParams p) {
   *reinterpret_cast<decltype(o.raw)*>(out) = o.raw;
 }
 
+// ---- GroupNorm32 (+FiLM, +act, +resample, +zero border) straight from the producer's group sums -------------------
+// Same thread mapping as gn_apply_kernel (one 16-byte channel vector of one padded output row position), but the thread
+// walks RPT consecutive rows with the same coefficients, which it builds itself: mean / rstd of the one or two groups
+// its channels belong to (C/32 >= channels per vector, checked on the host), gamma / beta / FiLM as 16-byte loads.  All
+// of these loads are independent of each other and of the activation loads: no dependent phase is added.
+// POOL (mode 1, 2x2 average after the activation: the three downsampling ResBlocks) reads four input vectors per output
+// and keeps one row per thread; otherwise one vector per row and RPT = 4 rows (register count decides the occupancy of
+// this bandwidth kernel: 16 staged vectors instead of 4 halved it and cost 2x in time).
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256) void gn_apply3_kernel(GnApply3Params q) {
+  constexpr int EPV = Vec16<T>::N;
+  constexpr int RPT = POOL ? 1 : 4;
+  constexpr int NV = POOL ? 4 : 1;
+  const GnApplyParams& p = q.a;
+  const int C = p.C0, CV = C / EPV, cpg = C / 32;
+  const int Ho = p.mode == 1 ? p.H / 2 : (p.mode == 2 ? p.H * 2 : p.H);
+  const int Wo = p.mode == 1 ? p.W / 2 : (p.mode == 2 ? p.W * 2 : p.W);
+  const int pad = p.pad, Hp = Ho + 2 * pad, Wp = Wo + 2 * pad;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Wp * CV) return;
+  const int xp = idx / CV, cv = idx - xp * CV;
+  const int xo = xp - pad, b = blockIdx.z;
+  const int c = cv * EPV;
+  const int yp0 = blockIdx.y * RPT;
+  const T* src = reinterpret_cast<const T*>(p.x0);
+  const bool x_in = xo >= 0 && xo < Wo;
+
+  // activation loads first (RPT rows), then the coefficient operands: everything is in flight together
+  Vec16<T> v[RPT][NV];
+  bool inside[RPT];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    const int yo = yp0 + r - pad;
+    inside[r] = x_in && yo >= 0 && yo < Ho && yp0 + r < Hp;
+    if (inside[r]) {
+      if constexpr (POOL) {
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx)
+            v[r][dy * 2 + dx].raw = *reinterpret_cast<const decltype(v[0][0].raw)*>(src + ((int64_t)(b * p.H + 2 * yo + dy) * p.W + 2 * xo + dx) * C + c);
+      } else {
+        const int yi = p.mode == 2 ? yo >> 1 : yo, xi = p.mode == 2 ? xo >> 1 : xo;
+        v[r][0].raw = *reinterpret_cast<const decltype(v[0][0].raw)*>(src + ((int64_t)(b * p.H + yi) * p.W + xi) * C + c);
+      }
+    }
+  }
+  const int g0 = c / cpg, g1 = (c + EPV - 1) / cpg;   // g1 <= g0 + 1 because cpg >= EPV
+  const double2 t0 = *reinterpret_cast<const double2*>(q.gsum + ((int64_t)b * 32 + g0) * 2);
+  const double2 t1 = *reinterpret_cast<const double2*>(q.gsum + ((int64_t)b * 32 + g1) * 2);
+  float gam[EPV], bet[EPV], fsc[EPV], fsh[EPV];
+#pragma unroll
+  for (int k = 0; k < EPV; k += 4) {
+    const float4 g4 = *reinterpret_cast<const float4*>(q.gamma + c + k);
+    const float4 b4 = *reinterpret_cast<const float4*>(q.beta + c + k);
+    gam[k] = g4.x; gam[k + 1] = g4.y; gam[k + 2] = g4.z; gam[k + 3] = g4.w;
+    bet[k] = b4.x; bet[k + 1] = b4.y; bet[k + 2] = b4.z; bet[k + 3] = b4.w;
+    if (q.film != nullptr) {
+      const float4 s4 = *reinterpret_cast<const float4*>(q.film + (int64_t)b * q.film_ld + c + k);
+      const float4 h4 = *reinterpret_cast<const float4*>(q.film + (int64_t)b * q.film_ld + C + c + k);
+      fsc[k] = s4.x; fsc[k + 1] = s4.y; fsc[k + 2] = s4.z; fsc[k + 3] = s4.w;
+      fsh[k] = h4.x; fsh[k + 1] = h4.y; fsh[k + 2] = h4.z; fsh[k + 3] = h4.w;
+    }
+  }
+  // fp64 only where the cancellation is (E[x^2] - mean^2); 1/n comes from the host, the square root is fp32
+  const double m0d = t0.x * q.inv_n, m1d = t1.x * q.inv_n;
+  double v0d = t0.y * q.inv_n - m0d * m0d, v1d = t1.y * q.inv_n - m1d * m1d;
+  if (v0d < 0.0) v0d = 0.0;
+  if (v1d < 0.0) v1d = 0.0;
+  const float mean0 = (float)m0d, mean1 = (float)m1d;
+  const float rstd0 = __builtin_amdgcn_rsqf((float)v0d + q.eps), rstd1 = __builtin_amdgcn_rsqf((float)v1d + q.eps);  // 1 ulp
+  const int split = (g0 + 1) * cpg - c;   // channels k < split belong to g0
+  float A[EPV], Bc[EPV];
+#pragma unroll
+  for (int k = 0; k < EPV; ++k) {
+    const bool first = k < split;
+    A[k] = (first ? rstd0 : rstd1) * gam[k];
+    Bc[k] = bet[k] - (first ? mean0 : mean1) * A[k];
+    if (q.film != nullptr) {
+      const float psc = 1.f + fsc[k];
+      A[k] *= psc;
+      Bc[k] = Bc[k] * psc + fsh[k];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    const int yp = yp0 + r;
+    if (yp >= Hp) break;
+    Vec16<T> o;
+    if (!inside[r]) {
+#pragma unroll
+      for (int k = 0; k < EPV / 2; ++k) o.set2(k, 0.f, 0.f);
+    } else {
+      float rr[EPV];
+      if constexpr (POOL) {
+#pragma unroll
+        for (int k = 0; k < EPV; ++k) {
+          float acc = 0.f;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc += apply_act(v[r][u].get(k) * A[k] + Bc[k], p.act);
+          rr[k] = acc * 0.25f;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < EPV; ++k) rr[k] = apply_act(v[r][0].get(k) * A[k] + Bc[k], p.act);
+      }
+#pragma unroll
+      for (int k = 0; k < EPV / 2; ++k) o.set2(k, rr[2 * k], rr[2 * k + 1]);
+    }
+    *reinterpret_cast<decltype(o.raw)*>(reinterpret_cast<T*>(p.out) + (((int64_t)b * Hp + yp) * Wp + xp) * C + c) = o.raw;
+  }
+}
+
 // ---- raw 2x resample of the residual branch (x_upd), unpadded NHWC -> unpadded NHWC ------------
 template <typename T>
 __global__ __launch_bounds__(256) void resample_kernel(const void* xin, void* yout, int B, int H, int W, int C, int mode) {
@@ -495,6 +608,32 @@ int launch_gn_apply(const GnApplyParams& p, int dtype, hipStream_t s) {
   dim3 grid((Wp * (C / epv) + 255) / 256, Hp, p.B);
   if (dtype == K22_BF16) hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, p);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+bool gn_apply3_supported(int C, int dtype) {
+  const int epv = dtype == K22_BF16 ? 8 : 4;
+  return C % 32 == 0 && C / 32 >= epv && (C / 32) % 1 == 0 && C % epv == 0;
+}
+int launch_gn_apply3(const GnApply3Params& q, int dtype, hipStream_t s) {
+  const GnApplyParams& p = q.a;
+  const int C = p.C0;
+  const int epv = dtype == K22_BF16 ? 8 : 4;
+  if (p.C1 != 0 || p.x1 != nullptr || !gn_apply3_supported(C, dtype) || q.gsum == nullptr)
+    return k22_set_error(K22_EINVAL, "gn_apply3: one source tensor with C/32 >= 8 (bf16) / 4 (fp32) channels per group");
+  const int Ho = p.mode == 1 ? p.H / 2 : (p.mode == 2 ? p.H * 2 : p.H);
+  const int Wo = p.mode == 1 ? p.W / 2 : (p.mode == 2 ? p.W * 2 : p.W);
+  const int Hp = Ho + 2 * p.pad, Wp = Wo + 2 * p.pad;
+  if (Hp > 65535 || p.B > 65535) return k22_set_error(K22_EINVAL, "gn_apply3: tensor too large");
+  const bool pool = p.mode == 1;
+  dim3 grid((Wp * (C / epv) + 255) / 256, pool ? Hp : (Hp + 3) / 4, p.B);
+  if (dtype == K22_BF16) {
+    if (pool) hipLaunchKernelGGL((gn_apply3_kernel<bf16_t, true>), grid, dim3(256), 0, s, q);
+    else hipLaunchKernelGGL((gn_apply3_kernel<bf16_t, false>), grid, dim3(256), 0, s, q);
+  } else {
+    if (pool) hipLaunchKernelGGL((gn_apply3_kernel<float, true>), grid, dim3(256), 0, s, q);
+    else hipLaunchKernelGGL((gn_apply3_kernel<float, false>), grid, dim3(256), 0, s, q);
+  }
   K22_CHECK_LAUNCH();
   return K22_OK;
 }

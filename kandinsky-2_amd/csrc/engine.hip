@@ -53,6 +53,8 @@ struct Act {  // unpadded NHWC activation, optionally a virtual channel concat o
   // GroupNorm partial sums delivered by the producing convolution (null = none: run gn_stats_kernel)
   const Tuned* p0 = nullptr; Slot* st0 = nullptr;
   const Tuned* p1 = nullptr; Slot* st1 = nullptr;
+  // byte offset, in the group-sum arena, of the per-group sums the producer of s0 accumulated for ITS tensor (-1 = none)
+  int64_t gs0 = -1;
   int C() const { return C0 + C1; }
 };
 
@@ -72,6 +74,7 @@ struct K22UNet {
   bool tuned_done = false;
   int autotune = 1;
   int fuse_skip = 1;
+  int gn_onepass = 0;
   size_t ws_bytes = 0;
   char* ws = nullptr;
   bool cond_set = false;
@@ -84,7 +87,7 @@ struct K22UNet {
   Slot *s_temb, *s_e1, *s_emb, *s_film, *s_xfproj, *s_ctx;
   Slot *s_full, *s_pool, *s_imgemb, *s_tmpf, *s_tmpf2, *s_fullT;
   Slot *s_part, *s_coeff, *s_P1, *s_U1, *s_P2, *s_S, *s_N, *s_QKV, *s_KALL, *s_VT, *s_ATT, *s_splitk, *s_flush;
-  Slot *s_U1st;
+  Slot *s_U1st, *s_gsum;
   Slot* s_h[3];
   Slot* s_hst[3];
   std::vector<Slot*> s_ctxkv;  // one per attention block
@@ -92,6 +95,11 @@ struct K22UNet {
   int64_t film_total = 0;
 
   Slot* new_slot(size_t bytes = 0) { slots.emplace_back(); slots.back().bytes = bytes; return &slots.back(); }
+  // GroupNorm group sums of every conv / GEMM output (common.h: gn_add_group_sums): [B][32][2] doubles each, in one arena
+  // (s_gsum) that a single memset clears at the start of a forward
+  size_t gsum_bytes = 0;
+  int64_t new_gsum() { const size_t off = gsum_bytes; gsum_bytes += ((size_t)B * 32 * 16 + 255) / 256 * 256; return (int64_t)off; }
+  double* gsum_at(int64_t off) const { return reinterpret_cast<double*>(ws + s_gsum->off + off); }
   static void need(Slot* s, size_t bytes) { if (bytes > s->bytes) s->bytes = bytes; }
   template <typename T = char> T* ptr(const Slot* s) const { return reinterpret_cast<T*>(ws + s->off); }
 
@@ -124,6 +132,21 @@ struct K22UNet {
     const Act a = in;
     const int dt = dtype;
     const double gn_bytes = (double)Bn * HW * C * esz * (fused ? 1.0 : 2.0) + (double)Bn * (Ho + 2 * pad) * (Wo + 2 * pad) * C * esz;
+    if (gn_onepass && a.s1 == nullptr && a.gs0 >= 0 && gn_apply3_supported(C, dtype)) {
+      // the producer accumulated this tensor's group sums: one kernel, no statistics / coefficient pass
+      const int64_t gs = a.gs0;
+      const double inv_n = 1.0 / ((double)HW * (double)(C / 32));
+      L.push_back(Op([=](hipStream_t st) {
+        GnApply3Params q = {};
+        GnApplyParams& ap = q.a;
+        ap.x0 = ptr(a.s0); ap.x1 = nullptr; ap.C0 = a.C0; ap.C1 = 0; ap.B = Bn; ap.H = a.H; ap.W = a.W;
+        ap.mode = mode; ap.pad = pad; ap.act = act; ap.coeff = nullptr; ap.out = ptr(dst);
+        q.gsum = gsum_at(gs); q.inv_n = inv_n; q.eps = 1e-5f; q.gamma = gamma; q.beta = beta;
+        q.film = film_off >= 0 ? ptr<float>(s_film) + film_off : nullptr; q.film_ld = film_total;
+        return launch_gn_apply3(q, dt, st);
+      }, OP_GN, 0.0, (double)Bn * HW * C * esz + (double)Bn * (Ho + 2 * pad) * (Wo + 2 * pad) * C * esz, 1));
+      return;
+    }
     L.push_back(Op([=](hipStream_t st) {
       const void* x0 = ptr(a.s0);
       const void* x1 = a.s1 ? ptr(a.s1) : nullptr;
@@ -185,6 +208,8 @@ struct K22UNet {
     default_cfg(*t);
     need(s_splitk, max_splitk_bytes(*t));
     if (t->want_stats) need(stats, (size_t)B * max_rpi(*t) * Cout * 2 * sizeof(float));
+    const int64_t gs = (gn_onepass && t->want_stats && Cout % 32 == 0) ? new_gsum() : -1;
+    t->gsum_off = gs;
     need(dst, out_mode == IG_OUT_ROWMAJOR ? (size_t)p.M * Cout * esz : (size_t)p.M * Cout * sizeof(float));
     Slot* rs = residual ? residual->s0 : nullptr;
     const int dt = dtype;
@@ -193,6 +218,7 @@ struct K22UNet {
       apply_cfg(q, t->cfg);
       q.A0 = ptr(src); q.residual = rs ? ptr(rs) : nullptr; q.out = ptr(dst); q.partial = ptr<float>(s_splitk);
       q.stats = t->want_stats ? ptr<float>(stats) : nullptr;
+      q.gsum = gs >= 0 ? gsum_at(gs) : nullptr;
       if (q.S0) { q.S0 = ptr(sk.s0); q.S1 = sk.s1 ? ptr(sk.s1) : nullptr; }
       return launch_igemm(q, dt, st);
     };
@@ -223,6 +249,8 @@ struct K22UNet {
     default_cfg(*t);
     need(s_splitk, max_splitk_bytes(*t));
     if (t->want_stats) need(stats, (size_t)B * max_rpi(*t) * N * 2 * sizeof(float));
+    const int64_t gs = (gn_onepass && t->want_stats && N % 32 == 0) ? new_gsum() : -1;
+    t->gsum_off = gs;
     need(dst, (size_t)M * p.ldo * esz);
     const Act a = in;
     Slot* rs = residual ? residual->s0 : nullptr;
@@ -234,6 +262,7 @@ struct K22UNet {
       q.residual = rs ? ptr(rs) : nullptr; q.out = ptr(dst); q.partial = ptr<float>(s_splitk);
       if (t->aux0) { q.kall = ptr(reinterpret_cast<Slot*>(t->aux0)); q.vtall = ptr(reinterpret_cast<Slot*>(t->aux1)); }
       q.stats = t->want_stats ? ptr<float>(stats) : nullptr;
+      q.gsum = gs >= 0 ? gsum_at(gs) : nullptr;
       return launch_igemm(q, dt, st);
     };
     L.push_back(Op([=](hipStream_t st) { return t->run(st); }, OP_GEMM, 2.0 * p.M * (double)p.N * p.Kc, 0.0, 1));
@@ -252,7 +281,7 @@ struct K22UNet {
     Tuned* t1 = op_conv(ops, s_P1, Ho, Wo, Cin, Cout, pfx + ".in_layers.2", nullptr, s_U1, IG_OUT_ROWMAJOR, s_U1st);
     // out_layers: GN * (1+scale) + shift -> SiLU -> conv3x3 (+ skip)
     Act u1; u1.s0 = s_U1; u1.C0 = Cout; u1.H = Ho; u1.W = Wo;
-    if (t1->want_stats) { u1.p0 = t1; u1.st0 = s_U1st; }
+    if (t1->want_stats) { u1.p0 = t1; u1.st0 = s_U1st; u1.gs0 = t1->gsum_off; }
     const int64_t film_off = film_cursor;
     film_cursor += 2 * Cout;
     op_gn(ops, u1, pfx + ".out_layers.0", film_off, K22_ACT_SILU, 0, 1, s_P2);
@@ -275,7 +304,7 @@ struct K22UNet {
         Tuned* t2 = op_conv(ops, s_P2, Ho, Wo, Cout, Cout, pfx + ".out_layers.3", nullptr, dst, IG_OUT_ROWMAJOR, dst_stats,
                             &in, pfx + ".skip_connection");
         Act out; out.s0 = dst; out.C0 = Cout; out.H = Ho; out.W = Wo;
-        if (t2->want_stats) { out.p0 = t2; out.st0 = dst_stats; }
+        if (t2->want_stats) { out.p0 = t2; out.st0 = dst_stats; out.gs0 = t2->gsum_off; }
         return out;
       }
       op_gemm(ops, in, B * Ho * Wo, Cout, pfx + ".skip_connection", nullptr, s_S);
@@ -286,7 +315,7 @@ struct K22UNet {
     }
     Tuned* t2 = op_conv(ops, s_P2, Ho, Wo, Cout, Cout, pfx + ".out_layers.3", &skip, dst, IG_OUT_ROWMAJOR, dst_stats);
     Act out; out.s0 = dst; out.C0 = Cout; out.H = Ho; out.W = Wo;
-    if (t2->want_stats) { out.p0 = t2; out.st0 = dst_stats; }
+    if (t2->want_stats) { out.p0 = t2; out.st0 = dst_stats; out.gs0 = t2->gsum_off; }
     return out;
   }
 
@@ -333,7 +362,7 @@ struct K22UNet {
     // proj_out + residual; its epilogue also delivers the GroupNorm partial sums the next ResBlock needs
     Tuned* tp = op_gemm(ops, a, B * T, C, pfx + ".proj_out", &in, dst, 0, IG_OUT_ROWMAJOR, dst_stats);
     Act out; out.s0 = dst; out.C0 = C; out.H = in.H; out.W = in.W;
-    if (tp->want_stats) { out.p0 = tp; out.st0 = dst_stats; }
+    if (tp->want_stats) { out.p0 = tp; out.st0 = dst_stats; out.gs0 = tp->gsum_off; }
     return out;
   }
 
@@ -344,7 +373,7 @@ struct K22UNet {
 
   int plan(int nB, int nH, int nW) {
     B = nB; H = nH; W = nW;
-    slots.clear(); ops.clear(); cond_ops.clear(); s_ctxkv.clear(); n_attn = 0; err.clear();
+    slots.clear(); ops.clear(); cond_ops.clear(); s_ctxkv.clear(); gsum_bytes = 0; n_attn = 0; err.clear();
     tuned.clear(); tuned_done = false;
     ws = nullptr; cond_set = false;
     if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
@@ -385,6 +414,7 @@ struct K22UNet {
     s_N = new_slot(); s_QKV = new_slot(); s_KALL = new_slot(); s_VT = new_slot(); s_ATT = new_slot();
     s_splitk = new_slot(256);
     s_U1st = new_slot();
+    s_gsum = new_slot();
     s_flush = new_slot(autotune ? ((size_t)320 << 20) : 0);  // evicts the Infinity Cache between tuning runs
     for (int i = 0; i < 3; ++i) { s_h[i] = new_slot(); s_hst[i] = new_slot(); }
     int hrot = 0, hcur = 0;
@@ -496,6 +526,15 @@ struct K22UNet {
     op_conv(ops, s_P1, H, W, ch, cfg.out_channels, "out.2", nullptr, s_out, IG_OUT_NCHW_F32);
 
     if (!err.empty()) return k22_set_error(K22_EINVAL, err.c_str());
+    // first op of every forward: clear the GroupNorm group sums the conv / GEMM epilogues accumulate into
+    need(s_gsum, gsum_bytes);
+    if (gsum_bytes) {
+      const size_t nbytes = gsum_bytes;
+      ops.insert(ops.begin(), Op([=](hipStream_t st) {
+        hipError_t e = hipMemsetAsync(ptr(s_gsum), 0, nbytes, st);
+        return e == hipSuccess ? (int)K22_OK : k22_set_error_hip(e, __FILE__, __LINE__);
+      }, OP_GN, 0.0, (double)nbytes, 1));
+    }
     // ---- lay the slots out -----------------------------------------------------------------------
     size_t off = 0;
     for (auto& s : slots) { s.off = off; off += (s.bytes + 255) / 256 * 256; }
@@ -577,6 +616,11 @@ int k22_unet_create(const K22UNetConfig* cfg, const K22Weight* weights, int n_we
   {
     const char* e = getenv("K22_AUTOTUNE");  // 0 = heuristics only (no measurement at the first forward)
     u->autotune = e ? (atoi(e) != 0) : 1;
+    // 1 = single-source GroupNorms in one pass from group sums the producer epilogue accumulates (gn_apply3_kernel).
+    // Measured on one box, same run: 117 steps/s against 120 with gn_coeff + gn_apply (GroupNorm class 1.41 vs 1.29 ms):
+    // re-deriving the coefficients in every thread costs more than the coefficient kernel it removes.  Off by default.
+    const char* gf = getenv("K22_GN_ONEPASS");
+    u->gn_onepass = gf ? (atoi(gf) != 0) : 0;
     const char* f = getenv("K22_FUSE_SKIP");  // 0 = 1x1 skip connections as separate GEMMs
     u->fuse_skip = f ? (atoi(f) != 0) : 1;
   }

@@ -55,6 +55,9 @@ struct IgemmParams {
   int res_f32;           // residual is fp32 (generic kernel / split-K finish only)
   float* stats;          // optional GroupNorm side output: per-row-block, per-channel (sum, sumsq) of the STORED
                          // values, [stats_rows][N][2] fp32 (see IgemmStatsInfo); null = not wanted
+  double* gsum;          // optional, with or without stats: per image and per GroupNorm group of the output tensor (32 groups
+                         // of N/32 channels) the (sum, sumsq) of the STORED values, [B][32][2], ACCUMULATED with fp64 atomics
+                         // (common.h: gn_add_group_sums; zero it before the launch); needs N % 32 == 0 and H, W set
 };
 
 // How a producer laid out its GroupNorm partial sums: image b owns rows [b*rows_per_image, (b+1)*rows_per_image).

@@ -27,6 +27,7 @@ struct Tuned {
   Cfg cfg;                     // current choice (heuristic until tuned)
   bool want_stats = false;     // epilogue also emits the GroupNorm partial sums of its output
   int rpi = 0;                 // stats rows per image under cfg
+  long long gsum_off = -1;     // engine-specific: offset of the output's GroupNorm group sums (-1 = none)
   float best_us = 0.f;
   void* aux0 = nullptr; void* aux1 = nullptr;  // engine-specific (IG_OUT_QKV: this block's K_all / V^T_all slots)
   std::function<int(hipStream_t)> run;
