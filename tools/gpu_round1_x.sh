@@ -2,5 +2,7 @@
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 600 python tools/bench_kernels.py --configs h256,a256,k256,h128,k128 --reps 10 > gpurun_out/bk_x.log 2>&1
-cat gpurun_out/bk_x.log | tail -31
+echo "== prior"; timeout 300 python tools/bench_prior.py 2>&1 | grep -v amdgpu.ids | tail -4
+echo "== movq"; timeout 300 python tools/bench_movq.py 2>&1 | grep -v amdgpu.ids | tail -4
+echo "== C3 per-GPU shape (1024^2, bs 4)"; timeout 600 python bench.py --size 1024 --bs 4 --steps 10 --warmup 2 --no-cpu-baseline --no-profile 2>&1 | tail -1 | cut -c1-200
+echo "== C4 inpaint 768^2 bs 4"; timeout 600 python bench.py --inpaint --bs 4 --steps 10 --warmup 2 --no-cpu-baseline --no-profile 2>&1 | tail -1 | cut -c1-200
