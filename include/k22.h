@@ -130,6 +130,13 @@ size_t k22_sampler_scratch_bytes(int N, int HW);
  * (a_t, a_prev, sigma_t, sqrt(1 - a_t)); noise may be NULL (eta = 0); x0_out may be NULL. */
 int k22_ddim_step(const float* x, const float* model_out, const float* noise, const float* table_row, float guidance, int use_cfg,
                   float* x_out, float* x0_out, int N, int HW, void* stream);
+/* PLMS step (PLMSSampler.p_sample_plms, kandinsky2/model/samplers.py:566-637; eta = 0) with model_fn's guidance folded in:
+ * e_t = u + g (c - u) of this model call; e' = Adams-Bashforth combination of e_t and the eps history by `order`
+ * (0: e_t; 1: (3 e_t - h1)/2; 2: (23 e_t - 16 h1 + 5 h2)/12; 3: (55 e_t - 59 h1 + 37 h2 - 9 h3)/24; 4: (h1 + e_t)/2, the second
+ * stage of the pseudo improved Euler start); x_out = DDIM update (sigma = 0) with e'.  eps_out (optional, [N][4][HW])
+ * receives e_t for the caller's history ring; table_row as for k22_ddim_step. */
+int k22_plms_step(const float* x, const float* model_out, const float* eps_hist1, const float* eps_hist2, const float* eps_hist3, int order,
+                  const float* table_row, float guidance, int use_cfg, float* x_out, float* eps_out, float* x0_out, int N, int HW, void* stream);
 int k22_sampler_step(const float* x, const float* model_out, const float* noise, const float* init_img,
                      const float* mask, const float* table, int step_index, float guidance, int use_cfg,
                      float clamp_lo, float clamp_hi, int pct_index, double pct_gamma, void* scratch,

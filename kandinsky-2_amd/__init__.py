@@ -6,7 +6,7 @@ reference's module / sampler interface for that path.
 """
 from .arch import MODEL_CONFIG_2_1, DIFFUSION_CONFIG_2_1, UNetArch, make_arch, param_shapes, tiny_model_config
 from .unet import Text2ImUNetHIP, create_model
-from .diffusion import SpacedDiffusionHIP, DDIMSamplerHIP, create_gaussian_diffusion, space_timesteps, percentile_index
+from .diffusion import SpacedDiffusionHIP, DDIMSamplerHIP, PLMSSamplerHIP, create_gaussian_diffusion, space_timesteps, percentile_index
 from .weights import init_unet_state_dict, make_conditioning
 from .prior import (PRIOR_HPARAMS_2_1, PRIOR_DIFFUSION_2_1, PriorDiffusionModelHIP, PriorSchedule, prior_param_shapes,
                     init_prior_state_dict, tiny_prior_hparams)
@@ -14,7 +14,7 @@ from .movq import MOVQ_CONFIG_2_1, MoVQArch, MoVQDecoderHIP, movq_param_shapes, 
 
 __all__ = [
     "MODEL_CONFIG_2_1", "DIFFUSION_CONFIG_2_1", "UNetArch", "make_arch", "param_shapes", "tiny_model_config",
-    "Text2ImUNetHIP", "create_model", "SpacedDiffusionHIP", "DDIMSamplerHIP", "create_gaussian_diffusion", "space_timesteps",
+    "Text2ImUNetHIP", "create_model", "SpacedDiffusionHIP", "DDIMSamplerHIP", "PLMSSamplerHIP", "create_gaussian_diffusion", "space_timesteps",
     "percentile_index", "init_unet_state_dict", "make_conditioning",
     "PRIOR_HPARAMS_2_1", "PRIOR_DIFFUSION_2_1", "PriorDiffusionModelHIP", "PriorSchedule", "prior_param_shapes",
     "init_prior_state_dict", "tiny_prior_hparams",

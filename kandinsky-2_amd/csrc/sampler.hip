@@ -199,6 +199,56 @@ __global__ __launch_bounds__(256) void ddim_step_kernel(const float* x, const fl
   }
 }
 
+// ---- PLMS step (kandinsky2/model/samplers.py:566-637, eta = 0 enforced at :355) with model_fn's guidance folded in --------
+// e_t = u + g (c - u) of THIS model call; e' by order (history h1 = newest):
+//   0: e_t   (first stage of the pseudo improved Euler start)      4: (h1 + e_t) / 2   (its second stage: h1 = e_t of stage one)
+//   1: (3 e_t - h1) / 2      2: (23 e_t - 16 h1 + 5 h2) / 12      3: (55 e_t - 59 h1 + 37 h2 - 9 h3) / 24
+// evaluated left to right with separate roundings like the reference's tensor expression; then the eta = 0 DDIM update
+// x_out = sqrt(a_prev) (x - sqrt(1-a_t) e') / sqrt(a_t) + sqrt(1 - a_prev) e'.  e_store (optional) receives e_t.
+__global__ __launch_bounds__(256) void plms_step_kernel(const float* x, const float* model_out, const float* h1, const float* h2, const float* h3,
+                                                        int order, const float* tab, float guidance, int use_cfg, float* x_out, float* e_store,
+                                                        float* x0_out, int N, int HW) {
+  const float a_t = tab[0], a_prev = tab[1], s1m = tab[3];
+  const float sq_at = sqrtf(a_t), sq_ap = sqrtf(a_prev);
+  const float dirc = sqrtf(__fsub_rn(__fsub_rn(1.0f, a_prev), 0.0f));
+  const int64_t total = (int64_t)N * 4 * HW;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int pix = (int)(i % HW);
+    const int c = (int)((i / HW) % 4), n = (int)(i / (4 * (int64_t)HW));
+    float e;
+    if (use_cfg) {
+      const int bs = N / 2, j = n % bs;
+      const float ce = model_out[((int64_t)j * 8 + c) * HW + pix], ue = model_out[((int64_t)(j + bs) * 8 + c) * HW + pix];
+      e = __fadd_rn(ue, __fmul_rn(guidance, __fsub_rn(ce, ue)));
+    } else {
+      e = model_out[((int64_t)n * 8 + c) * HW + pix];
+    }
+    float ep = e;
+    if (order == 4) ep = __fdiv_rn(__fadd_rn(h1[i], e), 2.0f);
+    else if (order == 1) ep = __fdiv_rn(__fsub_rn(__fmul_rn(3.0f, e), h1[i]), 2.0f);
+    else if (order == 2) ep = __fdiv_rn(__fadd_rn(__fsub_rn(__fmul_rn(23.0f, e), __fmul_rn(16.0f, h1[i])), __fmul_rn(5.0f, h2[i])), 12.0f);
+    else if (order == 3)
+      ep = __fdiv_rn(__fsub_rn(__fadd_rn(__fsub_rn(__fmul_rn(55.0f, e), __fmul_rn(59.0f, h1[i])), __fmul_rn(37.0f, h2[i])), __fmul_rn(9.0f, h3[i])), 24.0f);
+    const float x0 = __fdiv_rn(__fsub_rn(x[i], __fmul_rn(s1m, ep)), sq_at);
+    x_out[i] = __fadd_rn(__fmul_rn(sq_ap, x0), __fmul_rn(dirc, ep));
+    if (e_store != nullptr) e_store[i] = e;
+    if (x0_out != nullptr) x0_out[i] = x0;
+  }
+}
+
+int launch_plms_step(const float* x, const float* model_out, const float* h1, const float* h2, const float* h3, int order, const float* tab,
+                     float guidance, int use_cfg, float* x_out, float* e_store, float* x0_out, int N, int HW, hipStream_t s) {
+  if (N <= 0 || HW <= 0 || (use_cfg && (N & 1))) return k22_set_error(K22_EINVAL, "plms_step: bad batch");
+  if (order < 0 || order > 4 || ((order == 1 || order == 4) && !h1) || (order == 2 && (!h1 || !h2)) || (order == 3 && (!h1 || !h2 || !h3)))
+    return k22_set_error(K22_EINVAL, "plms_step: order 0-4 with the eps history it needs");
+  const int64_t total = (int64_t)N * 4 * HW;
+  int nb = (int)((total + 255) / 256);
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(plms_step_kernel, dim3(nb), dim3(256), 0, s, x, model_out, h1, h2, h3, order, tab, guidance, use_cfg, x_out, e_store, x0_out, N, HW);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+
 int launch_ddim_step(const float* x, const float* model_out, const float* noise, const float* tab, float guidance, int use_cfg,
                      float* x_out, float* x0_out, int N, int HW, hipStream_t s) {
   if (N <= 0 || HW <= 0 || (use_cfg && (N & 1))) return k22_set_error(K22_EINVAL, "ddim_step: bad batch");

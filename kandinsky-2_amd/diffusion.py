@@ -238,6 +238,62 @@ class DDIMSamplerHIP:
         return x, {"pred_x0": [x0]}
 
 
+class PLMSSamplerHIP(DDIMSamplerHIP):
+    """PLMSSampler (kandinsky2/model/samplers.py:334-637) for the decoder UNet: pseudo improved Euler start, then 2nd-4th order
+    Adams-Bashforth on the guided eps, each step's arithmetic + model_fn's guidance fused into k22_plms_step.
+
+        sampler = PLMSSamplerHIP(model, old_diffusion, guidance_scale)
+        samples, _ = sampler.sample(num_steps, batch_size * 2, (4, h, w), conditioning=model_kwargs, x_T=noise, init_step=None)
+    """
+
+    @torch.no_grad()
+    def sample(self, S, batch_size, shape, conditioning=None, eta=0.0, x_T=None, init_step=None, device="cuda", **_unused):
+        if eta != 0:
+            raise ValueError("ddim_eta must be 0 for PLMS")   # samplers.py:355-356
+        self.make_schedule(S, ddim_eta=0.0, init_step=init_step)
+        L = _lib.lib()
+        C, H, W = shape
+        if C != 4 or batch_size % 2:
+            raise ValueError("shape must be (4, h, w) and batch_size = 2*bs")
+        dev = torch.device(device)
+        N, HW, bs = batch_size, H * W, batch_size // 2
+        x = x_T.to(dev).float().contiguous().clone() if x_T is not None else torch.randn(N, C, H, W, device=dev)
+        x_next, x0 = torch.empty_like(x), torch.empty_like(x)
+        hist = [torch.empty_like(x) for _ in range(4)]   # ring of guided eps tensors: 3 of history + the one being written
+        old = []                                          # newest last, like the reference's old_eps
+        table = torch.from_numpy(self.table).to(dev)
+        kw = conditioning or {}
+        time_range = np.flip(self.ddim_timesteps)
+        total = len(time_range)
+        st = _lib.current_stream()
+
+        def model(xx, step):
+            half = xx[:bs]
+            return self.model(torch.cat([half, half], 0), torch.full((N,), float(step), device=dev), **kw)
+
+        for i, step in enumerate(time_range):
+            index = total - i - 1
+            row = table[index].data_ptr()
+            e_buf = next(b for b in hist if all(b is not o for o in old))
+            out = model(x, step)
+            if len(old) == 0:
+                # stage one: e_t -> e_buf, provisional x_prev -> x_next; stage two: model at t_next, e' = (e_t + e_next) / 2
+                _lib.check(L.k22_plms_step(x.data_ptr(), out.data_ptr(), None, None, None, 0, row, self.guidance_scale, 1,
+                                           x_next.data_ptr(), e_buf.data_ptr(), None, N, HW, st))
+                out2 = model(x_next, time_range[min(i + 1, total - 1)])
+                _lib.check(L.k22_plms_step(x.data_ptr(), out2.data_ptr(), e_buf.data_ptr(), None, None, 4, row, self.guidance_scale, 1,
+                                           x_next.data_ptr(), None, x0.data_ptr(), N, HW, st))
+            else:
+                h = [o.data_ptr() for o in reversed(old)] + [None, None]
+                _lib.check(L.k22_plms_step(x.data_ptr(), out.data_ptr(), h[0], h[1], h[2], len(old), row, self.guidance_scale, 1,
+                                           x_next.data_ptr(), e_buf.data_ptr(), x0.data_ptr(), N, HW, st))
+            old.append(e_buf)
+            if len(old) >= 4:
+                old.pop(0)
+            x, x_next = x_next, x
+        return x, {"pred_x0": [x0]}
+
+
 def create_gaussian_diffusion(**kw) -> SpacedDiffusionHIP:
     """Keyword-compatible with the reference's create_gaussian_diffusion (model_creation.py:86-128)."""
     return SpacedDiffusionHIP(**kw)

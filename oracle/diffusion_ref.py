@@ -116,3 +116,56 @@ def ddim_sample_loop(unet_fn, x_T, num_steps, guidance, eta=0.0, noise_seq=None,
         noise = sigma_t * (noise_seq[i] if noise_seq is not None else torch.zeros_like(x))
         x = a_prev.sqrt() * pred_x0 + dir_xt + noise
     return x
+
+
+def plms_sample_loop(unet_fn, x_T, num_steps, guidance, init_step=None, steps=1000, linear_start=0.00085, linear_end=0.012):
+    """PLMSSampler.sample / plms_sampling / p_sample_plms (kandinsky2/model/samplers.py:334-637, eta = 0 is enforced at
+    :355-356, 'uniform' discretisation) driven by generate_img's model_fn in its non-p_sampler branch
+    (kandinsky2_1_model.py:222-233: guided eps only).  unet_fn(x_combined, t [2bs] float) -> [2bs,8,h,w]."""
+    ac = np.cumprod(1.0 - linear_betas(steps, linear_start, linear_end))
+    c = steps // num_steps
+    ts = np.asarray(list(range(0, steps, c))) + 1
+    if init_step is not None:
+        ts = np.array([i for i in ts if i <= init_step])
+    alphas = ac[ts]
+    alphas_prev = np.asarray([ac[0]] + ac[ts[:-1]].tolist())
+    sqrt_1m = np.sqrt(1.0 - alphas)
+    f = lambda v: torch.tensor(float(v), dtype=torch.float32)  # noqa: E731  (torch.full(..., python float) rounds to fp32)
+    total = len(ts)
+    time_range = np.flip(ts)
+
+    def model(x, step):  # model_fn
+        half = x[: len(x) // 2]
+        out = unet_fn(torch.cat([half, half], 0), torch.full((len(x),), float(step)))
+        eps = out[:, :4]
+        cond, uncond = torch.split(eps, len(eps) // 2, dim=0)
+        he = uncond + guidance * (cond - uncond)
+        return torch.cat([he, he], dim=0)
+
+    def x_prev_of(x, e, index):  # get_x_prev_and_pred_x0 with sigma_t = 0 (the 0 * randn noise term adds exactly 0)
+        a_t, a_prev, s1m = f(alphas[index]), f(alphas_prev[index]), f(sqrt_1m[index])
+        pred_x0 = (x - s1m * e) / a_t.sqrt()
+        dir_xt = (1.0 - a_prev - f(0.0) ** 2).sqrt() * e
+        return a_prev.sqrt() * pred_x0 + dir_xt
+
+    x = x_T.clone()
+    old = []
+    for i, step in enumerate(time_range):
+        index = total - i - 1
+        t_next = time_range[min(i + 1, total - 1)]
+        e_t = model(x, step)
+        if len(old) == 0:
+            x_prev = x_prev_of(x, e_t, index)
+            e_next = model(x_prev, t_next)
+            e_p = (e_t + e_next) / 2
+        elif len(old) == 1:
+            e_p = (3 * e_t - old[-1]) / 2
+        elif len(old) == 2:
+            e_p = (23 * e_t - 16 * old[-1] + 5 * old[-2]) / 12
+        else:
+            e_p = (55 * e_t - 59 * old[-1] + 37 * old[-2] - 9 * old[-3]) / 24
+        x = x_prev_of(x, e_p, index)
+        old.append(e_t)
+        if len(old) >= 4:
+            old.pop(0)
+    return x

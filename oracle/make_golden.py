@@ -215,6 +215,55 @@ def ddim_case(name, model_config, B, h, w, steps, guidance=4.0, seed_w=0):
                os.path.join(GOLD, name + ".pt"))
 
 
+def plms_case(name, model_config, B, h, w, steps, guidance=4.0, seed_w=0):
+    """PLMSSampler.sample of the REFERENCE (kandinsky2/model/samplers.py:334-637) driven by the verbatim non-p_sampler branch
+    of generate_img's model_fn (kandinsky2_1_model.py:222-233); same CPU redirection as ddim_case."""
+    smp = ref_loader.ref("model.samplers")
+    arch = k22.make_arch(model_config)
+    sd = k22.init_unet_state_dict(arch, seed=seed_w)
+    model = ref_model(model_config, False)
+    model.load_state_dict(sd, strict=True)
+    full, pooled, image = k22.make_conditioning(arch, B, seed=2)
+    kw = dict(full_emb=full, pooled_emb=pooled, image_emb=image)
+
+    def model_fn(x_t, ts, **kwargs):
+        half = x_t[: len(x_t) // 2]
+        combined = torch.cat([half, half], dim=0)
+        model_out = model(combined, ts, **kwargs)
+        eps, rest = model_out[:, :4], model_out[:, 4:]
+        cond_eps, uncond_eps = torch.split(eps, len(eps) // 2, dim=0)
+        half_eps = uncond_eps + guidance * (cond_eps - uncond_eps)
+        return torch.cat([half_eps, half_eps], dim=0)
+
+    mc = ref_loader.ref("model.model_creation")
+    diffusion = mc.create_gaussian_diffusion(**k22.DIFFUSION_CONFIG_2_1)
+    g = torch.Generator().manual_seed(43)
+    x_T = torch.randn(B, 4, h, w, generator=g)
+    real_torch, real_to = smp.torch, torch.Tensor.to
+
+    def to_cpu(self, *a, **k):
+        a = tuple("cpu" if (x == "cuda" or (isinstance(x, torch.device) and x.type == "cuda")) else x for x in a)
+        return real_to(self, *a, **k)
+
+    smp.torch = _CpuTorch()
+    torch.Tensor.to = to_cpu
+    try:
+        model.del_cache()
+        sampler = smp.PLMSSampler(model=model_fn, old_diffusion=diffusion, schedule="linear")
+        with torch.no_grad():
+            ref_final, _ = sampler.sample(steps, B, (4, h, w), conditioning=kw, x_T=x_T.clone(), init_step=None, verbose=False)
+        model.del_cache()
+    finally:
+        smp.torch = real_torch
+        torch.Tensor.to = real_to
+    ora = diffusion_ref.plms_sample_loop(lambda xc, tt: unet_ref.unet_forward(sd, arch, xc, tt, full, pooled, image), x_T, steps, guidance)
+    d = (ora - ref_final).abs().max().item()
+    print(f"{name}: {steps}-step PLMS ref absmax {ref_final.abs().max():.4f}  oracle-vs-ref max|d| {d:.3e}")
+    assert d < 1e-4
+    torch.save(dict(name=name, model_config=model_config, B=B, h=h, w=w, steps=steps, guidance=guidance, seed_w=seed_w, final=ref_final.clone()),
+               os.path.join(GOLD, name + ".pt"))
+
+
 def prior_inputs(bs, seed=7):
     """Seeded conditioning of the prior: rows [cond | uncond]; padding masks of different lengths."""
     g = torch.Generator().manual_seed(seed)
@@ -306,6 +355,7 @@ if __name__ == "__main__":
     run_case("tiny_text2img", tiny, False, B=2, h=16, w=16, steps=6)
     run_case("tiny_inpaint", tiny, True, B=4, h=16, w=24, steps=4)
     ddim_case("tiny_ddim", tiny, B=2, h=16, w=16, steps=5)
+    plms_case("tiny_plms", tiny, B=2, h=16, w=16, steps=8)
     prior_case("prior_tiny", k22.tiny_prior_hparams(), bs=2, steps=5)
     movq_case("movq_small", B=2, h=8, w=8)
     movq_case("movq_wide", B=1, h=8, w=16)

@@ -228,6 +228,17 @@ def test_ddim_oracle_matches_reference_golden(golden_dir):
     assert (out - fx["final"]).abs().max().item() <= 1e-4 * fx["final"].abs().max().item()
 
 
+def test_plms_oracle_matches_reference_golden(golden_dir):
+    """oracle/diffusion_ref.plms_sample_loop == the reference PLMSSampler (golden made by importing it, make_golden.plms_case)."""
+    fx = _load(golden_dir, "tiny_plms")
+    arch = k22.make_arch(fx["model_config"])
+    sd = k22.init_unet_state_dict(arch, seed=fx["seed_w"])
+    full, pooled, image = k22.make_conditioning(arch, fx["B"], seed=2)
+    x_T = torch.randn(fx["B"], 4, fx["h"], fx["w"], generator=torch.Generator().manual_seed(43))
+    out = diffusion_ref.plms_sample_loop(lambda xc, tt: unet_ref.unet_forward(sd, arch, xc, tt, full, pooled, image), x_T, fx["steps"], fx["guidance"])
+    assert torch.equal(out, fx["final"])
+
+
 def test_ddim_schedule_matches_oracle():
     old = k22.create_gaussian_diffusion(**k22.DIFFUSION_CONFIG_2_1)
     s = k22.DDIMSamplerHIP(None, old, 4.0)

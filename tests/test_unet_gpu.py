@@ -7,6 +7,7 @@ scale and its end-to-end drift is reported (bf16 rounding of activations, not an
 """
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -151,6 +152,59 @@ def test_ddim_sampler_final_latent_vs_reference_golden_fp32(golden_dir):
     err = (out.cpu() - ref).abs().max().item()
     print(f"DDIM {fx['steps']} steps fp32: max|d|={err:.3e} scale={scale:.2f}")
     assert err <= 1e-3 * max(1.0, scale)
+
+
+def test_plms_sampler_final_latent_vs_reference_golden_fp32(golden_dir):
+    """PLMSSampler (pseudo improved Euler start + Adams-Bashforth on the guided eps) with the fused
+    k22_plms_step; fp32 engine, 8 steps (all four orders are exercised), final latent within 1e-3 of the reference's
+    (relative to its scale)."""
+    fx = _load(golden_dir, "tiny_plms")
+    arch = k22.make_arch(fx["model_config"])
+    sd = k22.init_unet_state_dict(arch, seed=fx["seed_w"])
+    m = k22.Text2ImUNetHIP(arch, backend_dtype=torch.float32, use_graph=True)
+    m.load_state_dict(sd)
+    m = m.to("cuda").eval()
+    full, pooled, image = k22.make_conditioning(arch, fx["B"], seed=2)
+    kw = dict(full_emb=full.cuda(), pooled_emb=pooled.cuda(), image_emb=image.cuda())
+    g = torch.Generator().manual_seed(43)
+    x_T = torch.randn(fx["B"], 4, fx["h"], fx["w"], generator=g)
+    old = k22.create_gaussian_diffusion(**k22.DIFFUSION_CONFIG_2_1)
+    sampler = k22.PLMSSamplerHIP(m, old, fx["guidance"])
+    out, _ = sampler.sample(fx["steps"], fx["B"], (4, fx["h"], fx["w"]), conditioning=kw, x_T=x_T.cuda())
+    ref = fx["final"]
+    scale = ref.abs().max().item()
+    err = (out.cpu() - ref).abs().max().item()
+    print(f"PLMS {fx['steps']} steps fp32: max|d|={err:.3e} scale={scale:.2f}")
+    assert err <= 1e-3 * max(1.0, scale)
+
+
+def test_plms_step_kernel_matches_the_oracle_arithmetic():
+    """k22_plms_step alone against the oracle's tensor expressions, every order: the guided eps bit-exact (same roundings, no
+    fma), the DDIM update to a few ulp (device sqrt / divide against the host's)."""
+    from kandinsky2_amd import _lib
+    N, H, W = 4, 8, 12
+    HW = H * W
+    g = torch.Generator().manual_seed(5)
+    x, out = torch.randn(N, 4, H, W, generator=g), torch.randn(N, 8, H, W, generator=g)
+    hs = [torch.randn(N, 4, H, W, generator=g) for _ in range(3)]
+    tab = torch.tensor([0.7312, 0.8125, 0.0, float(np.sqrt(np.float32(1 - 0.7312)))], dtype=torch.float32)
+    guidance = 4.0
+    eps = out[:, :4]
+    c, u = torch.split(eps, N // 2, dim=0)
+    he = u + guidance * (c - u)
+    e = torch.cat([he, he], 0)
+    want = {0: e, 4: (hs[0] + e) / 2, 1: (3 * e - hs[0]) / 2, 2: (23 * e - 16 * hs[0] + 5 * hs[1]) / 12,
+            3: (55 * e - 59 * hs[0] + 37 * hs[1] - 9 * hs[2]) / 24}
+    a_t, a_prev, s1m = tab[0], tab[1], tab[3]
+    xd, od, hd, td = x.cuda(), out.cuda(), [h.cuda() for h in hs], tab.cuda()
+    for order, ep in want.items():
+        x_out, e_out = torch.empty_like(xd), torch.empty_like(xd)
+        _lib.check(_lib.lib().k22_plms_step(xd.data_ptr(), od.data_ptr(), hd[0].data_ptr(), hd[1].data_ptr(), hd[2].data_ptr(), order, td.data_ptr(),
+                                            guidance, 1, x_out.data_ptr(), e_out.data_ptr(), None, N, HW, torch.cuda.current_stream().cuda_stream))
+        pred_x0 = (x - s1m * ep) / a_t.sqrt()
+        ref = a_prev.sqrt() * pred_x0 + (1.0 - a_prev - torch.tensor(0.0) ** 2).sqrt() * ep
+        assert torch.equal(e_out.cpu(), e), f"eps order {order}"
+        assert torch.allclose(x_out.cpu(), ref, rtol=2e-6, atol=2e-6), f"x_prev order {order}: {(x_out.cpu() - ref).abs().max().item():.3e}"
 
 
 def test_rank_nonzero_path_adopts_a_broadcast_arena():
