@@ -260,6 +260,13 @@ int k22_movq_bind(K22MoVQ* m, void* workspace, size_t workspace_bytes);
  * out: fp32 NCHW [B][3][H][W] (may be null); out_u8: uint8 NHWC [B][H][W][3] = ((x+1)*127.5).round().clamp(0,255)
  * (may be null); H = h << (n_levels-1). */
 int k22_movq_decode(K22MoVQ* m, const float* z, float* out, unsigned char* out_u8, void* stream);
+/* MoVQ ENCODER on the same handle type (MOVQ.encode, kandinsky2/vqgan/autoencoder.py:176-180 = Encoder.forward,
+ * vqgan_blocks.py:335-367, + quant_conv; the img2img / inpainting pre-step of kandinsky2_1_model.py:458-469, 519-534).
+ * Weights: "encoder.*" (GroupNorm weight/bias fp32; 3x3 packed [Npad][ky][kx][Cin], conv_in zero-extended to Cin = 64, conv_out
+ * rows padded to 64; 1x1 [Npad][Cin]) and fp32 "quant_conv.*".  image: fp32 NCHW [B][3][H][W]; latent: fp32 NCHW [B][4][H/8][W/8]
+ * (not multiplied by the pipeline's latent scale).  A handle holds one plan: encoder or decoder. */
+int k22_movq_plan_encoder(K22MoVQ* m, int B, int H, int W, size_t* workspace_bytes);
+int k22_movq_encode(K22MoVQ* m, const float* image, float* latent, void* stream);
 int k22_movq_num_ops(const K22MoVQ* m);
 
 #ifdef __cplusplus

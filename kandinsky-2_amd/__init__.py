@@ -10,7 +10,8 @@ from .diffusion import SpacedDiffusionHIP, DDIMSamplerHIP, PLMSSamplerHIP, creat
 from .weights import init_unet_state_dict, make_conditioning
 from .prior import (PRIOR_HPARAMS_2_1, PRIOR_DIFFUSION_2_1, PriorDiffusionModelHIP, PriorSchedule, prior_param_shapes,
                     init_prior_state_dict, tiny_prior_hparams)
-from .movq import MOVQ_CONFIG_2_1, MoVQArch, MoVQDecoderHIP, movq_param_shapes, init_movq_state_dict
+from .movq import (MOVQ_CONFIG_2_1, MoVQArch, MoVQDecoderHIP, MoVQEncoderHIP, movq_param_shapes, init_movq_state_dict,
+                   movq_encoder_param_shapes, init_movq_encoder_state_dict)
 
 __all__ = [
     "MODEL_CONFIG_2_1", "DIFFUSION_CONFIG_2_1", "UNetArch", "make_arch", "param_shapes", "tiny_model_config",
@@ -18,5 +19,6 @@ __all__ = [
     "percentile_index", "init_unet_state_dict", "make_conditioning",
     "PRIOR_HPARAMS_2_1", "PRIOR_DIFFUSION_2_1", "PriorDiffusionModelHIP", "PriorSchedule", "prior_param_shapes",
     "init_prior_state_dict", "tiny_prior_hparams",
-    "MOVQ_CONFIG_2_1", "MoVQArch", "MoVQDecoderHIP", "movq_param_shapes", "init_movq_state_dict",
+    "MOVQ_CONFIG_2_1", "MoVQArch", "MoVQDecoderHIP", "MoVQEncoderHIP", "movq_param_shapes", "init_movq_state_dict",
+    "movq_encoder_param_shapes", "init_movq_encoder_state_dict",
 ]

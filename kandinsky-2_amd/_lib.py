@@ -69,6 +69,8 @@ SIGNATURES = {
     "k22_movq_plan": (_I, [_P, _I, _I, _I, C.POINTER(_Z)]),
     "k22_movq_bind": (_I, [_P, _P, _Z]),
     "k22_movq_decode": (_I, [_P, _P, _P, _P, _P]),
+    "k22_movq_plan_encoder": (_I, [_P, _I, _I, _I, C.POINTER(_Z)]),
+    "k22_movq_encode": (_I, [_P, _P, _P, _P]),
     "k22_movq_num_ops": (_I, [_P]),
     "k22_ddim_step": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _I, _I, _P]),
     "k22_plms_step": (_I, [_P, _P, _P, _P, _P, _I, _P, _F, _I, _P, _P, _P, _I, _I, _P]),

@@ -126,4 +126,8 @@ int launch_softmax_rows(void* x, int64_t rows, int L, float scale, int dtype, hi
 int launch_movq_prepare(const float* z, const float* wpq, const float* bpq, float* zq, void* xin, int B, int h, int w,
                         int Cpad, int dtype, hipStream_t s);
 // fp32 NCHW [-1,1] image -> uint8 NHWC:  ((x + 1) * 127.5).round().clamp(0, 255)   (kandinsky2/utils.py:57-70)
+int launch_movq_enc_prepare(const float* img, void* xin, int B, int H, int W, int Cpad, int dtype, hipStream_t s);
+int launch_pad_copy(const void* x, void* y, int B, int H, int W, int C, int dtype, hipStream_t s);
+int launch_subsample_odd(const void* x, void* y, int B, int H, int W, int C, int dtype, hipStream_t s);
+int launch_movq_quant_conv(const float* h, const float* wq, const float* bq, float* out, int B, int HW, hipStream_t s);
 int launch_to_uint8_nhwc(const float* x, unsigned char* y, int B, int C, int H, int W, hipStream_t s);

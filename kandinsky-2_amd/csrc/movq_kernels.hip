@@ -140,6 +140,106 @@ __global__ void to_uint8_nhwc_kernel(const float* x, unsigned char* y, int B, in
   }
 }
 
+// ---- MoVQ ENCODER helpers (Encoder.forward, kandinsky2/vqgan/vqgan_blocks.py:335-367) ------------------------------------
+// image fp32 NCHW [B][3][H][W] -> zero-bordered NHWC T [B][H+2][W+2][Cpad], channels 3.. zero (conv_in weights are
+// zero-extended to Cpad input channels the same way): one thread per padded pixel
+template <typename T>
+__global__ void movq_enc_prepare_kernel(const float* img, void* xin, int B, int H, int W, int Cpad) {
+  const int Hp = H + 2, Wp = W + 2;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * Hp * Wp) return;
+  const int xp = (int)(i % Wp), yp = (int)((i / Wp) % Hp), b = (int)(i / ((int64_t)Wp * Hp));
+  T* dst = reinterpret_cast<T*>(xin) + i * Cpad;
+  const int y = yp - 1, x = xp - 1;
+  float v[3] = {0.f, 0.f, 0.f};
+  if (x >= 0 && y >= 0 && x < W && y < H) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = img[(((int64_t)b * 3 + c) * H + y) * W + x];
+  }
+  for (int c = 0; c < Cpad; ++c) dst[c] = from_f32<T>(c < 3 ? v[c] : 0.f);
+}
+
+// NHWC [B][H][W][C] -> zero-bordered [B][H+2][W+2][C] (input of Downsample's 3x3 convolution)
+template <typename T>
+__global__ __launch_bounds__(256) void pad_copy_kernel(const void* xin, void* yout, int B, int H, int W, int C) {
+  constexpr int EPV = Vec16<T>::N;
+  const int CV = C / EPV, Hp = H + 2, Wp = W + 2;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Wp * CV) return;
+  const int xp = idx / CV, cv = idx - xp * CV;
+  const int xo = xp - 1, yo = (int)blockIdx.y - 1, b = blockIdx.z;
+  Vec16<T> o;
+  if (xo < 0 || yo < 0 || xo >= W || yo >= H) {
+#pragma unroll
+    for (int k = 0; k < EPV / 2; ++k) o.set2(k, 0.f, 0.f);
+  } else {
+    o.raw = *reinterpret_cast<const decltype(o.raw)*>(reinterpret_cast<const T*>(xin) + (((int64_t)b * H + yo) * W + xo) * C + cv * EPV);
+  }
+  *reinterpret_cast<decltype(o.raw)*>(reinterpret_cast<T*>(yout) + (((int64_t)b * Hp + blockIdx.y) * Wp + xp) * C + cv * EPV) = o.raw;
+}
+
+// Downsample (vqgan_blocks.py:109-126) = F.pad(x, (0,1,0,1)) + conv 3x3 stride 2: out[y][x] = sum w[ky][kx] x[2y+ky][2x+kx],
+// which is the stride-1 "same" convolution s1 (1-pixel zero border) taken at the odd positions: out[y][x] = s1[2y+1][2x+1]
+// (its bottom / right border supplies the asymmetric zero padding).  This kernel is the gather.
+template <typename T>
+__global__ __launch_bounds__(256) void subsample_odd_kernel(const void* xin, void* yout, int B, int H, int W, int C) {
+  constexpr int EPV = Vec16<T>::N;
+  const int CV = C / EPV, Ho = H / 2, Wo = W / 2;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Wo * CV) return;
+  const int xo = idx / CV, cv = idx - xo * CV;
+  const int yo = blockIdx.y, b = blockIdx.z;
+  Vec16<T> o;
+  o.raw = *reinterpret_cast<const decltype(o.raw)*>(reinterpret_cast<const T*>(xin) + (((int64_t)b * H + 2 * yo + 1) * W + 2 * xo + 1) * C + cv * EPV);
+  *reinterpret_cast<decltype(o.raw)*>(reinterpret_cast<T*>(yout) + (((int64_t)b * Ho + yo) * Wo + xo) * C + cv * EPV) = o.raw;
+}
+
+// quant_conv (1x1, z_channels -> embed_dim = 4 -> 4) on the fp32 NCHW encoder output (MOVQ.encode, autoencoder.py:176-180)
+__global__ void movq_quant_conv_kernel(const float* h, const float* wq, const float* bq, float* out, int B, int HW) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * HW) return;
+  const int b = (int)(i / HW), pix = (int)(i - (int64_t)b * HW);
+  float zi[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) zi[c] = h[((int64_t)b * 4 + c) * HW + pix];
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+    out[((int64_t)b * 4 + o) * HW + pix] = ((wq[o * 4] * zi[0] + wq[o * 4 + 1] * zi[1]) + (wq[o * 4 + 2] * zi[2] + wq[o * 4 + 3] * zi[3])) + bq[o];
+}
+
+int launch_movq_enc_prepare(const float* img, void* xin, int B, int H, int W, int Cpad, int dtype, hipStream_t s) {
+  const int64_t total = (int64_t)B * (H + 2) * (W + 2);
+  const unsigned nb = (unsigned)((total + 255) / 256);
+  if (dtype == K22_BF16) hipLaunchKernelGGL(movq_enc_prepare_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, img, xin, B, H, W, Cpad);
+  else hipLaunchKernelGGL(movq_enc_prepare_kernel<float>, dim3(nb), dim3(256), 0, s, img, xin, B, H, W, Cpad);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+int launch_pad_copy(const void* x, void* y, int B, int H, int W, int C, int dtype, hipStream_t s) {
+  const int epv = dtype == K22_BF16 ? 8 : 4;
+  if (C % epv || H + 2 > 65535) return k22_set_error(K22_EINVAL, "pad_copy: bad shape");
+  dim3 grid(((W + 2) * (C / epv) + 255) / 256, H + 2, B);
+  if (dtype == K22_BF16) hipLaunchKernelGGL(pad_copy_kernel<bf16_t>, grid, dim3(256), 0, s, x, y, B, H, W, C);
+  else hipLaunchKernelGGL(pad_copy_kernel<float>, grid, dim3(256), 0, s, x, y, B, H, W, C);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+int launch_subsample_odd(const void* x, void* y, int B, int H, int W, int C, int dtype, hipStream_t s) {
+  const int epv = dtype == K22_BF16 ? 8 : 4;
+  if (C % epv || (H & 1) || (W & 1) || H / 2 > 65535) return k22_set_error(K22_EINVAL, "subsample_odd: bad shape");
+  dim3 grid(((W / 2) * (C / epv) + 255) / 256, H / 2, B);
+  if (dtype == K22_BF16) hipLaunchKernelGGL(subsample_odd_kernel<bf16_t>, grid, dim3(256), 0, s, x, y, B, H, W, C);
+  else hipLaunchKernelGGL(subsample_odd_kernel<float>, grid, dim3(256), 0, s, x, y, B, H, W, C);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+int launch_movq_quant_conv(const float* h, const float* wq, const float* bq, float* out, int B, int HW, hipStream_t s) {
+  const int64_t total = (int64_t)B * HW;
+  hipLaunchKernelGGL(movq_quant_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, h, wq, bq, out, B, HW);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+
 int launch_spatialnorm_apply(const SpatialNormParams& p, int dtype, hipStream_t s) {
   const int epv = dtype == K22_BF16 ? 8 : 4;
   if (p.C % epv) return k22_set_error(K22_EINVAL, "spatialnorm: channel alignment");

@@ -148,6 +148,30 @@ def movq_case(name, B, h, w, seed_w=0, seed_z=5):
                os.path.join(GOLD, name + ".pt"))
 
 
+def movq_enc_case(name, B, H, W, seed_w=0, seed_x=6):
+    """MOVQ.encode of the REFERENCE module (kandinsky2/vqgan/autoencoder.py:176-180) on seeded weights / image."""
+    from kandinsky2_amd.movq import movq_encoder_blocks
+    cfg = k22.MOVQ_CONFIG_2_1
+    arch = k22.MoVQArch(cfg["ddconfig"], cfg["embed_dim"])
+    sd = k22.init_movq_encoder_state_dict(arch, seed=seed_w)
+    ae = ref_loader.ref("vqgan.autoencoder")
+    m = ae.MOVQ(ddconfig=cfg["ddconfig"], n_embed=cfg["n_embed"], embed_dim=cfg["embed_dim"]).eval()
+    r = m.load_state_dict(sd, strict=False)
+    assert not r.unexpected_keys and all(not k.startswith(("encoder.", "quant_conv")) for k in r.missing_keys)
+    ref_keys = sorted(k for k in m.state_dict().keys() if k.startswith(("encoder.", "quant_conv")))
+    assert ref_keys == sorted(sd.keys()), "encoder key set differs from the reference module"
+    g = torch.Generator().manual_seed(seed_x)
+    x = torch.randn(B, 3, H, W, generator=g).clamp(-2, 2) * 0.5
+    blocks, last = movq_encoder_blocks(arch)
+    with torch.no_grad():
+        ref_out = m.encode(x)
+        ora = movq_ref.movq_encode(sd, blocks, last, x)
+    d = (ora - ref_out).abs().max().item()
+    print(f"{name}: MOVQ.encode ref absmax {ref_out.abs().max():.4f}  oracle-vs-ref max|d| {d:.3e}")
+    assert d < 1e-5
+    torch.save(dict(name=name, B=B, H=H, W=W, seed_w=seed_w, seed_x=seed_x, out=ref_out.clone()), os.path.join(GOLD, name + ".pt"))
+
+
 class _CpuTorch:
     """Stand-in for the `torch` module inside kandinsky2/model/samplers.py, whose DDIM code hard-codes device "cuda"
     (samplers.py:79-80, 102, 228, 265): every device= / .to("cuda") is redirected to the CPU so that the REFERENCE
@@ -359,5 +383,7 @@ if __name__ == "__main__":
     prior_case("prior_tiny", k22.tiny_prior_hparams(), bs=2, steps=5)
     movq_case("movq_small", B=2, h=8, w=8)
     movq_case("movq_wide", B=1, h=8, w=16)
+    movq_enc_case("movq_enc_small", B=2, H=64, W=64)
+    movq_enc_case("movq_enc_wide", B=1, H=64, W=128)
     if a.full:
         run_case("full_c1_text2img", k22.MODEL_CONFIG_2_1, False, B=2, h=32, w=32, steps=10)

@@ -63,3 +63,46 @@ def movq_decode(sd, arch, quant):
 def process_images_u8(batch):
     """kandinsky2/utils.py:57-70 up to the PIL conversion: NCHW float -> NHWC uint8."""
     return ((batch + 1) * 127.5).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+
+
+# ---- MoVQ encode (MOVQ.encode, kandinsky2/vqgan/autoencoder.py:176-180; Encoder.forward, vqgan_blocks.py:335-367;
+# ResnetBlock.forward :166-186, AttnBlock.forward :215-239, Downsample.forward :119-126, Normalize :87-90) ------------
+def _gnorm(sd, name, x):
+    return F.group_norm(x, 32, sd[name + ".weight"], sd[name + ".bias"], eps=1e-6)
+
+
+def _res_e(sd, pfx, x, cin, cout):
+    h = _conv(sd, pfx + ".conv1", _swish(_gnorm(sd, pfx + ".norm1", x)), 1)
+    h = _conv(sd, pfx + ".conv2", _swish(_gnorm(sd, pfx + ".norm2", h)), 1)
+    if cin != cout:
+        x = _conv(sd, pfx + ".nin_shortcut", x)
+    return x + h
+
+
+def _attn_e(sd, pfx, x):
+    h_ = _gnorm(sd, pfx + ".norm", x)
+    q, k, v = _conv(sd, pfx + ".q", h_), _conv(sd, pfx + ".k", h_), _conv(sd, pfx + ".v", h_)
+    b, c, h, w = q.shape
+    q = q.reshape(b, c, h * w).permute(0, 2, 1)
+    k = k.reshape(b, c, h * w)
+    w_ = torch.bmm(q, k) * (int(c) ** (-0.5))
+    w_ = F.softmax(w_, dim=2)
+    v = v.reshape(b, c, h * w)
+    h_ = torch.bmm(v, w_.permute(0, 2, 1)).reshape(b, c, h, w)
+    return x + _conv(sd, pfx + ".proj_out", h_)
+
+
+def movq_encode(sd, blocks, last, image):
+    """sd: fp32 state_dict (encoder.*, quant_conv.*); blocks: kandinsky2_amd.movq.movq_encoder_blocks(arch)[0];
+    image [B,3,H,W] -> latent [B,4,H/8,W/8] (un-quantised, as MOVQ.encode returns it)."""
+    h = _conv(sd, "encoder.conv_in", image, 1)
+    for kind, pfx, cin, cout in blocks:
+        if kind == "res":
+            h = _res_e(sd, pfx, h, cin, cout)
+        elif kind == "attn":
+            h = _attn_e(sd, pfx, h)
+        else:  # Downsample: asymmetric zero pad (right, bottom) then a stride-2 3x3 convolution
+            h = F.conv2d(F.pad(h, (0, 1, 0, 1), mode="constant", value=0), sd[pfx + ".weight"], sd[pfx + ".bias"], stride=2, padding=0)
+    h = _swish(_gnorm(sd, "encoder.norm_out", h))
+    h = _conv(sd, "encoder.conv_out", h, 1)
+    return _conv(sd, "quant_conv", h)

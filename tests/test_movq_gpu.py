@@ -70,3 +70,42 @@ def test_movq_rejects_cpu_tensor():
     arch, m = _model(torch.float32)
     with pytest.raises(RuntimeError):
         m.decode(torch.zeros(1, 4, 8, 8))
+
+
+# ---- encoder (MOVQ.encode: the img2img / inpainting pre-step) -----------------------------------------------
+def _encoder(backend):
+    arch = k22.MoVQArch(k22.MOVQ_CONFIG_2_1["ddconfig"])
+    if "sd_enc" not in _SD:
+        _SD["sd_enc"] = k22.init_movq_encoder_state_dict(arch, seed=0)
+    m = k22.MoVQEncoderHIP(backend_dtype=backend)
+    m.load_state_dict(_SD["sd_enc"], strict=True)
+    return arch, m.to("cuda")
+
+
+@pytest.mark.parametrize("name", ["movq_enc_small", "movq_enc_wide"])
+@pytest.mark.parametrize("backend,tol", [(torch.float32, 2e-4), (torch.bfloat16, 6e-2)])
+def test_movq_encode_vs_reference_golden(golden_dir, name, backend, tol):
+    """Encoder.forward + quant_conv: plain GroupNorm ResnetBlocks, single-head attention at the last level, Downsample as
+    the stride-1 convolution gathered at the odd positions (asymmetric (0,1,0,1) padding)."""
+    fx = _fixture(golden_dir, name)
+    arch, m = _encoder(backend)
+    g = torch.Generator().manual_seed(fx["seed_x"])
+    x = torch.randn(fx["B"], 3, fx["H"], fx["W"], generator=g).clamp(-2, 2) * 0.5
+    out = m.encode(x.cuda())
+    ref = fx["out"]
+    scale = ref.abs().max().item()
+    err = (out.cpu() - ref).abs().max().item()
+    print(f"{name} {backend}: max|d|={err:.3e} scale={scale:.3f}")
+    assert out.shape == ref.shape and err <= tol * scale
+
+
+def test_movq_encode_then_decode_shapes_and_batch_independence():
+    arch, m = _encoder(torch.float32)
+    g = torch.Generator().manual_seed(12)
+    x = (torch.randn(2, 3, 64, 64, generator=g) * 0.5).cuda()
+    both = m.encode(x)
+    assert both.shape == (2, 4, 8, 8) and torch.equal(both, m.encode(x))
+    one = m.encode(x[1:2])
+    assert (one - both[1:2]).abs().max().item() <= 1e-5 * both.abs().max().item()
+    with pytest.raises(RuntimeError):
+        m.encode(torch.zeros(1, 3, 64, 64))
