@@ -130,6 +130,10 @@ size_t k22_sampler_scratch_bytes(int N, int HW);
  * (a_t, a_prev, sigma_t, sqrt(1 - a_t)); noise may be NULL (eta = 0); x0_out may be NULL. */
 int k22_ddim_step(const float* x, const float* model_out, const float* noise, const float* table_row, float guidance, int use_cfg,
                   float* x_out, float* x0_out, int N, int HW, void* stream);
+/* Inpainting mask pre-step (prepare_mask, kandinsky2/utils.py:11-31, an O(h*w) Python loop in the reference): every pixel
+ * whose ORIGINAL value is not 1 zeroes its up / left / up-left / down / right / down-right neighbours.  mask, out: device fp32
+ * [C][H][W], out of place (channel 0 decides, every channel is written). */
+int k22_prepare_mask(const float* mask, float* out, int C, int H, int W, void* stream);
 /* PLMS step (PLMSSampler.p_sample_plms, kandinsky2/model/samplers.py:566-637; eta = 0) with model_fn's guidance folded in:
  * e_t = u + g (c - u) of this model call; e' = Adams-Bashforth combination of e_t and the eps history by `order`
  * (0: e_t; 1: (3 e_t - h1)/2; 2: (23 e_t - 16 h1 + 5 h2)/12; 3: (55 e_t - 59 h1 + 37 h2 - 9 h3)/24; 4: (h1 + e_t)/2, the second

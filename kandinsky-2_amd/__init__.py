@@ -10,6 +10,7 @@ from .diffusion import SpacedDiffusionHIP, DDIMSamplerHIP, PLMSSamplerHIP, creat
 from .weights import init_unet_state_dict, make_conditioning
 from .prior import (PRIOR_HPARAMS_2_1, PRIOR_DIFFUSION_2_1, PriorDiffusionModelHIP, PriorSchedule, prior_param_shapes,
                     init_prior_state_dict, tiny_prior_hparams)
+from . import prestep
 from .movq import (MOVQ_CONFIG_2_1, MoVQArch, MoVQDecoderHIP, MoVQEncoderHIP, movq_param_shapes, init_movq_state_dict,
                    movq_encoder_param_shapes, init_movq_encoder_state_dict)
 
@@ -20,5 +21,5 @@ __all__ = [
     "PRIOR_HPARAMS_2_1", "PRIOR_DIFFUSION_2_1", "PriorDiffusionModelHIP", "PriorSchedule", "prior_param_shapes",
     "init_prior_state_dict", "tiny_prior_hparams",
     "MOVQ_CONFIG_2_1", "MoVQArch", "MoVQDecoderHIP", "MoVQEncoderHIP", "movq_param_shapes", "init_movq_state_dict",
-    "movq_encoder_param_shapes", "init_movq_encoder_state_dict",
+    "movq_encoder_param_shapes", "init_movq_encoder_state_dict", "prestep",
 ]

@@ -73,6 +73,7 @@ SIGNATURES = {
     "k22_movq_encode": (_I, [_P, _P, _P, _P]),
     "k22_movq_num_ops": (_I, [_P]),
     "k22_ddim_step": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _I, _I, _P]),
+    "k22_prepare_mask": (_I, [_P, _P, _I, _I, _I, _P]),
     "k22_plms_step": (_I, [_P, _P, _P, _P, _P, _I, _P, _F, _I, _P, _P, _P, _I, _I, _P]),
     "k22_sampler_scratch_bytes": (_Z, [_I, _I]),
     "k22_sampler_step": (_I, [_P, _P, _P, _P, _P, _P, _I, _F, _I, _F, _F, _I, _D, _P, _P, _P, _I, _I, _P]),

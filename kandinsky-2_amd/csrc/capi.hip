@@ -196,6 +196,11 @@ int k22_ddim_step(const float* x, const float* model_out, const float* noise, co
   return launch_ddim_step(x, model_out, noise, table_row, guidance, use_cfg, x_out, x0_out, N, HW, reinterpret_cast<hipStream_t>(stream));
 }
 
+int k22_prepare_mask(const float* mask, float* out, int C, int H, int W, void* stream) {
+  if (!mask || !out) return k22_set_error(K22_EINVAL, "prepare_mask: null argument");
+  return launch_prepare_mask(mask, out, C, H, W, reinterpret_cast<hipStream_t>(stream));
+}
+
 int k22_plms_step(const float* x, const float* model_out, const float* eps_hist1, const float* eps_hist2, const float* eps_hist3, int order,
                   const float* table_row, float guidance, int use_cfg, float* x_out, float* eps_out, float* x0_out, int N, int HW, void* stream) {
   if (!x || !model_out || !table_row || !x_out) return k22_set_error(K22_EINVAL, "plms_step: null argument");

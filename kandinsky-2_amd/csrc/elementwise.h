@@ -103,6 +103,7 @@ int launch_attention(const AttentionParams& p, int dtype, hipStream_t s);
 int launch_sampler_step(const SamplerParams& p, hipStream_t s);
 int launch_plms_step(const float* x, const float* model_out, const float* h1, const float* h2, const float* h3, int order, const float* tab,
                      float guidance, int use_cfg, float* x_out, float* e_store, float* x0_out, int N, int HW, hipStream_t s);
+int launch_prepare_mask(const float* old_mask, float* out, int C, int H, int W, hipStream_t s);
 int launch_ddim_step(const float* x, const float* model_out, const float* noise, const float* tab, float guidance, int use_cfg,
                      float* x_out, float* x0_out, int N, int HW, hipStream_t s);
 

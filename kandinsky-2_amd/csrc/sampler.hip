@@ -249,6 +249,32 @@ int launch_plms_step(const float* x, const float* model_out, const float* h1, co
   return K22_OK;
 }
 
+// ---- inpainting mask pre-step (prepare_mask, kandinsky2/utils.py:11-31) ----------------------------------------------------
+// The reference walks the latent-resolution mask in a Python double loop and, for every pixel whose ORIGINAL value is not 1,
+// zeroes six neighbours: up, left, up-left, down, right, down-right (not the anti-diagonal ones).  As a gather: a pixel
+// becomes 0 when any of the six in-bounds pixels it is such a neighbour OF had an original value != 1; else it keeps its
+// value.  mask: fp32 [C][H][W] (channel 0 decides, all channels are written, as mask[:, i, j] = 0 does).
+__global__ __launch_bounds__(256) void prepare_mask_kernel(const float* old_mask, float* out, int C, int H, int W) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= H * W) return;
+  const int y = i / W, x = i - y * W;
+  // target (y, x) = source + d  for d in {(-1,0), (0,-1), (-1,-1), (1,0), (0,1), (1,1)}  =>  source = target - d
+  const int sy[6] = {y + 1, y, y + 1, y - 1, y, y - 1};
+  const int sx[6] = {x, x + 1, x + 1, x, x - 1, x - 1};
+  bool kill = false;
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+    if (sy[k] >= 0 && sy[k] < H && sx[k] >= 0 && sx[k] < W && old_mask[sy[k] * W + sx[k]] != 1.0f) kill = true;
+  for (int c = 0; c < C; ++c) out[(c * H + y) * W + x] = kill ? 0.0f : old_mask[(c * H + y) * W + x];
+}
+
+int launch_prepare_mask(const float* old_mask, float* out, int C, int H, int W, hipStream_t s) {
+  if (C < 1 || H < 1 || W < 1 || old_mask == out) return k22_set_error(K22_EINVAL, "prepare_mask: bad arguments (out of place only)");
+  hipLaunchKernelGGL(prepare_mask_kernel, dim3((H * W + 255) / 256), dim3(256), 0, s, old_mask, out, C, H, W);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+
 int launch_ddim_step(const float* x, const float* model_out, const float* noise, const float* tab, float guidance, int use_cfg,
                      float* x_out, float* x0_out, int N, int HW, hipStream_t s) {
   if (N <= 0 || HW <= 0 || (use_cfg && (N & 1))) return k22_set_error(K22_EINVAL, "ddim_step: bad batch");

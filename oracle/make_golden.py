@@ -172,6 +172,35 @@ def movq_enc_case(name, B, H, W, seed_w=0, seed_x=6):
     torch.save(dict(name=name, B=B, H=H, W=W, seed_w=seed_w, seed_x=seed_x, out=ref_out.clone()), os.path.join(GOLD, name + ".pt"))
 
 
+def prestep_case(name="prestep"):
+    """prepare_mask and q_sample of the REFERENCE (kandinsky2/utils.py:11-54) on seeded masks / latents; the oracle's gather
+    form of prepare_mask must equal the reference's scatter loop on every mask."""
+    from oracle import prestep_ref
+    u = ref_loader.ref("utils")
+    g = torch.Generator().manual_seed(9)
+    masks = []
+    for (h, w, p) in [(8, 8, 0.9), (12, 20, 0.8), (5, 7, 0.5), (16, 16, 0.97), (6, 6, 1.1), (6, 6, -0.1)]:
+        masks.append((torch.rand(1, 1, h, w, generator=g) < p).float())
+    corner = torch.ones(1, 1, 6, 9); corner[0, 0, 0, 0] = 0; corner[0, 0, 5, 8] = 0; corner[0, 0, 0, 8] = 0
+    soft = torch.ones(1, 1, 7, 7); soft[0, 0, 3, 3] = 0.5                      # a non-binary value is "not 1" too
+    multi = (torch.rand(1, 3, 9, 9, generator=g) < 0.85).float()                 # channel 0 decides, all channels are written
+    masks += [corner, soft, multi]
+    outs = []
+    for m in masks:
+        ref = u.prepare_mask(m.clone())
+        assert torch.equal(prestep_ref.prepare_mask(m), ref), "oracle prepare_mask differs from the reference loop"
+        outs.append(ref.clone())
+    x = torch.randn(2, 4, 8, 8, generator=g)
+    noise = torch.randn(2, 4, 8, 8, generator=g)
+    qs = {}
+    for t in (0, 399, 979, 999):
+        ref = u.q_sample(x, torch.tensor(t), schedule_name="linear", num_steps=1000, noise=noise)
+        assert torch.equal(prestep_ref.q_sample(x, t, noise=noise), ref), "oracle q_sample differs from the reference"
+        qs[t] = ref.clone()
+    print(f"{name}: {len(masks)} masks, {len(qs)} q_sample timesteps: oracle == reference (bit-identical)")
+    torch.save(dict(masks=masks, mask_out=outs, x=x, noise=noise, q=qs), os.path.join(GOLD, name + ".pt"))
+
+
 class _CpuTorch:
     """Stand-in for the `torch` module inside kandinsky2/model/samplers.py, whose DDIM code hard-codes device "cuda"
     (samplers.py:79-80, 102, 228, 265): every device= / .to("cuda") is redirected to the CPU so that the REFERENCE
@@ -385,5 +414,6 @@ if __name__ == "__main__":
     movq_case("movq_wide", B=1, h=8, w=16)
     movq_enc_case("movq_enc_small", B=2, H=64, W=64)
     movq_enc_case("movq_enc_wide", B=1, H=64, W=128)
+    prestep_case()
     if a.full:
         run_case("full_c1_text2img", k22.MODEL_CONFIG_2_1, False, B=2, h=32, w=32, steps=10)

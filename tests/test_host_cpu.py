@@ -173,6 +173,16 @@ def test_movq_encoder_oracle_matches_reference_golden(golden_dir):
     assert torch.equal(out, fx["out"])
 
 
+def test_prestep_oracle_matches_reference_golden(golden_dir):
+    """prepare_mask (gather form) and q_sample of oracle/prestep_ref.py == kandinsky2/utils.py:11-54 (goldens made by calling it)."""
+    from oracle import prestep_ref
+    fx = _load(golden_dir, "prestep")
+    for m, want in zip(fx["masks"], fx["mask_out"]):
+        assert torch.equal(prestep_ref.prepare_mask(m), want)
+    for t, want in fx["q"].items():
+        assert torch.equal(prestep_ref.q_sample(fx["x"], t, noise=fx["noise"]), want)
+
+
 def test_movq_state_dict_keys_match_reference(golden_dir):
     with open(os.path.join(golden_dir, "ref_movq_keys.json")) as f:
         ref = json.load(f)
