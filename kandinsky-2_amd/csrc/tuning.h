@@ -183,7 +183,9 @@ inline int tune_igemm_ops(std::deque<Tuned>& tuned, int dtype, void* flush, size
         t.cfg = c;
         tuned_finish_cfg(t, dtype);
         float tmin = 1e30f;
-        for (int rep = 0; rep < 3 && rc == K22_OK; ++rep) {
+        // rep 0 = warm-up (code load, function attributes); the minimum of the next five is kept: a whole table costs well
+        // under a second, and a noisy pick stays for the life of the plan
+        for (int rep = 0; rep < 6 && rc == K22_OK; ++rep) {
           if (flush && flush_bytes) (void)hipMemsetAsync(flush, 0, flush_bytes, st);
           (void)hipEventRecord(e0, st);
           rc = t.run(st);
@@ -191,7 +193,7 @@ inline int tune_igemm_ops(std::deque<Tuned>& tuned, int dtype, void* flush, size
           if (hipStreamSynchronize(st) != hipSuccess) rc = k22_set_error(K22_EHIP, "tune: kernel failed");
           float ms = 0.f;
           (void)hipEventElapsedTime(&ms, e0, e1);
-          if (rep > 0 && ms < tmin) tmin = ms;  // rep 0 = warm-up (code load, function attributes)
+          if (rep > 0 && ms < tmin) tmin = ms;
         }
         if (rc) break;
         if (tmin < best_ms) { best_ms = tmin; best = c; }
