@@ -631,6 +631,7 @@ int launch_igemm(const IgemmParams& p, int dtype, hipStream_t stream) {
     q.splitk = pl.splitk;
     q.xcd_remap = g_xcd_remap;
     q.algo = pl.halo;
+    if (q.stages < 2 && g_stages_override >= 0) q.stages = g_stages_override;   // "igemm_stages" option (benches / tests)
     int rc = launch_conv3_halo(q, dtype, pl.bm, pl.splitk, stream);
     if (rc || pl.splitk == 1) return rc;
     return dtype == K22_BF16 ? launch_reduce<bf16_t>(q, stream) : launch_reduce<float>(q, stream);
