@@ -183,9 +183,10 @@ inline int tune_igemm_ops(std::deque<Tuned>& tuned, int dtype, void* flush, size
         t.cfg = c;
         tuned_finish_cfg(t, dtype);
         float tmin = 1e30f;
-        // rep 0 = warm-up (code load, function attributes); the minimum of the next five is kept: a whole table costs well
-        // under a second, and a noisy pick stays for the life of the plan
-        for (int rep = 0; rep < 6 && rc == K22_OK; ++rep) {
+        // rep 0 = warm-up (code load, function attributes); the minimum of the next K22_TUNE_REPS (default 5) is kept: a whole
+        // table costs about a second, and a noisy pick stays for the life of the plan
+        static const int timed_reps = [] { const char* e = getenv("K22_TUNE_REPS"); const int v = e ? atoi(e) : 5; return v < 1 ? 1 : (v > 20 ? 20 : v); }();
+        for (int rep = 0; rep <= timed_reps && rc == K22_OK; ++rep) {
           if (flush && flush_bytes) (void)hipMemsetAsync(flush, 0, flush_bytes, st);
           (void)hipEventRecord(e0, st);
           rc = t.run(st);

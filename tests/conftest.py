@@ -8,6 +8,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# the parity tests build dozens of engines: two timed runs per tile candidate keep the suite short (the bench uses five)
+os.environ.setdefault("K22_TUNE_REPS", "2")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
