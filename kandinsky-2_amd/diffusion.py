@@ -246,12 +246,19 @@ class PLMSSamplerHIP(DDIMSamplerHIP):
         samples, _ = sampler.sample(num_steps, batch_size * 2, (4, h, w), conditioning=model_kwargs, x_T=noise, init_step=None)
     """
 
+    def _step(self, x, model_out, hist, order, table_row, x_out, eps_out, x0_out):
+        """One fused k22_plms_step launch; hist = eps history, newest first (as many tensors as `order` needs)."""
+        N, HW = x.shape[0], x.shape[2] * x.shape[3]
+        h = [t.data_ptr() for t in hist] + [None, None, None]
+        _lib.check(_lib.lib().k22_plms_step(x.data_ptr(), model_out.data_ptr(), h[0], h[1], h[2], order, table_row.data_ptr(),
+                                            self.guidance_scale, 1, x_out.data_ptr(), _lib.ptr(eps_out), _lib.ptr(x0_out), N, HW,
+                                            _lib.current_stream()))
+
     @torch.no_grad()
     def sample(self, S, batch_size, shape, conditioning=None, eta=0.0, x_T=None, init_step=None, device="cuda", **_unused):
         if eta != 0:
             raise ValueError("ddim_eta must be 0 for PLMS")   # samplers.py:355-356
         self.make_schedule(S, ddim_eta=0.0, init_step=init_step)
-        L = _lib.lib()
         C, H, W = shape
         if C != 4 or batch_size % 2:
             raise ValueError("shape must be (4, h, w) and batch_size = 2*bs")
@@ -265,7 +272,6 @@ class PLMSSamplerHIP(DDIMSamplerHIP):
         kw = conditioning or {}
         time_range = np.flip(self.ddim_timesteps)
         total = len(time_range)
-        st = _lib.current_stream()
 
         def model(xx, step):
             half = xx[:bs]
@@ -273,20 +279,16 @@ class PLMSSamplerHIP(DDIMSamplerHIP):
 
         for i, step in enumerate(time_range):
             index = total - i - 1
-            row = table[index].data_ptr()
+            row = table[index]
             e_buf = next(b for b in hist if all(b is not o for o in old))
             out = model(x, step)
             if len(old) == 0:
                 # stage one: e_t -> e_buf, provisional x_prev -> x_next; stage two: model at t_next, e' = (e_t + e_next) / 2
-                _lib.check(L.k22_plms_step(x.data_ptr(), out.data_ptr(), None, None, None, 0, row, self.guidance_scale, 1,
-                                           x_next.data_ptr(), e_buf.data_ptr(), None, N, HW, st))
+                self._step(x, out, [], 0, row, x_next, e_buf, None)
                 out2 = model(x_next, time_range[min(i + 1, total - 1)])
-                _lib.check(L.k22_plms_step(x.data_ptr(), out2.data_ptr(), e_buf.data_ptr(), None, None, 4, row, self.guidance_scale, 1,
-                                           x_next.data_ptr(), None, x0.data_ptr(), N, HW, st))
+                self._step(x, out2, [e_buf], 4, row, x_next, None, x0)
             else:
-                h = [o.data_ptr() for o in reversed(old)] + [None, None]
-                _lib.check(L.k22_plms_step(x.data_ptr(), out.data_ptr(), h[0], h[1], h[2], len(old), row, self.guidance_scale, 1,
-                                           x_next.data_ptr(), e_buf.data_ptr(), x0.data_ptr(), N, HW, st))
+                self._step(x, out, list(reversed(old)), len(old), row, x_next, e_buf, x0)
             old.append(e_buf)
             if len(old) >= 4:
                 old.pop(0)

@@ -264,6 +264,49 @@ def test_plms_oracle_matches_reference_golden(golden_dir):
     assert torch.equal(out, fx["final"])
 
 
+def test_plms_host_loop_ring_and_schedule_on_cpu(golden_dir):
+    """PLMSSamplerHIP's host side (schedule table, two-stage start, eps history ring, order selection) with the fused device
+    step replaced by the same tensor expressions on the CPU and the CPU oracle as the UNet: must land exactly on the
+    reference PLMSSampler's golden latent."""
+    fx = _load(golden_dir, "tiny_plms")
+    arch = k22.make_arch(fx["model_config"])
+    sd = k22.init_unet_state_dict(arch, seed=fx["seed_w"])
+    full, pooled, image = k22.make_conditioning(arch, fx["B"], seed=2)
+
+    class CpuStep(k22.PLMSSamplerHIP):
+        def _step(self, x, model_out, hist, order, table_row, x_out, eps_out, x0_out):
+            eps = model_out[:, :4]
+            c, u = torch.split(eps, len(eps) // 2, dim=0)
+            he = u + self.guidance_scale * (c - u)
+            e = torch.cat([he, he], 0)
+            if order == 0:
+                ep = e
+            elif order == 4:
+                ep = (hist[0] + e) / 2
+            elif order == 1:
+                ep = (3 * e - hist[0]) / 2
+            elif order == 2:
+                ep = (23 * e - 16 * hist[0] + 5 * hist[1]) / 12
+            else:
+                ep = (55 * e - 59 * hist[0] + 37 * hist[1] - 9 * hist[2]) / 24
+            a_t, a_prev, s1m = table_row[0], table_row[1], table_row[3]
+            pred_x0 = (x - s1m * ep) / a_t.sqrt()
+            x_out.copy_(a_prev.sqrt() * pred_x0 + (1.0 - a_prev - torch.tensor(0.0) ** 2).sqrt() * ep)
+            if eps_out is not None:
+                eps_out.copy_(e)
+            if x0_out is not None:
+                x0_out.copy_(pred_x0)
+
+    def model(xc, ts, **_kw):
+        with torch.no_grad():
+            return unet_ref.unet_forward(sd, arch, xc, ts, full, pooled, image)
+
+    old = k22.create_gaussian_diffusion(**k22.DIFFUSION_CONFIG_2_1)
+    x_T = torch.randn(fx["B"], 4, fx["h"], fx["w"], generator=torch.Generator().manual_seed(43))
+    out, _ = CpuStep(model, old, fx["guidance"]).sample(fx["steps"], fx["B"], (4, fx["h"], fx["w"]), x_T=x_T, device="cpu")
+    assert torch.equal(out, fx["final"])
+
+
 def test_ddim_schedule_matches_oracle():
     old = k22.create_gaussian_diffusion(**k22.DIFFUSION_CONFIG_2_1)
     s = k22.DDIMSamplerHIP(None, old, 4.0)
