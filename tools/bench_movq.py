@@ -26,3 +26,17 @@ torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / n * 1e3
 gflop = {768: 4885.5, 1024: 9647.4}.get(a.size, 4885.5 * (a.size / 768) ** 2) * a.bs
 print(f"MoVQ decode {a.size}x{a.size} bs={a.bs} {a.dtype}: {ms:.2f} ms/image-batch  (~{gflop / ms:.0f} TFLOP/s, finite={bool(torch.isfinite(out).all())}, ws={m._ws.numel() / 2**20:.0f} MiB)")
+
+# encoder (img2img / inpainting pre-step): once per call
+e = k22.MoVQEncoderHIP(backend_dtype=torch.bfloat16 if a.dtype == "bf16" else torch.float32)
+e.load_state_dict(k22.init_movq_encoder_state_dict(arch, seed=0), strict=True)
+e = e.to("cuda")
+img = torch.randn(a.bs, 3, a.size, a.size, device="cuda") * 0.5
+lat_out = e.encode(img)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(n):
+    lat_out = e.encode(img)
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / n * 1e3
+print(f"MoVQ encode {a.size}x{a.size} bs={a.bs} {a.dtype}: {ms:.2f} ms/image-batch  (finite={bool(torch.isfinite(lat_out).all())}, ws={e._ws.numel() / 2**20:.0f} MiB)")
