@@ -211,10 +211,15 @@ class DDIMSamplerHIP:
         tab[:, 0], tab[:, 1], tab[:, 2], tab[:, 3] = alphas, alphas_prev, sigmas, np.sqrt(1.0 - alphas)
         self.table, self.eta = tab, float(ddim_eta)
 
+    def _ddim_step(self, x, model_out, noise, table_row, x_out, x0_out):
+        """One fused k22_ddim_step launch."""
+        N, HW = x.shape[0], x.shape[2] * x.shape[3]
+        _lib.check(_lib.lib().k22_ddim_step(x.data_ptr(), model_out.data_ptr(), _lib.ptr(noise), table_row.data_ptr(), self.guidance_scale, 1,
+                                            x_out.data_ptr(), x0_out.data_ptr(), N, HW, _lib.current_stream()))
+
     @torch.no_grad()
     def sample(self, S, batch_size, shape, conditioning=None, eta=0.0, x_T=None, init_step=None, noise_seq=None, device="cuda", **_unused):
         self.make_schedule(S, ddim_eta=eta, init_step=init_step)
-        L = _lib.lib()
         C, H, W = shape
         if C != 4 or batch_size % 2:
             raise ValueError("shape must be (4, h, w) and batch_size = 2*bs")
@@ -232,8 +237,7 @@ class DDIMSamplerHIP:
             nz = None
             if self.eta > 0.0:
                 nz = noise_seq[i].to(dev).float().contiguous() if noise_seq is not None else torch.randn_like(x)
-            _lib.check(L.k22_ddim_step(x.data_ptr(), out.data_ptr(), _lib.ptr(nz), table[index].data_ptr(), self.guidance_scale, 1,
-                                       x_next.data_ptr(), x0.data_ptr(), N, HW, _lib.current_stream()))
+            self._ddim_step(x, out, nz, table[index], x_next, x0)
             x, x_next = x_next, x
         return x, {"pred_x0": [x0]}
 

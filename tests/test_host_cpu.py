@@ -264,6 +264,35 @@ def test_plms_oracle_matches_reference_golden(golden_dir):
     assert torch.equal(out, fx["final"])
 
 
+def test_ddim_host_loop_and_schedule_on_cpu(golden_dir):
+    """DDIMSamplerHIP's host side (uniform timesteps, table rows, step order) with the fused device step replaced by the same
+    tensor expressions on the CPU and the CPU oracle as the UNet: lands on the reference DDIMSampler's golden latent."""
+    fx = _load(golden_dir, "tiny_ddim")
+    arch = k22.make_arch(fx["model_config"])
+    sd = k22.init_unet_state_dict(arch, seed=fx["seed_w"])
+    full, pooled, image = k22.make_conditioning(arch, fx["B"], seed=2)
+
+    class CpuStep(k22.DDIMSamplerHIP):
+        def _ddim_step(self, x, model_out, noise, table_row, x_out, x0_out):
+            eps = model_out[:, :4]
+            c, u = torch.split(eps, len(eps) // 2, dim=0)
+            he = u + self.guidance_scale * (c - u)
+            e = torch.cat([he, he], 0)
+            a_t, a_prev, sigma, s1m = table_row[0], table_row[1], table_row[2], table_row[3]
+            pred_x0 = (x - s1m * e) / a_t.sqrt()
+            x_out.copy_(a_prev.sqrt() * pred_x0 + (1.0 - a_prev - sigma ** 2).sqrt() * e + sigma * torch.zeros_like(x))
+            x0_out.copy_(pred_x0)
+
+    def model(xc, ts, **_kw):
+        with torch.no_grad():
+            return unet_ref.unet_forward(sd, arch, xc, ts, full, pooled, image)
+
+    old = k22.create_gaussian_diffusion(**k22.DIFFUSION_CONFIG_2_1)
+    x_T = torch.randn(fx["B"], 4, fx["h"], fx["w"], generator=torch.Generator().manual_seed(42))
+    out, _ = CpuStep(model, old, fx["guidance"]).sample(fx["steps"], fx["B"], (4, fx["h"], fx["w"]), x_T=x_T, device="cpu")
+    assert (out - fx["final"]).abs().max().item() <= 1e-4 * fx["final"].abs().max().item()
+
+
 def test_plms_host_loop_ring_and_schedule_on_cpu(golden_dir):
     """PLMSSamplerHIP's host side (schedule table, two-stage start, eps history ring, order selection) with the fused device
     step replaced by the same tensor expressions on the CPU and the CPU oracle as the UNet: must land exactly on the
