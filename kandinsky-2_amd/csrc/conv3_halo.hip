@@ -13,7 +13,7 @@
 //
 //   * 8 waves (4 along M x 2 along N), BM in {256, 128}, BN = 128, K slab = 128 bytes of channels
 //   * halo buffer double-buffered across slabs (the next slab's halo trickles in, one 8-row piece per wave per
-//     tap), weight tiles in an NBST-deep ring (2..4, as many as the LDS holds next to the halo) with a COUNTED
+//     tap), weight tiles in an NBST-deep ring (2, 3, 4 or 6: as many as the LDS holds next to the halo) with a COUNTED
 //     vmcnt: NBST-1 taps of weights are in flight across the ONE raw s_barrier per tap (at the low-resolution
 //     levels the weights stream from HBM, ~2 us away, and a tap is ~0.4 us of MFMA work)
 //   * LDS images are lane-linear per LDS-DMA instruction with the chunk-XOR swizzle of common.h on the source
@@ -22,6 +22,10 @@
 //     fp32 tile -> 32 B per thread row segments: bias, residual, one rounding, 16-byte stores, and the per-channel
 //     (sum, sum of squares) of the STORED values for the next GroupNorm (deterministic, no atomics)
 //   * split-K over channel slabs for the low-resolution levels (fp32 partials, finished by splitk_reduce)
+//   * variants selected by p.algo (measured in DESIGN.md section 9): 2 = this kernel; 7 = its LDS-DMA issued from inline asm
+//     (exact lgkmcnt for the fragment reads; the tuner's usual pick); 6 = 7 + explicit fragment pipeline; 5 = loader-wave
+//     specialisation; 3 / 4 = conv3_halo3 / conv3_halo4 below; 8 / 9 = measurement only.  gemm8_kernel (plain GEMM on the
+//     same frame, qkv / proj_out) lives in this file too because it shares the epilogue (halo_tail)
 //   * optional fused 1x1 skip_connection of the ResBlock (out += x . Ws^T): a second, plain-GEMM K loop over the
 //     block input's channels (A rows = the tile's own pixels, no halo) that accumulates into the same registers,
 //     so the skip tensor is never written, re-read or launched separately
