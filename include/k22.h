@@ -104,6 +104,19 @@ int k22_unet_num_ops(const K22UNet* u);
 int k22_unet_set_autotune(K22UNet* u, int on);
 int k22_unet_tuning_report(const K22UNet* u, char* buf, size_t cap);
 
+/* Tile table: the process-wide map  conv / GEMM problem -> tile configuration  that every engine consults BEFORE it
+ * measures anything (csrc/tuning.h).  The package ships kandinsky-2_amd/tiles_gfx950.txt (measured on an MI355X for the
+ * shapes of BASELINE.json's configs); the Python binding loads it when the library is opened, so those shapes get the
+ * same configurations, and therefore the same bits, on every box.  Problems outside the table are measured on the
+ * device at the first forward (K22_AUTOTUNE=0: fixed heuristic instead) and remembered for the life of the process;
+ * env K22_TUNE_CACHE=<file> persists them.  load / save return the number of lines (< 0 = error), size the number of
+ * entries, measured the number of entries this process timed itself. */
+int k22_tile_table_load(const char* path);
+int k22_tile_table_save(const char* path);
+int k22_tile_table_size(void);
+int k22_tile_table_measured(void);
+void k22_tile_table_clear(void);
+
 /* Measurement aid for bench.py: replays the planned forward EAGERLY `reps` times on `stream` with a HIP
  * event pair around every op, and reports per op class k (0 conv3x3, 1 GEMM, 2 GroupNorm, 3 attention,
  * 4 other): ms[k] = average summed device time per forward, flops[k]/bytes[k] = algorithmic work per

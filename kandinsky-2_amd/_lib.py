@@ -10,6 +10,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libk22hip.so")
+# conv / GEMM tile configurations measured once on an MI355X for the shapes of BASELINE.json's configs (csrc/tuning.h):
+# loaded when the library is opened so that those shapes run the same configurations - the same bits - on every box.
+# K22_TILE_TABLE=<file> substitutes another table, K22_TILE_TABLE=0 starts with an empty one.
+TILE_TABLE_PATH = os.path.join(_HERE, "tiles_gfx950.txt")
 
 K22_BF16, K22_F32 = 0, 1
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
@@ -47,6 +51,11 @@ SIGNATURES = {
     "k22_version": (_I, []),
     "k22_last_error": (C.c_char_p, []),
     "k22_set_option": (_I, [C.c_char_p, _I]),
+    "k22_tile_table_load": (_I, [C.c_char_p]),
+    "k22_tile_table_save": (_I, [C.c_char_p]),
+    "k22_tile_table_size": (_I, []),
+    "k22_tile_table_measured": (_I, []),
+    "k22_tile_table_clear": (None, []),
     "k22_unet_create": (_I, [C.POINTER(K22UNetConfig), C.POINTER(K22Weight), _I, C.POINTER(_P)]),
     "k22_unet_destroy": (None, [_P]),
     "k22_unet_plan": (_I, [_P, _I, _I, _I, C.POINTER(_Z)]),
@@ -107,6 +116,10 @@ def lib() -> C.CDLL:
             fn.restype = res
             fn.argtypes = args
         _lib = l
+        tbl = os.environ.get("K22_TILE_TABLE", TILE_TABLE_PATH)
+        if tbl != "0" and os.path.exists(tbl):
+            if l.k22_tile_table_load(tbl.encode()) < 0:
+                raise RuntimeError(f"k22: cannot read the tile table {tbl}")
     return _lib
 
 

@@ -2,6 +2,7 @@
 #include "kernels.h"
 #include "elementwise.h"
 #include "../../include/k22.h"
+#include "tuning.h"
 #include <stdio.h>
 #include <string.h>
 
@@ -28,6 +29,36 @@ int k22_set_option(const char* name, int value) {
   return k22_set_error(K22_EINVAL, "k22_set_option: unknown option");
 }
 const char* k22_last_error(void) { return g_err; }
+
+// ---- tile table (tuning.h) ---------------------------------------------------------------------------------------
+int k22_tile_table_load(const char* path) {
+  if (!path) return k22_set_error(K22_EINVAL, "k22_tile_table_load: null path");
+  const int n = tile_table_load_file(path);
+  if (n < 0) return k22_set_error(K22_EINVAL, "k22_tile_table_load: cannot read the file");
+  return n;
+}
+int k22_tile_table_save(const char* path) {
+  if (!path) return k22_set_error(K22_EINVAL, "k22_tile_table_save: null path");
+  const int n = tile_table_save_file(path);
+  if (n < 0) return k22_set_error(K22_EINVAL, "k22_tile_table_save: cannot write the file");
+  return n;
+}
+int k22_tile_table_size(void) {
+  TileTable& tt = tile_table();
+  std::lock_guard<std::mutex> lk(tt.mu);
+  return (int)tt.m.size();
+}
+int k22_tile_table_measured(void) {
+  TileTable& tt = tile_table();
+  std::lock_guard<std::mutex> lk(tt.mu);
+  return (int)tt.measured;
+}
+void k22_tile_table_clear(void) {
+  TileTable& tt = tile_table();
+  std::lock_guard<std::mutex> lk(tt.mu);
+  tt.m.clear();
+  tt.measured = 0;
+}
 
 int k22_gemm(const void* A0, const void* A1, const void* Wp, const float* bias, const void* residual, void* out,
              void* partial, int M, int N, int Npad, int K0, int K1, long lda0, long lda1, int ldo, int ldr,

@@ -1203,12 +1203,8 @@ bool gemm8_supported(const IgemmParams& p, int dtype, int bm) {
 template <typename T, int BM, int NST>
 static int launch_gemm8_cfg(const IgemmParams& p, int splitk, hipStream_t stream) {
   const size_t smem = gemm8_smem_bytes(BM, NST);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_kernel<T, BM, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-    attr_set = true;
-  }
+  static LdsAttrGuard attr_guard;
+  if (int rc_ = k22_ensure_lds_attr(attr_guard, reinterpret_cast<const void*>(&gemm8_kernel<T, BM, NST>), 160 * 1024, __FILE__, __LINE__)) return rc_;
   IgemmParams q = p;
   q.splitk = splitk;
   const int hw = p.H > 0 ? p.H * p.W : p.M;
@@ -1250,12 +1246,8 @@ int conv3_halo_tiles_per_image(const IgemmParams& p, int bm) { return (p.H * (p.
 template <typename T, int BM, int NBST, int LW, int MODE>
 static int launch_halo_cfg(const IgemmParams& p, int splitk, hipStream_t stream) {
   const size_t smem = halo_smem_bytes(p, BM, NBST);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_kernel<T, BM, NBST, false, LW, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-    attr_set = true;
-  }
+  static LdsAttrGuard attr_guard;
+  if (int rc_ = k22_ensure_lds_attr(attr_guard, reinterpret_cast<const void*>(&conv3_halo_kernel<T, BM, NBST, false, LW, MODE>), 160 * 1024, __FILE__, __LINE__)) return rc_;
   IgemmParams q = p;
   q.splitk = splitk;
   const int B = p.M / (p.H * p.W);
@@ -1276,12 +1268,8 @@ static int launch_halo_nbst(const IgemmParams& p, int nbst, int splitk, hipStrea
 template <typename T, int BM, int RB>
 static int launch_halo3_cfg(const IgemmParams& p, int splitk, hipStream_t stream) {
   const size_t smem = halo3_smem_bytes(p, BM, RB);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo3_kernel<T, BM, RB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-    attr_set = true;
-  }
+  static LdsAttrGuard attr_guard;
+  if (int rc_ = k22_ensure_lds_attr(attr_guard, reinterpret_cast<const void*>(&conv3_halo3_kernel<T, BM, RB>), 160 * 1024, __FILE__, __LINE__)) return rc_;
   IgemmParams q = p;
   q.splitk = splitk;
   const int B = p.M / (p.H * p.W);
@@ -1300,12 +1288,8 @@ static int launch_halo3_rb(const IgemmParams& p, int rb, int splitk, hipStream_t
 template <typename T, int BM, int NBST>
 static int launch_halo4_cfg(const IgemmParams& p, int splitk, hipStream_t stream) {
   const size_t smem = halo_smem_bytes(p, BM, NBST);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo4_kernel<T, BM, NBST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-    attr_set = true;
-  }
+  static LdsAttrGuard attr_guard;
+  if (int rc_ = k22_ensure_lds_attr(attr_guard, reinterpret_cast<const void*>(&conv3_halo4_kernel<T, BM, NBST>), 160 * 1024, __FILE__, __LINE__)) return rc_;
   IgemmParams q = p;
   q.splitk = splitk;
   const int B = p.M / (p.H * p.W);

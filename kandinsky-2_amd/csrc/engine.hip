@@ -372,15 +372,17 @@ struct K22UNet {
   }
 
   int plan(int nB, int nH, int nW) {
+    // validate before touching the current plan: a rejected shape leaves the engine usable at the old one
+    const int n_down = cfg.n_levels - 1;
+    if (nB < 1 || nH < 1 || nW < 1) return k22_set_error(K22_EINVAL, "unet: B, H, W must be positive");
+    if (nH % (1 << n_down) || nW % (1 << n_down)) return k22_set_error(K22_EINVAL, "unet: H, W must be divisible by 2^(levels-1)");
+    if (nB > 8) return k22_set_error(K22_EINVAL, "unet: batch (2*bs) must be <= 8 per engine call");
     B = nB; H = nH; W = nW;
     slots.clear(); ops.clear(); cond_ops.clear(); s_ctxkv.clear(); gsum_bytes = 0; n_attn = 0; err.clear();
     tuned.clear(); tuned_done = false;
     ws = nullptr; cond_set = false;
     if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
     const int mc = cfg.model_channels, ted = 4 * mc;
-    const int n_down = cfg.n_levels - 1;
-    if (H % (1 << n_down) || W % (1 << n_down)) return k22_set_error(K22_EINVAL, "unet: H, W must be divisible by 2^(levels-1)");
-    if (B > 8) return k22_set_error(K22_EINVAL, "unet: batch (2*bs) must be <= 8 per engine call");
 
     // total FiLM width = sum over ResBlocks of 2*Cout, in module order
     film_total = 0;
@@ -685,7 +687,7 @@ int k22_unet_forward(K22UNet* u, const float* x, const float* timesteps, const f
     K22_CPY(u->ptr(u->s_mask), inpaint_mask, (size_t)u->B * hw * 4);
   }
   if (u->autotune && !u->tuned_done) {
-    // first forward on this plan: pick every conv / GEMM tile configuration by measurement
+    // first forward on this plan: conv / GEMM problems the tile table does not know are measured on the device
     int rc = u->tune_all(st);
     if (rc) return rc;
     u->tuned_done = true;

@@ -568,11 +568,8 @@ static int launch_reduce(const IgemmParams& q, hipStream_t stream) {
 template <typename T, int BM, int BN, int STAGES>
 static int launch_cfg(const IgemmParams& p, int splitk, hipStream_t stream) {
   constexpr int smem = STAGES * (BM + BN) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+  static LdsAttrGuard attr_guard;
+  if (int rc_ = k22_ensure_lds_attr(attr_guard, reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, STAGES>), smem, __FILE__, __LINE__)) return rc_;
   IgemmParams q = p;
   q.splitk = splitk;
   q.xcd_remap = g_xcd_remap;

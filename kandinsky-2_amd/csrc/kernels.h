@@ -3,10 +3,26 @@
 #pragma once
 #include "common.h"
 
+#include <atomic>
+
 #define K22_OK 0
 #define K22_EINVAL (-1)
 #define K22_EHIP (-2)
 #define K22_ENOMEM (-3)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: one guard per kernel instantiation holds a
+// bit per device ordinal, so a process that drives several GPUs (or launches from several threads) sets it on each.
+struct LdsAttrGuard { std::atomic<unsigned long long> done{0}; };
+inline int k22_ensure_lds_attr(LdsAttrGuard& g, const void* fn, int bytes, const char* file, int line) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (g.done.load(std::memory_order_acquire) & bit) return K22_OK;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return k22_set_error_hip(e, file, line);
+  g.done.fetch_or(bit, std::memory_order_release);
+  return K22_OK;
+}
 
 // ---------------------------------------------------------------------------------------
 // Implicit GEMM:  out[m][n] = sum_k A(m,k) * Wp[n][k]  (+bias[n]) (+residual[m][n]) -> act

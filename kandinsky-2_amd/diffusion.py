@@ -73,13 +73,22 @@ def percentile_index(n: int, p: float = 99.5):
 
 class SpacedDiffusionHIP:
     """create_gaussian_diffusion(**diffusion_config) equivalent for the decoder UNet: EPSILON mean,
-    LEARNED_RANGE variance (learn_sigma=True), timestep respacing, rescale_timesteps."""
+    LEARNED_RANGE variance (learn_sigma=True), timestep respacing, rescale_timesteps.
 
-    def __init__(self, steps=1000, learn_sigma=True, sigma_small=False, noise_schedule="linear", use_kl=False,
-                 predict_xstart=False, rescale_timesteps=True, rescale_learned_sigmas=True, timestep_respacing="",
+    The keyword set AND the defaults are the reference's (model_creation.py:86-99: learn_sigma=False,
+    rescale_timesteps=False, rescale_learned_sigmas=False); the decoder configuration this engine implements is
+    learn_sigma=True, predict_xstart=False (CONFIG_2_1["diffusion_config"], configs.py:141-152) and anything else raises.
+    use_kl / rescale_learned_sigmas only select the training loss (model_creation.py:103-108) and do not touch sampling."""
+
+    def __init__(self, steps=1000, learn_sigma=False, sigma_small=False, noise_schedule="linear", use_kl=False,
+                 predict_xstart=False, rescale_timesteps=False, rescale_learned_sigmas=False, timestep_respacing="",
                  linear_start=0.0001, linear_end=0.02):
         if not learn_sigma or predict_xstart:
-            raise NotImplementedError("decoder sampler: learn_sigma=True, predict_xstart=False (CONFIG_2_1)")
+            raise NotImplementedError("decoder sampler: only learn_sigma=True, predict_xstart=False (CONFIG_2_1['diffusion_config']) is "
+                                      "implemented; pass the reference's diffusion_config explicitly (the prior's START_X / FIXED_SMALL "
+                                      "sampler lives in kandinsky2_amd.prior)")
+        if sigma_small:
+            raise NotImplementedError("sigma_small only matters with learn_sigma=False, which is not implemented")
         base_betas = named_betas(noise_schedule, steps, linear_start, linear_end)
         if not timestep_respacing:
             timestep_respacing = [steps]
@@ -128,25 +137,76 @@ class SpacedDiffusionHIP:
         tab[:, 7] = self.model_timesteps()
         return tab
 
+    @staticmethod
+    def _fusable_denoised_fn(denoised_fn, shape, dev):
+        """The sampler kernel implements denoised_fn as clamp(lo, hi) followed by the optional inpainting blend
+        x0 * (1 - mask) + init * mask (kandinsky2_1_model.py:237-243).  A reference-style Python closure is recognised by
+        probing it: returns (lo, hi, init [N,4,H,W] or None, mask [N,1,H,W] or None), or raises if it is anything else."""
+        if denoised_fn is None:
+            return float("-inf"), float("inf"), None, None
+        N, Cc, H, W = shape
+        big = 1.0e4
+        zero = denoised_fn(torch.zeros(shape, device=dev)).float()
+        top = denoised_fn(torch.full(shape, big, device=dev)).float()
+        bot = denoised_fn(torch.full(shape, -big, device=dev)).float()
+        hi, lo = (top - zero).max().item(), (bot - zero).min().item()
+        init = mask = None
+        if hi <= 0 or lo >= 0:
+            raise NotImplementedError("p_sample_loop: denoised_fn is not clamp(lo, hi) [+ inpainting blend]")
+        keep = (top - zero) / hi                           # = 1 - mask
+        if not torch.equal(keep, torch.ones_like(keep)) or zero.abs().max().item() != 0.0:
+            m4 = 1.0 - keep
+            mask = m4[:, :1].contiguous()
+            if not torch.equal(m4, mask.expand(N, Cc, H, W)):
+                raise NotImplementedError("p_sample_loop: denoised_fn blends with a per-channel mask")
+            init = torch.where(m4 > 0, zero / m4.clamp_min(1e-30), torch.zeros_like(zero)).contiguous()
+        g = torch.Generator(device="cpu").manual_seed(1234)
+        probe = (torch.randn(shape, generator=g) * 3.0).to(dev)
+        want = denoised_fn(probe.clone()).float()
+        got = probe.clamp(lo, hi)
+        if mask is not None:
+            got = got * (1 - mask) + init * mask
+        if (got - want).abs().max().item() > 1e-5 * max(1.0, want.abs().max().item()):
+            raise NotImplementedError("p_sample_loop: denoised_fn is not clamp(lo, hi) [+ inpainting blend]; only the reference's "
+                                      "denoised_fun (kandinsky2_1_model.py:237-243) can be folded into the sampler kernel")
+        return lo, hi, init, mask
+
     @torch.no_grad()
-    def p_sample_loop(self, model, shape: Sequence[int], model_kwargs: dict, guidance_scale: float,
-                      noise: Optional[torch.Tensor] = None, noise_seq: Optional[torch.Tensor] = None,
-                      device="cuda", init_step: Optional[int] = None, init_img: Optional[torch.Tensor] = None,
-                      img_mask: Optional[torch.Tensor] = None, clip_denoised: bool = True,
-                      return_pred_xstart: bool = False):
-        """Fused equivalent of
-            diffusion.p_sample_loop(model_fn, shape, device=, noise=, model_kwargs=, init_step=, denoised_fn=)
-        as Kandinsky2_1.generate_img calls it (kandinsky2_1_model.py:245-257) with sampler='p_sampler':
-        model_fn's classifier-free guidance (:222-233) and denoised_fun (clamp +-2, inpaint blend, :237-243)
-        are folded into k22_sampler_step.  `shape` = (2*bs, 4, h, w) with halves [cond | uncond];
-        noise_seq[k] (optional, [n_iters, *shape]) replaces randn_like at the k-th executed step.
+    def p_sample_loop(self, model, shape: Sequence[int], noise: Optional[torch.Tensor] = None, clip_denoised: bool = True,
+                      denoised_fn=None, model_kwargs: Optional[dict] = None, device=None, progress: bool = False,
+                      init_step: Optional[int] = None, *, guidance_scale: Optional[float] = None,
+                      noise_seq: Optional[torch.Tensor] = None, init_img: Optional[torch.Tensor] = None,
+                      img_mask: Optional[torch.Tensor] = None, return_pred_xstart: bool = False):
+        """GaussianDiffusion.p_sample_loop (gaussian_diffusion.py:384-425) with the reference's positional / keyword set, on
+        the GPU without a host round trip per step.  Two ways to call it:
+
+        * drop-in, exactly as Kandinsky2_1.generate_img does (kandinsky2_1_model.py:245-257):
+              diffusion.p_sample_loop(model_fn, (2*bs, 4, h, w), device=, noise=, progress=, model_kwargs=, init_step=,
+                                      denoised_fn=denoised_fun)
+          `model_fn` is the reference's closure (its classifier-free guidance runs as written, on the HIP UNet's output);
+          `denoised_fun` (clamp +-2, optional inpainting blend) is recognised by probing and folded into the sampler kernel;
+        * fused: pass the Text2ImUNetHIP itself as `model` plus guidance_scale= (and init_img= / img_mask= for inpainting):
+          model_fn's guidance and denoised_fun (clamp +-2) are computed inside k22_sampler_step.
+
+        `shape` = (2*bs, 4, h, w) with halves [cond | uncond].  noise_seq[k] (optional, [n_iters, *shape]) replaces
+        randn_like at the k-th executed step (parity tests inject the reference's noise).
         """
         L = _lib.lib()
         N, Cc, H, W = shape
         if Cc != 4 or N % 2:
             raise ValueError("shape must be (2*bs, 4, h, w)")
         bs = N // 2
-        dev = torch.device(device)
+        dev = torch.device("cuda" if device is None else device)
+        if dev.type != "cuda":
+            raise RuntimeError("p_sample_loop runs on the GPU only (no CPU fallback)")
+        model_kwargs = model_kwargs or {}
+        fused = guidance_scale is not None
+        if fused and not hasattr(model, "arch"):
+            raise TypeError("guidance_scale= needs the Text2ImUNetHIP itself as `model` (the guidance is fused into the sampler step)")
+        if (init_img is None) != (img_mask is None):
+            raise ValueError("init_img and img_mask go together")
+        if noise is not None and tuple(noise.shape) != tuple(shape):
+            raise ValueError(f"noise must have shape {tuple(shape)}")
         x = noise.to(dev).float().contiguous().clone() if noise is not None else torch.randn(*shape, device=dev)
         x_next = torch.empty_like(x)
         table = torch.from_numpy(self.step_table()).to(dev)
@@ -155,23 +215,44 @@ class SpacedDiffusionHIP:
         HW = H * W
         scratch = torch.empty(L.k22_sampler_scratch_bytes(N, HW), dtype=torch.uint8, device=dev)
         pct_lo, pct_gamma = percentile_index(4 * HW) if clip_denoised else (-1, 0.0)
-        init = mask = None
-        if (init_img is None) != (img_mask is None):
-            raise ValueError("init_img and img_mask go together")
-        if init_img is not None:
-            init = init_img.to(dev).float().contiguous()
-            mask = img_mask.to(dev).float().contiguous()
+        if fused:
+            if denoised_fn is not None:
+                raise ValueError("fused call: denoised_fn is implied (clamp +-2 and the init_img / img_mask blend)")
+            lo, hi, init, mask = -2.0, 2.0, init_img, img_mask
+        else:
+            if init_img is not None:
+                raise ValueError("drop-in call: the inpainting blend comes from denoised_fn; init_img= / img_mask= belong to the fused call")
+            lo, hi, init, mask = self._fusable_denoised_fn(denoised_fn, tuple(shape), dev)
+        if init is not None:
+            # the kernel indexes init as [N,4,H,W] and mask as [N,1,H,W]: broadcast what the reference's expression
+            # x_start * (1 - img_mask) + init_img * img_mask would broadcast (kandinsky2_1_model.py:238-240)
+            try:
+                init = init.to(dev).float().expand(N, 4, H, W).contiguous()
+                mask = mask.to(dev).float().expand(N, 1, H, W).contiguous()
+            except RuntimeError as e:
+                raise ValueError(f"init_img / img_mask do not broadcast to {(N, 4, H, W)} / {(N, 1, H, W)}: {e}") from None
+        if noise_seq is not None and tuple(noise_seq.shape[1:]) != tuple(shape):
+            raise ValueError(f"noise_seq must have shape [n_steps, {tuple(shape)}]")
         x0 = torch.empty_like(x) if return_pred_xstart else None
         indices = list(range(self.num_timesteps))[::-1] if init_step is None else list(range(self.num_timesteps))[:init_step][::-1]
+        if progress:
+            from tqdm.auto import tqdm
+            indices = tqdm(indices)
         stream = _lib.current_stream()
         for k, i in enumerate(indices):
-            half = x[:bs]
-            combined = torch.cat([half, half], dim=0)  # model_fn: the second half of x is never fed to the UNet
-            out = model(combined, ts_rows[i], **model_kwargs)
+            if fused:
+                half = x[:bs]
+                combined = torch.cat([half, half], dim=0)  # model_fn: the second half of x is never fed to the UNet
+                out = model(combined, ts_rows[i], **model_kwargs)
+            else:
+                out = model(x, ts_rows[i], **model_kwargs)   # already guided: [N, 8, H, W]
+                if tuple(out.shape) != (N, 8, H, W):
+                    raise ValueError(f"model_fn must return [N, 8, H, W] (eps | learned variance); got {tuple(out.shape)}")
+                out = out.float().contiguous()
             nz = noise_seq[k].to(dev).float().contiguous() if noise_seq is not None else torch.randn_like(x)
             _lib.check(L.k22_sampler_step(
                 x.data_ptr(), out.data_ptr(), nz.data_ptr(), _lib.ptr(init), _lib.ptr(mask), table.data_ptr(), i,
-                float(guidance_scale), 1, -2.0, 2.0, pct_lo, pct_gamma, scratch.data_ptr(),
+                float(guidance_scale) if fused else 1.0, 1 if fused else 0, lo, hi, pct_lo, pct_gamma, scratch.data_ptr(),
                 x_next.data_ptr(), _lib.ptr(x0), N, HW, stream))
             x, x_next = x_next, x
         if return_pred_xstart:

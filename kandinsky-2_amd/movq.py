@@ -235,6 +235,7 @@ class MoVQDecoderHIP(nn.Module):
         if self._handle is None:
             self.prepare()
         if self._plan_key != (B, h, w):
+            self._plan_key = None   # a failed plan / bind leaves the native engine without a plan: never skip re-planning after it
             nbytes = C.c_size_t()
             _lib.check(_lib.lib().k22_movq_plan(self._handle, B, h, w, C.byref(nbytes)))
             self._ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=self._arena.device)
@@ -450,6 +451,7 @@ class MoVQEncoderHIP(nn.Module):
         if self._handle is None:
             self.prepare()
         if self._plan_key != (B, H, W):
+            self._plan_key = None   # a failed plan / bind leaves the native engine without a plan: never skip re-planning after it
             nbytes = C.c_size_t()
             _lib.check(_lib.lib().k22_movq_plan_encoder(self._handle, B, H, W, C.byref(nbytes)))
             self._ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=self._arena.device)

@@ -235,6 +235,7 @@ class PriorDiffusionModelHIP(nn.Module):
         if self._handle is None:
             self.prepare()
         if self._plan_key != B:
+            self._plan_key = None   # a failed plan / bind leaves the native engine without a plan: never skip re-planning after it
             nbytes = C.c_size_t()
             _lib.check(_lib.lib().k22_prior_plan(self._handle, B, C.byref(nbytes)))
             self._ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=self._arena.device)

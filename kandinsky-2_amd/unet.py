@@ -164,6 +164,8 @@ class Text2ImUNetHIP(nn.Module):
             self.prepare()
         key = (B, H, W)
         if self._plan_key != key:
+            self._plan_key = None   # a failed plan / bind leaves the native engine without a plan: never skip re-planning after it
+            self._cond_key = None
             L = _lib.lib()
             nbytes = C.c_size_t()
             _lib.check(L.k22_unet_plan(self._handle, B, H, W, C.byref(nbytes)))
@@ -197,6 +199,16 @@ class Text2ImUNetHIP(nn.Module):
     def set_condition(self, full_emb, pooled_emb, image_emb):
         """Text2ImUNet.get_text_emb (text2im_model2_1.py:57-80) + hoisted encoder_kv projections."""
         L = _lib.lib()
+        if self._plan_key is None:
+            raise RuntimeError("set_condition: no plan yet (call forward, which plans for its input shape)")
+        B, a = self._plan_key[0], self.arch
+        ntext = a.ctx_len - a.num_image_embs
+        for name, t, want in (("full_emb", full_emb, (B, ntext, a.text_dim1)), ("pooled_emb", pooled_emb, (B, a.text_dim2)),
+                              ("image_emb", image_emb, (B, a.image_dim))):
+            if tuple(t.shape) != want:   # the engine copies B * ... bytes from these pointers: a wrong batch would read out of bounds
+                raise ValueError(f"{name} must have shape {want} for a batch of {B}; got {tuple(t.shape)}")
+            if t.device.type != "cuda":
+                raise RuntimeError(f"{name} must be on the GPU (no CPU fallback)")
         f = full_emb.detach().float().contiguous()
         p = pooled_emb.detach().float().contiguous()
         i = image_emb.detach().float().contiguous()
@@ -218,13 +230,21 @@ class Text2ImUNetHIP(nn.Module):
             self.set_condition(full_emb, pooled_emb, image_emb)
             self._cond_key = True
             self.cache = {"cached": True}
+        if timesteps.numel() != B:
+            raise ValueError(f"timesteps must hold one value per batch element ({B}); got {tuple(timesteps.shape)}")
         xf = x.detach().float().contiguous()
-        tf = timesteps.detach().float().contiguous()
+        tf = timesteps.detach().float().reshape(B).contiguous().to(x.device)
         img = msk = None
         if self.arch.inpainting:
-            # InpaintText2ImUNet.forward defaults (text2im_model2_1.py:146-150)
-            img = torch.zeros_like(xf) if inpaint_image is None else inpaint_image.detach().float().contiguous()
-            msk = torch.zeros_like(xf[:, :1]) if inpaint_mask is None else inpaint_mask.detach().float().contiguous()
+            # InpaintText2ImUNet.forward defaults (text2im_model2_1.py:146-150); operands are broadcast the way the
+            # reference's torch.cat([x, inpaint_image * inpaint_mask, inpaint_mask], dim=1) would need them ([B,4,H,W], [B,1,H,W])
+            try:
+                img = torch.zeros_like(xf) if inpaint_image is None else inpaint_image.detach().float().to(x.device).expand(B, 4, H, W).contiguous()
+                msk = torch.zeros_like(xf[:, :1]) if inpaint_mask is None else inpaint_mask.detach().float().to(x.device).expand(B, 1, H, W).contiguous()
+            except RuntimeError as e:
+                raise ValueError(f"inpaint_image / inpaint_mask do not match x {tuple(x.shape)}: {e}") from None
+        elif inpaint_image is not None or inpaint_mask is not None:
+            raise ValueError("inpaint_image / inpaint_mask given to a text2img UNet (create it with inpainting=True)")
         out = torch.empty(B, self.arch.out_channels, H, W, dtype=torch.float32, device=x.device)
         _lib.check(_lib.lib().k22_unet_forward(
             self._handle, xf.data_ptr(), tf.data_ptr(), _lib.ptr(img), _lib.ptr(msk), out.data_ptr(),

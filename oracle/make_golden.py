@@ -82,7 +82,7 @@ def ref_p_sample_loop(model, diffusion, x_T, noise_seq, kwargs, guidance, init_i
     return out
 
 
-def run_case(name, model_config, inpainting, B, h, w, steps, guidance=4.0, seed_w=0):
+def run_case(name, model_config, inpainting, B, h, w, steps, guidance=4.0, seed_w=0, compact=False):
     arch = k22.make_arch(model_config, inpainting=inpainting)
     sd = k22.init_unet_state_dict(arch, seed=seed_w)
     model = ref_model(model_config, inpainting)
@@ -102,7 +102,11 @@ def run_case(name, model_config, inpainting, B, h, w, steps, guidance=4.0, seed_
     print(f"  forward: ref absmax {ref_out.abs().max():.4f} std {ref_out.std():.4f}  oracle-vs-ref max|d| {(ora - ref_out).abs().max():.3e}")
     assert (ora - ref_out).abs().max() < 2e-4 * max(1.0, ref_out.abs().max().item())
     fix = dict(name=name, model_config=model_config, inpainting=inpainting, B=B, h=h, w=w, steps=steps, guidance=guidance,
-               seed_w=seed_w, t=t, forward_out=ref_out.clone())
+               seed_w=seed_w, t=t, absmax=ref_out.abs().max().item())
+    if compact:
+        fix["forward_compact"] = _compact(ref_out, stride=2)
+    else:
+        fix["forward_out"] = ref_out.clone()
     if steps:
         g = torch.Generator().manual_seed(42)
         x_T = torch.randn(B, 4, h, w, generator=g)
@@ -125,7 +129,90 @@ def run_case(name, model_config, inpainting, B, h, w, steps, guidance=4.0, seed_
     torch.save(fix, os.path.join(GOLD, name + ".pt"))
 
 
-def movq_case(name, B, h, w, seed_w=0, seed_z=5):
+def big_case(name, inpainting, bs, lat, steps, guidance=4.0, seed_w=0, keep=(1, 2, 5, 10, 25)):
+    """BASELINE.json configs at their full shapes (C2: 768^2 bs=1 50 steps; C4: inpainting 768^2 bs=4; SURVEY 8d inputs):
+    the REFERENCE create_model(...) (1.23 B params) + verbatim model_fn + SpacedDiffusion.p_sample_loop_progressive
+    (gaussian_diffusion.py:426-475; p_sample_loop is `final of the progressive loop`, :413-425) with injected noise.
+    Stores the first model output, the latent after the steps in `keep`, and the final latent.  The oracle restatement is
+    checked on the first forward only (the loop arithmetic is pinned bit-identical by the smaller cases)."""
+    import time
+    arch = k22.make_arch(k22.MODEL_CONFIG_2_1, inpainting=inpainting)
+    sd = k22.init_unet_state_dict(arch, seed=seed_w)
+    model = ref_model(k22.MODEL_CONFIG_2_1, inpainting)
+    model.load_state_dict(sd, strict=True)
+    B = 2 * bs
+    full, pooled, image = k22.make_conditioning(arch, B, seed=2)
+    g = torch.Generator().manual_seed(42)
+    x_T = torch.randn(B, 4, lat, lat, generator=g)
+    noise_seq = torch.randn(steps, B, 4, lat, lat, generator=g)
+    kw = dict(full_emb=full, pooled_emb=pooled, image_emb=image)
+    ii = mm = None
+    if inpainting:
+        _, ii, _ = inputs(arch, B, lat, lat)
+        mm = torch.zeros(B, 1, lat, lat)
+        mm[..., : lat // 2] = 1.0            # half-plane mask (SURVEY 8d)
+        kw.update(inpaint_image=ii * mm, inpaint_mask=mm)
+    gd = ref_loader.ref("model.gaussian_diffusion")
+    diff = ref_diffusion(steps)
+    first = {}
+
+    def model_fn(x_t, ts, **kwargs):  # kandinsky2_1_model.py:222-233, sampler == 'p_sampler'
+        half = x_t[: len(x_t) // 2]
+        combined = torch.cat([half, half], dim=0)
+        model_out = model(combined, ts, **kwargs)
+        if "out" not in first:
+            first["out"], first["ts"] = model_out.clone(), ts.clone()
+        eps, rest = model_out[:, :4], model_out[:, 4:]
+        cond_eps, uncond_eps = torch.split(eps, len(eps) // 2, dim=0)
+        half_eps = uncond_eps + guidance * (cond_eps - uncond_eps)
+        eps = torch.cat([half_eps, half_eps], dim=0)
+        return torch.cat([eps, rest], dim=1)
+
+    if mm is not None:
+        def denoised_fun(x_start):
+            x_start = x_start.clamp(-2, 2)
+            return x_start * (1 - mm) + ii * mm
+    else:
+        def denoised_fun(x):
+            return x.clamp(-2, 2)
+
+    it = iter(list(noise_seq))
+    orig = gd.th.randn_like
+    gd.th.randn_like = lambda t: next(it).to(t)
+    traj = {}
+    t0 = time.time()
+    try:
+        model.del_cache()
+        n = 0
+        for out in diff.p_sample_loop_progressive(model_fn, tuple(x_T.shape), device="cpu", noise=x_T.clone(), progress=False,
+                                                  model_kwargs=kw, init_step=None, denoised_fn=denoised_fun):
+            n += 1
+            if n in keep:
+                traj[n] = out["sample"].clone()
+            final = out["sample"]
+            print(f"  {name}: step {n}/{steps}  {time.time() - t0:.0f} s  absmax {final.abs().max():.3f}", flush=True)
+        model.del_cache()
+    finally:
+        gd.th.randn_like = orig
+    ora = unet_ref.unet_forward(sd, arch, torch.cat([x_T[:bs], x_T[:bs]], 0), first["ts"].float(), full, pooled, image,
+                                kw.get("inpaint_image"), kw.get("inpaint_mask"))
+    d = (ora - first["out"]).abs().max().item()
+    print(f"{name}: first forward ref absmax {first['out'].abs().max():.4f}  oracle-vs-ref max|d| {d:.3e}")
+    assert d < 2e-4 * max(1.0, first["out"].abs().max().item())
+    torch.save(dict(name=name, inpainting=inpainting, bs=bs, B=B, lat=lat, steps=steps, guidance=guidance, seed_w=seed_w,
+                    first_ts=first["ts"], first_out=first["out"], traj=traj, final=final.clone()),
+               os.path.join(GOLD, name + ".pt"))
+
+
+def _compact(out, stride=4, band=8):
+    """Large fp32 images are stored as a strided sub-grid plus one full-resolution band of rows and one of columns (every
+    pixel class of the tiling is hit) so that the fixture stays small; the uint8 image is stored whole."""
+    H, W = out.shape[-2:]
+    return dict(stride=stride, sub=out[..., ::stride, ::stride].clone(), r0=H // 2 - 3, rows=out[..., H // 2 - 3: H // 2 - 3 + band, :].clone(),
+                c0=W // 3, cols=out[..., :, W // 3: W // 3 + band].clone())
+
+
+def movq_case(name, B, h, w, seed_w=0, seed_z=5, compact=False):
     """MOVQ.decode of the REFERENCE module (kandinsky2/vqgan/autoencoder.py:163-185) on seeded weights / latent."""
     cfg = k22.MOVQ_CONFIG_2_1
     arch = k22.MoVQArch(cfg["ddconfig"], cfg["embed_dim"])
@@ -144,8 +231,12 @@ def movq_case(name, B, h, w, seed_w=0, seed_z=5):
     d = (ora - ref_out).abs().max().item()
     print(f"{name}: MOVQ.decode ref absmax {ref_out.abs().max():.4f}  oracle-vs-ref max|d| {d:.3e}")
     assert d < 1e-5 and torch.equal(movq_ref.process_images_u8(ref_out), ref_u8)
-    torch.save(dict(name=name, B=B, h=h, w=w, seed_w=seed_w, seed_z=seed_z, out=ref_out.clone(), out_u8=ref_u8.clone()),
-               os.path.join(GOLD, name + ".pt"))
+    fix = dict(name=name, B=B, h=h, w=w, seed_w=seed_w, seed_z=seed_z, out_u8=ref_u8.clone(), absmax=ref_out.abs().max().item())
+    if compact:
+        fix["out_compact"] = _compact(ref_out)
+    else:
+        fix["out"] = ref_out.clone()
+    torch.save(fix, os.path.join(GOLD, name + ".pt"))
 
 
 def movq_enc_case(name, B, H, W, seed_w=0, seed_x=6):
@@ -397,12 +488,33 @@ def table_fixtures():
     print("tables + keys written;", len(keys["text2img"]), "keys")
 
 
+BIG_CASES = {
+    # BASELINE.json configs[1] (C2): 768x768 bs=1, 50 steps -> CFG batch [2,4,96,96]; ~15 min on 8 cores
+    "c2": lambda: big_case("c2_text2img", False, bs=1, lat=96, steps=50),
+    # configs[3] (C4): inpainting 768x768 bs=4 -> [8,9ch,96,96]; ~1 h on 8 cores
+    "c4": lambda: big_case("c4_inpaint", True, bs=4, lat=96, steps=50, keep=(1, 10, 25)),
+    # configs[2] (C3) per-GPU shape: 1024x1024, 4 images per GPU -> one forward of the CFG batch [8,4,128,128]
+    "c3": lambda: run_case("c3_forward", k22.MODEL_CONFIG_2_1, False, B=8, h=128, w=128, steps=0, compact=True),
+    # the production prior (2048 wide x 20 layers, K = 8192 MLP): transformer forward + a 5-step sample, bs = 2
+    "prior": lambda: prior_case("prior_full", k22.PRIOR_HPARAMS_2_1, bs=2, steps=5),
+    # MoVQ at real sizes: 32x32 latents (256x256 px, attention over T = 1024) and C2's 96x96 (768x768 px, T = 9216)
+    "movq32": lambda: movq_case("movq_256px", B=1, h=32, w=32, compact=True),
+    "movq96": lambda: movq_case("movq_768px", B=1, h=96, w=96, compact=True),
+    "movqenc": lambda: (movq_enc_case("movq_enc_256px", B=1, H=256, W=256), movq_enc_case("movq_enc_768px", B=1, H=768, W=768)),
+}
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
+    ap.add_argument("--only", default="", help="comma list of the big cases to (re)generate: c2, c4, ... (skips everything else)")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
+    if a.only:
+        for c in a.only.split(","):
+            BIG_CASES[c]()
+        sys.exit(0)
     table_fixtures()
     tiny = k22.tiny_model_config()
     run_case("tiny_text2img", tiny, False, B=2, h=16, w=16, steps=6)

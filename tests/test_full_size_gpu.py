@@ -1,0 +1,255 @@
+"""GPU parity at the FULL shapes of BASELINE.json's configs, against golden outputs of the REFERENCE's own modules
+(oracle/make_golden.py --only c2,c3,c4: reference create_model(...) 1.23 B params + verbatim model_fn +
+SpacedDiffusion.p_sample_loop_progressive with injected noise, kandinsky2_1_model.py:222-257,
+gaussian_diffusion.py:384-475).
+
+  C2  text2img 768x768, bs 1, 50 steps  -> CFG batch [2,4,96,96]      (the configuration bench.py times)
+  C3  1024x1024, 4 images per GPU       -> one forward of [8,4,128,128]
+  C4  inpainting 768x768, bs 4, 50 steps -> [8,9ch,96,96] + masked-latent blend
+
+Gates:
+  * fp32 engine (exact-fp32 MFMA): final latent within 1e-3 max-abs of the reference p_sampler (the north-star statement),
+    every stored intermediate latent too; first forward within 2e-4 of the output scale;
+  * bf16 engine (the benchmarked path): bf16 storage of activations / weights cannot meet 1e-3 after 50 chained,
+    thresholded steps of a random-weight UNet (the reference's own fp16 mode does not either: DESIGN.md section 3 has its
+    measured drift); its max-abs / rms distance from the fp32 reference is MEASURED here and bounded at 2x the value
+    observed on MI355X with the shipped tile table (BF16_BOUNDS below; numbers in DESIGN.md section 3), so a wrong tile
+    variant, a broken split-K or a mis-rounded epilogue shows up as a failed bound, not as "drift".
+"""
+import json
+import os
+
+import pytest
+import torch
+
+import kandinsky2_amd as k22
+
+pytestmark = pytest.mark.gpu
+
+# bounds = 2x the values measured on MI355X with the shipped tile table (profiles/r02_parity_*.json):
+#   first_forward_rel: max-abs of one raw UNet output / its scale      (C2 measured 7.4e-3)
+#   traj: (max-abs, rms) over every stored latent of the 50-step loop  (C2 measured 2.8e-2 at step 25, 3.6e-3 rms at step 50)
+BF16_BOUNDS = {
+    "c2_text2img": {"first_forward_rel": 1.5e-2, "traj": (0.06, 0.0075)},
+    "c4_inpaint": {"first_forward_rel": 1.5e-2, "traj": (0.06, 0.0075)},
+    "c3_forward": {"first_forward_rel": 1.5e-2},
+}
+
+_SD = {}
+_REPORT = {}
+
+
+def _load(golden_dir, name):
+    p = os.path.join(golden_dir, name + ".pt")
+    if not os.path.exists(p):
+        pytest.skip(f"{name}.pt not generated")
+    return torch.load(p, weights_only=False)
+
+
+def _state_dict(inpainting):
+    if inpainting not in _SD:
+        _SD.clear()   # one 4.9 GB fp32 state dict at a time
+        arch = k22.make_arch(k22.MODEL_CONFIG_2_1, inpainting=inpainting)
+        _SD[inpainting] = (arch, k22.init_unet_state_dict(arch, seed=0))
+    return _SD[inpainting]
+
+
+def _model(inpainting, backend):
+    arch, sd = _state_dict(inpainting)
+    m = k22.Text2ImUNetHIP(arch, backend_dtype=backend, use_graph=True)
+    m.load_state_dict(sd)
+    m = m.to("cuda").eval()
+    m.prepare(free_params=True)
+    return arch, m
+
+
+def _record(name, key, **vals):
+    _REPORT.setdefault(name, {})[key] = vals
+    out = os.environ.get("K22_PARITY_REPORT")
+    if out:
+        with open(out, "w") as f:
+            json.dump(_REPORT, f, indent=1, sort_keys=True)
+
+
+def _loop_case(fx, backend):
+    """Runs the fused p_sampler on the fixture's seeded inputs; returns {step: latent} for the stored steps + 'final' + the
+    first raw UNet output."""
+    inp, bs, B, lat, steps = fx["inpainting"], fx["bs"], fx["B"], fx["lat"], fx["steps"]
+    arch, m = _model(inp, backend)
+    full, pooled, image = k22.make_conditioning(arch, B, seed=2)
+    g = torch.Generator().manual_seed(42)
+    x_T = torch.randn(B, 4, lat, lat, generator=g)
+    noise_seq = torch.randn(steps, B, 4, lat, lat, generator=g)
+    kw = dict(full_emb=full.cuda(), pooled_emb=pooled.cuda(), image_emb=image.cuda())
+    ii = mm = None
+    if inp:
+        g3 = torch.Generator().manual_seed(3)
+        _x = torch.randn(B, 4, lat, lat, generator=g3)
+        ii = torch.randn(B, 4, lat, lat, generator=g3).cuda()
+        mm = torch.zeros(B, 1, lat, lat)
+        mm[..., : lat // 2] = 1.0
+        mm = mm.cuda()
+        kw.update(inpaint_image=ii * mm, inpaint_mask=mm)
+    d = k22.create_gaussian_diffusion(**dict(k22.DIFFUSION_CONFIG_2_1, timestep_respacing=str(steps)))
+    first = m(torch.cat([x_T[:bs], x_T[:bs]], 0).cuda(), fx["first_ts"].float().cuda(), **kw).cpu()
+    out = {}
+    # the loop is run in segments that end at the stored steps (the engine keeps no state between steps other than x, so a
+    # segmented run is the same computation as one p_sample_loop call: asserted bit-for-bit in the fp32 test)
+    x = x_T.cuda()
+    done = 0
+    for stop in sorted(fx["traj"].keys()) + [steps]:
+        if stop > done:
+            x = _segment(d, m, x, kw, fx, noise_seq, done, stop, ii, mm)
+            done = stop
+        out[stop] = x.cpu()
+    out["final"] = out[steps]
+    return first, out
+
+
+def _segment(d, m, x, kw, fx, noise_seq, done, stop, ii, mm):
+    """steps done+1 .. stop of the T-step loop: loop indices T-1-done down to T-stop."""
+    from kandinsky2_amd import _lib
+    L = _lib.lib()
+    B, lat, T, bs = fx["B"], fx["lat"], fx["steps"], fx["bs"]
+    HW = lat * lat
+    table = torch.from_numpy(d.step_table()).cuda()
+    ts_rows = torch.from_numpy(d.model_timesteps()).cuda()[:, None].expand(-1, B).contiguous()
+    scratch = torch.empty(L.k22_sampler_scratch_bytes(B, HW), dtype=torch.uint8, device="cuda")
+    lo, gamma = k22.percentile_index(4 * HW)
+    x = x.clone()
+    x_next = torch.empty_like(x)
+    for k in range(done, stop):
+        i = T - 1 - k
+        half = x[:bs]
+        out = m(torch.cat([half, half], 0), ts_rows[i], **kw)
+        nz = noise_seq[k].cuda().contiguous()
+        _lib.check(L.k22_sampler_step(x.data_ptr(), out.data_ptr(), nz.data_ptr(), _lib.ptr(ii), _lib.ptr(mm), table.data_ptr(), i,
+                                      float(fx["guidance"]), 1, -2.0, 2.0, lo, gamma, scratch.data_ptr(), x_next.data_ptr(), None, B, HW,
+                                      _lib.current_stream()))
+        x, x_next = x_next, x
+    return x
+
+
+def _dist(a, b):
+    d = (a - b).float()
+    return d.abs().max().item(), d.pow(2).mean().sqrt().item()
+
+
+@pytest.mark.parametrize("name", ["c2_text2img", "c4_inpaint"])
+def test_full_size_p_sampler_fp32_gate(golden_dir, name):
+    """North-star gate at the benchmarked shape: reference p_sampler, fixed seed, injected noise, 50 steps, <= 1e-3 max-abs."""
+    fx = _load(golden_dir, name)
+    first, traj = _loop_case(fx, torch.float32)
+    scale = fx["first_out"].abs().max().item()
+    e_first = (first - fx["first_out"]).abs().max().item()
+    print(f"{name} fp32: first forward max|d| {e_first:.3e} (scale {scale:.2f})")
+    _record(name, "fp32_first_forward", max_abs=e_first, scale=scale)
+    assert e_first <= 2e-4 * scale
+    for n in sorted(fx["traj"].keys()):
+        ma, rms = _dist(traj[n], fx["traj"][n])
+        print(f"{name} fp32: latent after step {n:2d}: max|d| {ma:.3e} rms {rms:.3e}")
+        _record(name, f"fp32_step{n}", max_abs=ma, rms=rms)
+        assert ma <= 1e-3
+    ma, rms = _dist(traj["final"], fx["final"])
+    print(f"{name} fp32: FINAL latent ({fx['steps']} steps): max|d| {ma:.3e} rms {rms:.3e}")
+    _record(name, "fp32_final", max_abs=ma, rms=rms)
+    assert ma <= 1e-3
+    # the loop entry point gives the same bits as the segmented run above
+    inp = fx["inpainting"]
+    if not inp:
+        arch, m = _model(inp, torch.float32)
+        B, lat, steps = fx["B"], fx["lat"], fx["steps"]
+        full, pooled, image = k22.make_conditioning(arch, B, seed=2)
+        g = torch.Generator().manual_seed(42)
+        x_T = torch.randn(B, 4, lat, lat, generator=g)
+        noise_seq = torch.randn(steps, B, 4, lat, lat, generator=g)
+        d = k22.create_gaussian_diffusion(**dict(k22.DIFFUSION_CONFIG_2_1, timestep_respacing=str(steps)))
+        whole = d.p_sample_loop(m, (B, 4, lat, lat), model_kwargs=dict(full_emb=full.cuda(), pooled_emb=pooled.cuda(), image_emb=image.cuda()),
+                                guidance_scale=fx["guidance"], noise=x_T.cuda(), noise_seq=noise_seq.cuda()).cpu()
+        assert torch.equal(whole, traj["final"])
+
+
+@pytest.mark.parametrize("name", ["c2_text2img", "c4_inpaint"])
+def test_full_size_p_sampler_bf16_measured_bound(golden_dir, name):
+    """The benchmarked dtype at the benchmarked shape: distance of the bf16 engine's latents from the fp32 reference,
+    measured, reported, and bounded at 2x the value observed with the shipped tile table."""
+    fx = _load(golden_dir, name)
+    first, traj = _loop_case(fx, torch.bfloat16)
+    scale = fx["first_out"].abs().max().item()
+    e_first = (first - fx["first_out"]).abs().max().item()
+    print(f"{name} bf16: first forward max|d| {e_first:.3e} = {e_first / scale:.3e} of scale {scale:.2f}")
+    _record(name, "bf16_first_forward", max_abs=e_first, scale=scale, rel=e_first / scale)
+    bound = BF16_BOUNDS[name]
+    worst = (0.0, 0.0)
+    for n in sorted(fx["traj"].keys()):
+        ma, rms = _dist(traj[n], fx["traj"][n])
+        worst = (max(worst[0], ma), max(worst[1], rms))
+        print(f"{name} bf16: latent after step {n:2d}: max|d| {ma:.3e} rms {rms:.3e}")
+        _record(name, f"bf16_step{n}", max_abs=ma, rms=rms)
+    ma, rms = _dist(traj["final"], fx["final"])
+    worst = (max(worst[0], ma), max(worst[1], rms))
+    print(f"{name} bf16: FINAL latent ({fx['steps']} steps): max|d| {ma:.3e} rms {rms:.3e}  (latent range [-1, 1])")
+    _record(name, "bf16_final", max_abs=ma, rms=rms)
+    assert torch.isfinite(traj["final"]).all()
+    assert e_first <= bound["first_forward_rel"] * scale
+    assert worst[0] <= bound["traj"][0] and worst[1] <= bound["traj"][1]
+
+
+def _compact_err(out, c):
+    """max-abs distance on the stored sub-grid, row band and column band of a compact fixture (make_golden._compact)."""
+    s = c["stride"]
+    e = (out[..., ::s, ::s] - c["sub"]).abs().max().item()
+    e = max(e, (out[..., c["r0"]: c["r0"] + c["rows"].shape[-2], :] - c["rows"]).abs().max().item())
+    e = max(e, (out[..., :, c["c0"]: c["c0"] + c["cols"].shape[-1]] - c["cols"]).abs().max().item())
+    return e
+
+
+@pytest.mark.parametrize("backend", [torch.float32, torch.bfloat16])
+def test_c3_forward_1024px_batch8(golden_dir, backend):
+    """C3's per-GPU shape (1024x1024, 4 images -> CFG batch 8 at 128x128 latents): one forward against the reference."""
+    fx = _load(golden_dir, "c3_forward")
+    arch, m = _model(False, backend)
+    B, h, w = fx["B"], fx["h"], fx["w"]
+    full, pooled, image = k22.make_conditioning(arch, B, seed=2)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 4, h, w, generator=g)
+    out = m(x.cuda(), fx["t"].cuda(), full_emb=full.cuda(), pooled_emb=pooled.cuda(), image_emb=image.cuda()).cpu()
+    scale = fx["absmax"]
+    err = _compact_err(out, fx["forward_compact"])
+    print(f"c3_forward {backend}: max|d| {err:.3e} = {err / scale:.3e} of scale {scale:.2f}")
+    _record("c3_forward", "fp32" if backend == torch.float32 else "bf16", max_abs=err, scale=scale, rel=err / scale)
+    assert err <= (2e-4 if backend == torch.float32 else BF16_BOUNDS["c3_forward"]["first_forward_rel"]) * scale
+
+
+def test_bf16_bits_do_not_depend_on_the_tuner(golden_dir):
+    """Fixed-seed reproducibility of the product dtype: at a shape covered by the shipped tile table, an engine that may
+    measure tile configurations (autotune on) and one that may not (autotune off) run the SAME configurations and give
+    bit-identical outputs - and nothing is timed on the device for that shape."""
+    from kandinsky2_amd import _lib
+    fx = _load(golden_dir, "c2_text2img")
+    L = _lib.lib()
+    if L.k22_tile_table_size() == 0:
+        pytest.skip("no tile table shipped / loaded")
+    arch, sd = _state_dict(False)
+    B, lat, bs = fx["B"], fx["lat"], fx["bs"]
+    full, pooled, image = k22.make_conditioning(arch, B, seed=2)
+    g = torch.Generator().manual_seed(42)
+    x_T = torch.randn(B, 4, lat, lat, generator=g)
+    x = torch.cat([x_T[:bs], x_T[:bs]], 0).cuda()
+    kw = dict(full_emb=full.cuda(), pooled_emb=pooled.cuda(), image_emb=image.cuda())
+    outs, reports = [], []
+    measured_before = L.k22_tile_table_measured()
+    for autotune in ("1", "0"):
+        os.environ["K22_AUTOTUNE"] = autotune
+        try:
+            m = k22.Text2ImUNetHIP(arch, backend_dtype=torch.bfloat16, use_graph=True)
+            m.load_state_dict(sd)
+            m = m.to("cuda").eval()
+            outs.append(m(x, fx["first_ts"].float().cuda(), **kw).cpu())
+            reports.append(m.tuning_report())
+            del m
+        finally:
+            os.environ.pop("K22_AUTOTUNE", None)
+    assert L.k22_tile_table_measured() == measured_before, "the C2 shape must be fully covered by the shipped tile table"
+    assert reports[0] == reports[1]
+    assert torch.equal(outs[0], outs[1])

@@ -54,6 +54,37 @@ def test_movq_decode_vs_reference_golden(golden_dir, name, backend, tol):
         assert (u8.cpu().int() - fx["out_u8"].int()).abs().max().item() <= 1
 
 
+def _compact_err(out, c):
+    """max-abs distance on the stored sub-grid, row band and column band of a compact fixture (make_golden._compact)."""
+    s = c["stride"]
+    e = (out[..., ::s, ::s] - c["sub"]).abs().max().item()
+    e = max(e, (out[..., c["r0"]: c["r0"] + c["rows"].shape[-2], :] - c["rows"]).abs().max().item())
+    return max(e, (out[..., :, c["c0"]: c["c0"] + c["cols"].shape[-1]] - c["cols"]).abs().max().item())
+
+
+@pytest.mark.parametrize("name", ["movq_256px", "movq_768px"])
+@pytest.mark.parametrize("backend,tol", [(torch.float32, 2e-4), (torch.bfloat16, 6e-2)])
+def test_movq_decode_real_sizes_vs_reference_golden(golden_dir, name, backend, tol):
+    """MOVQ.decode at 32x32 latents (256 px, attention over T = 1024) and at C2's 96x96 latents (768 px, T = 9216: the
+    wide-image convolutions and the long softmax rows the small fixtures never reach).  The float output is compared on the
+    fixture's sub-grid + full-resolution row / column bands, the uint8 image everywhere."""
+    fx = _fixture(golden_dir, name)
+    arch, m = _model(backend)
+    g = torch.Generator().manual_seed(fx["seed_z"])
+    z = torch.randn(fx["B"], 4, fx["h"], fx["w"], generator=g)
+    out, u8 = m.decode(z.cuda(), return_uint8=True)
+    out, u8 = out.cpu(), u8.cpu()
+    scale = fx["absmax"]
+    err = _compact_err(out, fx["out_compact"])
+    du8 = (u8.int() - fx["out_u8"].int()).abs()
+    print(f"{name} {backend}: max|d|={err:.3e} = {err / scale:.3e} of scale {scale:.3f}; uint8: max diff {du8.max().item()}, "
+          f"{(du8 > 0).float().mean().item() * 100:.3f} % of the bytes differ")
+    assert err <= tol * scale
+    assert torch.equal(u8, movq_ref.process_images_u8(out))
+    if backend == torch.float32:
+        assert du8.max().item() <= 1
+
+
 def test_movq_decode_is_deterministic_and_batch_independent(golden_dir):
     """Images are independent chains: decoding a batch equals decoding its elements one by one."""
     arch, m = _model(torch.float32)
@@ -82,7 +113,7 @@ def _encoder(backend):
     return arch, m.to("cuda")
 
 
-@pytest.mark.parametrize("name", ["movq_enc_small", "movq_enc_wide"])
+@pytest.mark.parametrize("name", ["movq_enc_small", "movq_enc_wide", "movq_enc_256px", "movq_enc_768px"])
 @pytest.mark.parametrize("backend,tol", [(torch.float32, 2e-4), (torch.bfloat16, 6e-2)])
 def test_movq_encode_vs_reference_golden(golden_dir, name, backend, tol):
     """Encoder.forward + quant_conv: plain GroupNorm ResnetBlocks, single-head attention at the last level, Downsample as

@@ -28,34 +28,52 @@ def _inputs(bs, seed=7):
     return cm, cs, txt_feat, txt_seq, mask, x, g
 
 
-def _fixture(golden_dir):
-    p = os.path.join(golden_dir, "prior_tiny.pt")
+# prior_tiny: 512 wide x 4 layers; prior_full: the production configuration (2048 wide x 20 layers, MLP K = 8192:
+# CONFIG_2_1["prior"], kandinsky2/configs.py:101-111), which runs other tile configurations and split-K factors
+FIXTURES = ["prior_tiny", "prior_full"]
+
+
+def _fixture(golden_dir, name="prior_tiny"):
+    p = os.path.join(golden_dir, name + ".pt")
     if not os.path.exists(p):
-        pytest.skip("prior_tiny.pt not generated")
+        pytest.skip(f"{name}.pt not generated")
     return torch.load(p, weights_only=False)
+
+
+_SD = {}
+
+
+def _prior_sd(fx):
+    key = (fx["hp"]["xf_width"], fx["hp"]["xf_layers"], fx["seed_w"])
+    if key not in _SD:
+        _SD.clear()
+        _SD[key] = k22.init_prior_state_dict(fx["hp"], seed=fx["seed_w"])
+    return _SD[key]
 
 
 def _model(fx, backend, cm, cs):
     m = k22.PriorDiffusionModelHIP(fx["hp"], k22.PRIOR_DIFFUSION_2_1, cm, cs, backend_dtype=backend)
-    m.load_state_dict(k22.init_prior_state_dict(fx["hp"], seed=fx["seed_w"]))
+    m.load_state_dict(_prior_sd(fx))
     return m.to("cuda")
 
 
+@pytest.mark.parametrize("name", FIXTURES)
 @pytest.mark.parametrize("backend,tol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)])
-def test_prior_transformer_vs_reference_golden(golden_dir, backend, tol):
-    fx = _fixture(golden_dir)
+def test_prior_transformer_vs_reference_golden(golden_dir, name, backend, tol):
+    fx = _fixture(golden_dir, name)
     cm, cs, txt_feat, txt_seq, mask, x, g = _inputs(fx["bs"])
     m = _model(fx, backend, cm, cs)
     out = m.transformer(x.cuda(), fx["t"].cuda(), txt_feat.cuda(), txt_seq.cuda(), mask.cuda()).cpu()
     ref = fx["forward_out"]
     scale = ref.abs().max().item()
     err = (out - ref).abs().max().item()
-    print(f"prior transformer {backend}: max|d|={err:.3e} scale={scale:.3f}")
+    print(f"{name} transformer {backend}: max|d|={err:.3e} = {err / scale:.3e} of scale {scale:.3f}")
     assert err <= tol * scale
 
 
-def test_prior_sample_vs_reference_golden_fp32(golden_dir):
-    fx = _fixture(golden_dir)
+@pytest.mark.parametrize("name", FIXTURES)
+def test_prior_sample_vs_reference_golden_fp32(golden_dir, name):
+    fx = _fixture(golden_dir, name)
     cm, cs, txt_feat, txt_seq, mask, x, g = _inputs(fx["bs"])
     N, steps = 2 * fx["bs"], fx["steps"]
     x_T, noise_seq = torch.randn(N, 768, generator=g), torch.randn(steps, N, 768, generator=g)
@@ -65,12 +83,13 @@ def test_prior_sample_vs_reference_golden_fp32(golden_dir):
     ref = fx["sample"]
     scale = ref.abs().max().item()
     err = (out - ref).abs().max().item()
-    print(f"prior {steps}-step sample fp32: max|d|={err:.3e} scale={scale:.3f}")
+    print(f"{name} {steps}-step sample fp32: max|d|={err:.3e} scale={scale:.3f}")
     assert out.shape == ref.shape and err <= 1e-3 * scale
 
 
-def test_prior_bf16_sample_drift_is_bounded(golden_dir):
-    fx = _fixture(golden_dir)
+@pytest.mark.parametrize("name", FIXTURES)
+def test_prior_bf16_sample_drift_is_bounded(golden_dir, name):
+    fx = _fixture(golden_dir, name)
     cm, cs, txt_feat, txt_seq, mask, x, g = _inputs(fx["bs"])
     N, steps = 2 * fx["bs"], fx["steps"]
     x_T, noise_seq = torch.randn(N, 768, generator=g), torch.randn(steps, N, 768, generator=g)
@@ -79,7 +98,7 @@ def test_prior_bf16_sample_drift_is_bounded(golden_dir):
             noise=x_T.cuda(), noise_seq=noise_seq.cuda()).cpu()
     ref = fx["sample"]
     err = (out - ref).abs().max().item() / ref.abs().max().item()
-    print(f"prior bf16 {steps}-step sample drift: {err:.3e} of the sample scale")
+    print(f"{name} bf16 {steps}-step sample drift: {err:.3e} of the sample scale")
     assert torch.isfinite(out).all() and err <= 0.1
 
 

@@ -85,8 +85,8 @@ def test_p_sampler_final_latent_vs_reference_golden_fp32(golden_dir, name):
     noise_seq = torch.randn(fx["steps"], fx["B"], 4, fx["h"], fx["w"], generator=g)
     d = k22.create_gaussian_diffusion(**dict(k22.DIFFUSION_CONFIG_2_1, timestep_respacing=str(fx["steps"])))
     ii, mm = (img.cuda(), mask.cuda()) if fx["inpainting"] else (None, None)
-    final = d.p_sample_loop(m, (fx["B"], 4, fx["h"], fx["w"]), kw, fx["guidance"], noise=x_T.cuda(), noise_seq=noise_seq.cuda(),
-                            init_img=ii, img_mask=mm).cpu()
+    final = d.p_sample_loop(m, (fx["B"], 4, fx["h"], fx["w"]), model_kwargs=kw, guidance_scale=fx["guidance"], noise=x_T.cuda(),
+                            noise_seq=noise_seq.cuda(), init_img=ii, img_mask=mm).cpu()
     err = (final - fx["final"]).abs().max().item()
     print(f"{name}: fp32 engine vs reference p_sampler final latent max|d| = {err:.3e}")
     assert err <= 1e-3
@@ -99,7 +99,8 @@ def test_p_sampler_bf16_drift_reported(golden_dir):
     x_T = torch.randn(fx["B"], 4, fx["h"], fx["w"], generator=g)
     noise_seq = torch.randn(fx["steps"], fx["B"], 4, fx["h"], fx["w"], generator=g)
     d = k22.create_gaussian_diffusion(**dict(k22.DIFFUSION_CONFIG_2_1, timestep_respacing=str(fx["steps"])))
-    final = d.p_sample_loop(m, (fx["B"], 4, fx["h"], fx["w"]), kw, fx["guidance"], noise=x_T.cuda(), noise_seq=noise_seq.cuda()).cpu()
+    final = d.p_sample_loop(m, (fx["B"], 4, fx["h"], fx["w"]), model_kwargs=kw, guidance_scale=fx["guidance"], noise=x_T.cuda(),
+                            noise_seq=noise_seq.cuda()).cpu()
     err = (final - fx["final"]).abs().max().item()
     rms = (final - fx["final"]).pow(2).mean().sqrt().item()
     print(f"bf16 engine vs fp32 reference p_sampler final latent max|d| = {err:.3e}, rms {rms:.3e} (reported; latent range [-1, 1])")

@@ -1,0 +1,91 @@
+#!/usr/bin/env python
+"""Measures the conv / GEMM tile configurations of the shapes BASELINE.json's configs run (and the small shapes smoke() and
+the parity tests use) on THIS MI355X and writes the tile table the package ships (kandinsky-2_amd/tiles_gfx950.txt).
+
+    K22_TILE_TABLE=0 python tools/make_tile_table.py gpurun_out/tiles_gfx950.txt
+
+Run it after a kernel change that alters which configuration is fastest (or that changes the candidate set), copy the file
+to kandinsky-2_amd/tiles_gfx950.txt and commit it: engines then resolve those problems from the table without timing
+anything, which is what makes the bf16 bits of a fixed seed the same on every box (csrc/tuning.h).
+"""
+import os
+import sys
+import time
+
+os.environ["K22_TILE_TABLE"] = "0"          # start empty: everything below is measured here
+os.environ.setdefault("K22_TUNE_REPS", "7")
+os.environ.pop("K22_TUNE_CACHE", None)
+os.environ["K22_AUTOTUNE"] = "1"
+
+import torch  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import kandinsky2_amd as k22  # noqa: E402
+from kandinsky2_amd import _lib  # noqa: E402
+
+
+def unet(cfg, inpainting, shapes, dtypes=(torch.bfloat16, torch.float32)):
+    arch = k22.make_arch(cfg, inpainting=inpainting)
+    sd = k22.init_unet_state_dict(arch, seed=0)
+    for dt in dtypes:
+        m = k22.Text2ImUNetHIP(arch, backend_dtype=dt, use_graph=False)
+        m.load_state_dict(sd)
+        m = m.to("cuda")
+        m.prepare(free_params=True)
+        for (B, h, w) in shapes:
+            t0 = time.time()
+            full, pooled, image = k22.make_conditioning(arch, B, seed=2)
+            kw = dict(full_emb=full.cuda(), pooled_emb=pooled.cuda(), image_emb=image.cuda())
+            if inpainting:
+                kw.update(inpaint_image=torch.zeros(B, 4, h, w, device="cuda"), inpaint_mask=torch.zeros(B, 1, h, w, device="cuda"))
+            m.del_cache()
+            m(torch.randn(B, 4, h, w, device="cuda"), torch.full((B,), 500.0, device="cuda"), **kw)
+            torch.cuda.synchronize()
+            print(f"unet {'inpaint' if inpainting else 'text2img'} C={arch.model_channels} {dt} B={B} {h}x{w}: "
+                  f"{time.time() - t0:.1f} s, table = {_lib.lib().k22_tile_table_size()} entries", flush=True)
+        del m
+        torch.cuda.empty_cache()
+
+
+def prior(hp, batches, dtypes=(torch.bfloat16, torch.float32)):
+    sd = k22.init_prior_state_dict(hp, seed=0)
+    for dt in dtypes:
+        m = k22.PriorDiffusionModelHIP(hp, backend_dtype=dt)
+        m.load_state_dict(sd)
+        m = m.to("cuda")
+        for N in batches:
+            x, t = torch.randn(N, 768, device="cuda"), torch.full((N,), 500.0, device="cuda")
+            te, tq = torch.randn(N, 768, device="cuda"), torch.randn(N, 77, 768, device="cuda")
+            m.transformer(x, t, te, tq, torch.ones(N, 77, dtype=torch.bool, device="cuda"))
+            torch.cuda.synchronize()
+            print(f"prior width {hp['xf_width']} {dt} N={N}: table = {_lib.lib().k22_tile_table_size()} entries", flush=True)
+        del m
+        torch.cuda.empty_cache()
+
+
+def main():
+    out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/tiles_gfx950.txt"
+    quick = "--quick" in sys.argv
+    tiny = k22.tiny_model_config()
+    # smoke() / parity-test shapes of the 1/3-width model
+    unet(tiny, False, [(2, 16, 16), (4, 8, 24)])
+    unet(tiny, True, [(4, 16, 24)])
+    # BASELINE.json configs: C1 (256^2 bs 1), C2 (768^2 bs 1: the bench line), 512^2, C3 per-GPU (1024^2 bs 4), 768^2 bs 2 / bs 4
+    if quick:
+        unet(k22.MODEL_CONFIG_2_1, False, [(2, 96, 96)], dtypes=(torch.bfloat16,))
+    else:
+        # bf16 (product path): every configured shape; fp32 (parity path): the shapes the parity tests run
+        unet(k22.MODEL_CONFIG_2_1, False, [(2, 32, 32), (2, 96, 96), (2, 64, 64), (4, 96, 96), (8, 96, 96), (2, 128, 128), (8, 128, 128)],
+             dtypes=(torch.bfloat16,))
+        unet(k22.MODEL_CONFIG_2_1, False, [(2, 32, 32), (2, 96, 96), (8, 128, 128)], dtypes=(torch.float32,))
+        unet(k22.MODEL_CONFIG_2_1, True, [(8, 96, 96), (2, 96, 96)], dtypes=(torch.bfloat16,))   # C4 (inpainting 768^2 bs 4) and bs 1
+        unet(k22.MODEL_CONFIG_2_1, True, [(8, 96, 96)], dtypes=(torch.float32,))
+        prior(k22.tiny_prior_hparams(), [4])
+        prior(k22.PRIOR_HPARAMS_2_1, [2, 4, 8], dtypes=(torch.bfloat16,))
+        prior(k22.PRIOR_HPARAMS_2_1, [4], dtypes=(torch.float32,))
+    n = _lib.lib().k22_tile_table_save(out.encode())
+    print(f"{n} entries -> {out}")
+
+
+if __name__ == "__main__":
+    main()
