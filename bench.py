@@ -53,6 +53,10 @@ def main():
     ap.add_argument("--tuning-report", default="", help="write the chosen conv/GEMM tile configurations to this file")
     ap.add_argument("--inpaint", action="store_true", help="inpainting UNet (9 input channels, masked-latent blend in the sampler step): config C4")
     ap.add_argument("--tiny", action="store_true", help="1/3-width UNet (debug only; not a valid bench config)")
+    ap.add_argument("--head", default="2.1", choices=["2.1", "2.2"],
+                    help="conditioning head: 2.1 = Text2ImUNet (10 image + 77 text tokens; parity pinned against the reference's modules); "
+                         "2.2 = diffusers UNet2DConditionModel of the 2.2 decoder (32 image tokens, DDPM step with clip +-2; parity unpinned)")
+    ap.add_argument("--controlnet", action="store_true", help="2.2 ControlNet-depth UNet (hint conv stack, in_channels 8): config C5")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -69,8 +73,16 @@ def main():
     if a.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
-    mcfg = k22.tiny_model_config() if a.tiny else k22.MODEL_CONFIG_2_1
-    arch = k22.make_arch(mcfg, inpainting=a.inpaint)
+    v22 = a.head == "2.2" or a.controlnet
+    if v22:
+        if a.inpaint:
+            raise SystemExit("--inpaint runs on the 2.1 head")
+        arch = k22.make_arch22(k22.tiny_unet22_config() if a.tiny else k22.UNET_CONFIG_2_2, controlnet=a.controlnet)
+        Model, init_sd = k22.UNet2DConditionHIP, k22.init_unet22_state_dict
+    else:
+        mcfg = k22.tiny_model_config() if a.tiny else k22.MODEL_CONFIG_2_1
+        arch = k22.make_arch(mcfg, inpainting=a.inpaint)
+        Model, init_sd = k22.Text2ImUNetHIP, k22.init_unet_state_dict
     tdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     lat = a.size // 8
     B = 2 * a.bs
@@ -79,14 +91,14 @@ def main():
     t0 = time.time()
     sd = None
     if rank == 0:
-        sd = k22.init_unet_state_dict(arch, seed=0)
-        m = k22.Text2ImUNetHIP(arch, backend_dtype=tdt, use_graph=not a.no_graph)
+        sd = init_sd(arch, seed=0)
+        m = Model(arch, backend_dtype=tdt, use_graph=not a.no_graph)
         m.load_state_dict(sd)
         m = m.to(dev)
         m.prepare(free_params=True)
         arena = m._arena
     else:
-        m = k22.Text2ImUNetHIP(arch, backend_dtype=tdt, use_graph=not a.no_graph, meta_params=True)
+        m = Model(arch, backend_dtype=tdt, use_graph=not a.no_graph, meta_params=True)
         arena = None
     if world > 1:
         arena = broadcast_arena(arena, m.arena_bytes() if rank else arena.numel(), dev, src=0)
@@ -94,12 +106,26 @@ def main():
             m.prepare(arena=arena)
     t_load = time.time() - t0
 
-    full, pooled, image = k22.make_conditioning(arch, B, seed=2 + rank)
-    kw = dict(full_emb=full.to(dev), pooled_emb=pooled.to(dev), image_emb=image.to(dev))
-    d = k22.create_gaussian_diffusion(**dict(k22.DIFFUSION_CONFIG_2_1, timestep_respacing=str(a.sched_steps)))
-    T = d.num_timesteps
-    table = torch.from_numpy(d.step_table()).to(dev)
-    ts_rows = torch.from_numpy(d.model_timesteps()).to(dev)[:, None].expand(-1, B).contiguous()
+    if v22:
+        gc = torch.Generator().manual_seed(2 + rank)
+        emb22 = torch.randn(B, arch.image_dim, generator=gc).to(dev)
+        ack = {"image_embeds": emb22}
+        if a.controlnet:
+            hint = torch.rand(a.bs, 3, a.size, a.size, generator=gc)          # depth map in [0,1]
+            ack["hint"] = torch.cat([hint, hint], 0).to(dev)
+        kw = dict(encoder_hidden_states=None, added_cond_kwargs=ack, return_dict=False)
+        sch = k22.DDPMSchedulerHIP().set_timesteps(a.sched_steps, device=dev)
+        T = a.sched_steps
+        table = sch._table
+        ts_rows = sch.timesteps.float().flip(0)[:, None].expand(-1, B).contiguous()   # row i = loop index i (ascending t), like the 2.1 table
+        table = table.flip(0).contiguous()
+    else:
+        full, pooled, image = k22.make_conditioning(arch, B, seed=2 + rank)
+        kw = dict(full_emb=full.to(dev), pooled_emb=pooled.to(dev), image_emb=image.to(dev))
+        d = k22.create_gaussian_diffusion(**dict(k22.DIFFUSION_CONFIG_2_1, timestep_respacing=str(a.sched_steps)))
+        T = d.num_timesteps
+        table = torch.from_numpy(d.step_table()).to(dev)
+        ts_rows = torch.from_numpy(d.model_timesteps()).to(dev)[:, None].expand(-1, B).contiguous()
     L = _lib.lib()
     HW = lat * lat
     g = torch.Generator(device="cpu").manual_seed(42 + rank)
@@ -107,7 +133,7 @@ def main():
     x_next = torch.empty_like(x)
     noise = torch.randn(a.steps + a.warmup + 1, B, 4, lat, lat, generator=g).to(dev)  # resident before timing
     scratch = torch.empty(L.k22_sampler_scratch_bytes(B, HW), dtype=torch.uint8, device=dev)
-    lo, gamma = k22.percentile_index(4 * HW)
+    lo, gamma = (-1, 0.0) if v22 else k22.percentile_index(4 * HW)    # 2.2: DDPMScheduler clip_sample +-2, no dynamic threshold
     stream = torch.cuda.current_stream().cuda_stream
     init_img = img_mask = None
     if a.inpaint:
@@ -121,6 +147,8 @@ def main():
         i = T - 1 - (k % T)
         half = x[: a.bs]
         out = m(torch.cat([half, half], 0), ts_rows[i], **kw)
+        if v22:
+            out = out[0]
         _lib.check(L.k22_sampler_step(x.data_ptr(), out.data_ptr(), noise[k].data_ptr(), _lib.ptr(init_img), _lib.ptr(img_mask), table.data_ptr(), i,
                                       4.0, 1, -2.0, 2.0, lo, gamma, scratch.data_ptr(), x_next.data_ptr(), None, B, HW, stream))
         return x_next, x
@@ -129,6 +157,7 @@ def main():
     # tile table on the device and captures the hipGraph (the equivalent of building the model)
     m(torch.cat([x[: a.bs], x[: a.bs]], 0), ts_rows[T - 1], **kw)
     torch.cuda.synchronize()
+    measured_here = _lib.lib().k22_tile_table_measured()
     k = 0
     for _ in range(a.warmup):
         x, x_next = step(k, x, x_next)
@@ -175,8 +204,12 @@ def main():
             "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(el / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic (seeded random-init weights + N(0,1) conditioning/noise)",
-            "config": {"workload": f"Kandinsky-2.x {'inpainting' if a.inpaint else 'text2img'} {a.size}x{a.size}, decoder_steps={a.sched_steps}, bs={a.bs}/GPU "
-                                   f"(CFG batch {B}x4x{lat}x{lat}), 2.1-architecture UNet ({'tiny' if a.tiny else '1.23B'}) p_sampler step",
+            "config": {"workload": f"Kandinsky-2.x {'ControlNet-depth' if a.controlnet else ('inpainting' if a.inpaint else 'text2img')} {a.size}x{a.size}, "
+                                   f"decoder_steps={a.sched_steps}, bs={a.bs}/GPU (CFG batch {B}x4x{lat}x{lat}), " +
+                                   (f"2.2 decoder UNet ({'tiny' if a.tiny else '1.25B'}, diffusers UNet2DConditionModel layout, 32 image tokens"
+                                    f"{', hint stack' if a.controlnet else ''}) + DDPM learned-range step; parity UNPINNED (diffusers absent)" if v22 else
+                                    f"2.1-architecture UNet ({'tiny' if a.tiny else '1.23B'}) p_sampler step; parity pinned against the reference's modules"),
+                       "head": "2.2" if v22 else "2.1", "tile_configs_measured_in_this_process": measured_here,
                        "images_per_gpu": a.bs, "parallelism": f"prompt-sharded x{world}, weights by one RCCL broadcast",
                        "graph": not a.no_graph},
             "images_per_sec": round(world * a.bs * a.steps / el / a.sched_steps, 4),
@@ -198,19 +231,22 @@ def measure_roofline(m, a):
     tot_ms = sum(v["ms"] for v in prof.values())
     tot_fl = sum(v["flops"] for v in prof.values())
     gn = prof["groupnorm"]
-    # HBM traffic of the same kernel class from the committed rocprofv3 PMC pass (tools/gpu_pmc.sh):
-    # FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE, per launch; null when no pass is on file
-    traffic = None
+    # HBM traffic of the same kernel class: NOT measured in this run (PMC counters need their own rocprofv3 passes); the value
+    # is read from the committed summary of tools/gpu_pmc_conv.sh run on this command (FETCH_SIZE doubled per
+    # MI355X_MICROARCH.md + WRITE_SIZE, per launch) and labelled as such; null when no pass is on file for this workload
+    traffic = traffic_src = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_conv.json")
-    if a.size == 768 and a.bs == 1 and a.dtype == "bf16" and os.path.exists(pmc_path):
+    if a.size == 768 and a.bs == 1 and a.dtype == "bf16" and a.head == "2.1" and not a.controlnet and not a.inpaint and os.path.exists(pmc_path):
         with open(pmc_path) as f:
-            traffic = json.load(f).get("hbm_bytes_per_launch")
+            pj = json.load(f)
+        traffic = pj.get("hbm_bytes_per_launch")
+        traffic_src = f"profiles/pmc_conv.json ({pj.get('round', 'r01')}: rocprofv3 --pmc passes of this command on another box; not live)"
     roofline = {
         "kernel": "conv3_halo_kernel (3x3 convolutions of the ResBlocks: LDS-resident halo implicit GEMM, incl. "
                   "split-K finish; 83% of the step's FLOPs)",
         "bound": "mfma",
         "achieved": round(conv_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(conv_tf / peak, 4),
-        "traffic": traffic,
+        "traffic": traffic, "traffic_source": traffic_src,
         "launches_per_step": conv["launches"], "avg_launch_ms": round(conv["ms"] / max(1, conv["launches"]), 5),
         "flops_per_launch": conv["flops"] / max(1, conv["launches"]), "flops_per_step": conv["flops"],
         "timing": "HIP events around every engine op on the launch stream, eager replay of the step, mean of 3",
@@ -231,22 +267,43 @@ def cpu_baseline(arch, sd, a, B):
     torch.set_num_threads(cores)
     size = a.cpu_baseline_size or a.size
     lat = size // 8
-    full, pooled, image = k22.make_conditioning(arch, B, seed=2)
     g = torch.Generator().manual_seed(42)
     x = torch.randn(B, 4, lat, lat, generator=g)
     nz = torch.randn(B, 4, lat, lat, generator=g)
-    od = diffusion_ref.RefDiffusion(a.sched_steps)
-    i = od.T - 1
-    n = 3 if size >= 512 else 10   # ~10-15 s of CPU work at 768x768
+    n = 3 if size >= 512 else 10   # ~10-15 s of CPU work at 768x768 (+ one untimed warm-up step)
+    if arch.head == "2.2":
+        from oracle import unet22_ref
+        cfg22 = k22.tiny_unet22_config() if a.tiny else k22.UNET_CONFIG_2_2
+        gc = torch.Generator().manual_seed(2)
+        emb = torch.randn(B, arch.image_dim, generator=gc)
+        hint = torch.rand(B // 2, 3, size, size, generator=gc).repeat(2, 1, 1, 1) if a.controlnet else None
+        sch = unet22_ref.RefDDPMScheduler(a.sched_steps)
+        t_first = int(sch.timesteps[0])
+
+        def one_step(x):
+            half = x[: B // 2]
+            out = unet22_ref.unet22_forward(sd, cfg22, torch.cat([half, half], 0), t_first, emb, hint)
+            eps = out[B // 2:, :4] + 4.0 * (out[: B // 2, :4] - out[B // 2:, :4])
+            xh = sch.step(torch.cat([eps, out[: B // 2, 4:]], 1), t_first, half, nz[: B // 2])
+            return torch.cat([xh, xh], 0)
+    else:
+        full, pooled, image = k22.make_conditioning(arch, B, seed=2)
+        od = diffusion_ref.RefDiffusion(a.sched_steps)
+        i = od.T - 1
+
+        def one_step(x):
+            half = x[: B // 2]
+            out = unet_ref.unet_forward(sd, arch, torch.cat([half, half], 0), torch.full((B,), od.model_t(i)), full, pooled, image)
+            return od.p_sample(out, x, i, nz, 4.0)[0]
+    x = one_step(x)   # warm-up (oneDNN primitive creation, page faults of the 4.9 GB weight set)
     t0 = time.perf_counter()
     for _ in range(n):
-        half = x[: B // 2]
-        out = unet_ref.unet_forward(sd, arch, torch.cat([half, half], 0), torch.full((B,), od.model_t(i)), full, pooled, image)
-        x, _ = od.p_sample(out, x, i, nz, 4.0)
+        x = one_step(x)
     el = time.perf_counter() - t0
     return {"value": round(n / el, 4), "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} denoise steps (UNet fwd CFG batch {B}x4x{lat}x{lat} + p_sample) of the same workload, fp32, "
-                      f"{cores} threads (of {os.cpu_count()} host cores; more threads are slower), no warm-up"}
+            "sample": f"{n} denoise steps (UNet fwd CFG batch {B}x4x{lat}x{lat} + sampler step) of the same workload after 1 warm-up step, "
+                      f"CPU oracle (PyTorch fp32 restatement of the reference), {cores} threads (of {os.cpu_count()} host cores; more "
+                      f"threads are slower)"}
 
 
 if __name__ == "__main__":

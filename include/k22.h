@@ -47,7 +47,7 @@ int k22_set_option(const char* name, int value);
  */
 typedef struct K22UNetConfig {
   int dtype;               /* K22_BF16 | K22_F32 */
-  int in_channels;         /* 4, or 9 for the inpainting UNet (x, image*mask, mask) */
+  int in_channels;         /* 4; 9 for the inpainting UNet (x, image*mask, mask); 8 for the 2.2 ControlNet-depth UNet (x, hint latent) */
   int model_channels;      /* 384 */
   int out_channels;        /* 8 = eps + learned variance */
   int num_res_blocks;      /* 3 */
@@ -61,7 +61,14 @@ typedef struct K22UNetConfig {
   int n_image_embs;        /* 10 */
   int text_dim1;           /* text_encoder_in_dim1, 1024 */
   int text_dim2;           /* text_encoder_in_dim2, 768 (pooled) */
-  int image_dim;           /* image_encoder_in_dim, 768 */
+  int image_dim;           /* image_encoder_in_dim, 768 (2.2: CLIP-bigG image embedding, 1280) */
+  int head_type;           /* 0: Kandinsky 2.1 head (Text2ImUNet.get_text_emb: 10 image tokens + 77 text tokens,
+                            *    text2im_model2_1.py:57-80);
+                            * 1: Kandinsky 2.2 head (image-only: ctx = LayerNorm(Linear(image_emb)) as ctx_len tokens, additive
+                            *    time term LayerNorm(Linear(image_emb)): the UNet2DConditionModel the reference injects,
+                            *    kandinsky2_2_model.py:26-41) */
+  int hint_channels;       /* 0, or 3: ControlNet-depth variant of the 2.2 UNet (hint image through the input_hint_block conv
+                            *    stack, concatenated to the latent: in_channels 8; notebooks/kandinsky2_2_controlnet.ipynb:9235) */
 } K22UNetConfig;
 
 /* One packed parameter tensor inside the caller's weight arena (see kandinsky-2_amd/pack.py for the
@@ -87,6 +94,10 @@ int k22_unet_bind(K22UNet* u, void* workspace, size_t workspace_bytes);
  * full_emb [B,77,text_dim1], pooled_emb [B,text_dim2], image_emb [B,image_dim], all fp32 contiguous. */
 int k22_unet_set_condition(K22UNet* u, const float* full_emb, const float* pooled_emb, const float* image_emb,
                            void* stream);
+
+/* ControlNet-depth variant only (hint_channels == 3), once per generation after k22_unet_bind: hint [B,3,8H,8W] fp32 NCHW
+ * (the depth map in [0,1]) -> input_hint_block -> [B,4,H,W], kept in the workspace and concatenated to x by every forward. */
+int k22_unet_set_hint(K22UNet* u, const float* hint, void* stream);
 
 /* One UNet evaluation.  x [B,4,H,W] fp32 NCHW, timesteps [B] fp32 (already mapped/rescaled exactly as
  * _WrappedModel.__call__ does, kandinsky2/model/respace.py:128-133), inpaint_image [B,4,H,W] and

@@ -11,6 +11,11 @@ from .weights import init_unet_state_dict, make_conditioning
 from .prior import (PRIOR_HPARAMS_2_1, PRIOR_DIFFUSION_2_1, PriorDiffusionModelHIP, PriorSchedule, prior_param_shapes,
                     init_prior_state_dict, tiny_prior_hparams)
 from . import prestep
+from . import pipeline22
+from .unet22 import (UNET_CONFIG_2_2, DDPMSchedulerHIP, UNet2DConditionHIP, init_unet22_state_dict, make_arch22, param_shapes22,
+                     tiny_unet22_config)
+from .pipeline import (CONFIG_2_1, Kandinsky2_1HIP, ReferenceConditioner, SeededConditioner, get_kandinsky2, prepare_image,
+                       process_images)
 from .movq import (MOVQ_CONFIG_2_1, MoVQArch, MoVQDecoderHIP, MoVQEncoderHIP, movq_param_shapes, init_movq_state_dict,
                    movq_encoder_param_shapes, init_movq_encoder_state_dict)
 
@@ -22,4 +27,6 @@ __all__ = [
     "init_prior_state_dict", "tiny_prior_hparams",
     "MOVQ_CONFIG_2_1", "MoVQArch", "MoVQDecoderHIP", "MoVQEncoderHIP", "movq_param_shapes", "init_movq_state_dict",
     "movq_encoder_param_shapes", "init_movq_encoder_state_dict", "prestep",
+    "UNET_CONFIG_2_2", "DDPMSchedulerHIP", "UNet2DConditionHIP", "init_unet22_state_dict", "make_arch22", "param_shapes22", "tiny_unet22_config",
+    "CONFIG_2_1", "Kandinsky2_1HIP", "ReferenceConditioner", "SeededConditioner", "get_kandinsky2", "prepare_image", "process_images",
 ]

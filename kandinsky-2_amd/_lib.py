@@ -26,7 +26,7 @@ class K22UNetConfig(C.Structure):
         ("num_res_blocks", C.c_int), ("n_levels", C.c_int), ("channel_mult", C.c_int * 8),
         ("n_attention_ds", C.c_int), ("attention_ds", C.c_int * 8), ("num_head_channels", C.c_int),
         ("ctx_dim", C.c_int), ("ctx_len", C.c_int), ("n_image_embs", C.c_int), ("text_dim1", C.c_int),
-        ("text_dim2", C.c_int), ("image_dim", C.c_int),
+        ("text_dim2", C.c_int), ("image_dim", C.c_int), ("head_type", C.c_int), ("hint_channels", C.c_int),
     ]
 
 
@@ -61,6 +61,7 @@ SIGNATURES = {
     "k22_unet_plan": (_I, [_P, _I, _I, _I, C.POINTER(_Z)]),
     "k22_unet_bind": (_I, [_P, _P, _Z]),
     "k22_unet_set_condition": (_I, [_P, _P, _P, _P, _P]),
+    "k22_unet_set_hint": (_I, [_P, _P, _P]),
     "k22_unet_forward": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "k22_unet_num_ops": (_I, [_P]),
     "k22_unet_set_autotune": (_I, [_P, _I]),

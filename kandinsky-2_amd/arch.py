@@ -83,6 +83,8 @@ class UNetArch:
     text_ctx: int = 77
     inpainting: bool = False
     blocks: List[tuple] = field(default_factory=list)
+    head: str = "2.1"          # "2.1": Text2ImUNet.get_text_emb (image + text tokens); "2.2": image-only head (unet22.py)
+    hint_channels: int = 0     # 3 for the 2.2 ControlNet-depth UNet (hint conv stack, in_channels 8)
 
     @property
     def time_embed_dim(self) -> int:
@@ -165,6 +167,9 @@ def _walk(a: UNetArch) -> List[tuple]:
 def param_shapes(a: UNetArch) -> "OrderedDict[str, tuple]":
     """state_dict key -> shape, identical to the reference Text2ImUNet's (checked against
     tests/golden/ref_unet_keys_*.json)."""
+    if a.head == "2.2":   # the diffusers UNet2DConditionModel keys of the Kandinsky 2.2 decoder
+        from .unet22 import param_shapes22
+        return param_shapes22(a)
     mc, ted = a.model_channels, a.time_embed_dim
     p: "OrderedDict[str, tuple]" = OrderedDict()
 

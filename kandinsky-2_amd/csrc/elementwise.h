@@ -43,7 +43,15 @@ struct ConvInParams {
   const float* w; const float* bias;                    // [Cout][Cin][3][3], [Cout] fp32
   void* out;                                            // NHWC T [B][H][W][Cout]
   int B, H, W, Cin, Cout;
+  int img_premul;                                       // channels 4-7 = img as is (2.2: hint latent / already masked image); else img*mask
 };
+// Direct fp32 3x3 convolution, pad 1, stride 1 or 2, NCHW in / out, optional SiLU: the ControlNet-depth hint stack of the 2.2 UNet
+// (3 -> 16 -> 16 -> 32/2 -> 32 -> 96/2 -> 96 -> 256/2 -> 4 on the 8h x 8w hint image), run ONCE per generation.
+struct ConvDirectParams {
+  const float* x; const float* w; const float* bias; float* y;   // x [B][Cin][Hin][Win], w [Cout][Cin][3][3], y [B][Cout][Ho][Wo]
+  int B, Cin, Cout, Hin, Win, stride, act;
+};
+int launch_conv3x3_direct(const ConvDirectParams& p, hipStream_t s);
 struct LinearSmallParams {
   const float* x; int64_t ldx;  // [M][K] fp32
   const void* W;                // [N][K] (dtype given at launch)

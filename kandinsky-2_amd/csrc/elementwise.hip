@@ -410,7 +410,7 @@ __global__ __launch_bounds__(128) void conv_in_kernel(ConvInParams p) {
     if (yy >= 0 && yy < p.H && xs >= 0 && xs < p.W) {
       const int64_t o = (int64_t)yy * p.W + xs;
       if (c < 4) v = p.x[((int64_t)b * 4 + c) * hw + o];
-      else if (c < 8) v = p.img[((int64_t)b * 4 + (c - 4)) * hw + o] * p.mask[(int64_t)b * hw + o];
+      else if (c < 8) v = p.img[((int64_t)b * 4 + (c - 4)) * hw + o] * (p.img_premul ? 1.f : p.mask[(int64_t)b * hw + o]);
       else v = p.mask[(int64_t)b * hw + o];
     }
     patch[c][r][xx] = v;
@@ -433,6 +433,44 @@ __global__ __launch_bounds__(128) void conv_in_kernel(ConvInParams p) {
       out[((int64_t)(b * p.H + y) * p.W + x0 + px) * p.Cout + n] = from_f32<T>(acc);
     }
   }
+}
+
+// ---- direct fp32 3x3 convolution (hint stack of the 2.2 ControlNet-depth UNet; once per generation) -----------------
+// thread = one output pixel x OCB output channels; the weights of a workgroup's channel group are wave-uniform loads.
+template <int OCB>
+__global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvDirectParams p) {
+  const int Ho = (p.Hin - 1) / p.stride + 1, Wo = (p.Win - 1) / p.stride + 1;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int oc0 = blockIdx.y * OCB, b = blockIdx.z;
+  if (pix >= Ho * Wo) return;
+  const int yo = pix / Wo, xo = pix - yo * Wo;
+  const int yi = yo * p.stride - 1, xi = xo * p.stride - 1;
+  float acc[OCB];
+#pragma unroll
+  for (int o = 0; o < OCB; ++o) acc[o] = (oc0 + o < p.Cout) ? p.bias[oc0 + o] : 0.f;
+  const int64_t plane = (int64_t)p.Hin * p.Win;
+  for (int c = 0; c < p.Cin; ++c) {
+    const float* xp = p.x + ((int64_t)b * p.Cin + c) * plane;
+    float v[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int yy = yi + r, xx = xi + q;
+        v[r * 3 + q] = (yy >= 0 && yy < p.Hin && xx >= 0 && xx < p.Win) ? xp[(int64_t)yy * p.Win + xx] : 0.f;
+      }
+#pragma unroll
+    for (int o = 0; o < OCB; ++o) {
+      if (oc0 + o < p.Cout) {
+        const float* wp = p.w + ((int64_t)(oc0 + o) * p.Cin + c) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[o] += wp[k] * v[k];
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < OCB; ++o)
+    if (oc0 + o < p.Cout) p.y[(((int64_t)b * p.Cout + oc0 + o) * Ho + yo) * Wo + xo] = apply_act(acc[o], p.act);
 }
 
 // ---- sinusoidal timestep embedding with a host-supplied frequency table (nn.py:101-121) --------
@@ -654,9 +692,21 @@ int launch_conv_in(const ConvInParams& p, int dtype, hipStream_t s) {
   } else if (p.Cin == 9) {
     if (dtype == K22_BF16) hipLaunchKernelGGL((conv_in_kernel<bf16_t, 9>), grid, dim3(128), 0, s, p);
     else hipLaunchKernelGGL((conv_in_kernel<float, 9>), grid, dim3(128), 0, s, p);
+  } else if (p.Cin == 8) {
+    if (dtype == K22_BF16) hipLaunchKernelGGL((conv_in_kernel<bf16_t, 8>), grid, dim3(128), 0, s, p);
+    else hipLaunchKernelGGL((conv_in_kernel<float, 8>), grid, dim3(128), 0, s, p);
   } else {
-    return k22_set_error(K22_EINVAL, "conv_in: in_channels must be 4 or 9");
+    return k22_set_error(K22_EINVAL, "conv_in: in_channels must be 4, 8 or 9");
   }
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+int launch_conv3x3_direct(const ConvDirectParams& p, hipStream_t s) {
+  if (p.stride != 1 && p.stride != 2) return k22_set_error(K22_EINVAL, "conv3x3_direct: stride must be 1 or 2");
+  const int Ho = (p.Hin - 1) / p.stride + 1, Wo = (p.Win - 1) / p.stride + 1;
+  constexpr int OCB = 8;
+  dim3 grid((Ho * Wo + 255) / 256, (p.Cout + OCB - 1) / OCB, p.B);
+  hipLaunchKernelGGL((conv3x3_direct_kernel<OCB>), grid, dim3(256), 0, s, p);
   K22_CHECK_LAUNCH();
   return K22_OK;
 }

@@ -70,6 +70,8 @@ struct K22UNet {
   std::deque<Slot> slots;
   OpList ops;       // one UNet forward
   OpList cond_ops;  // conditioning head
+  OpList hint_ops;  // 2.2 ControlNet-depth: input_hint_block over the hint image (once per generation)
+  bool hint_set = false;
   std::deque<Tuned> tuned;  // stable addresses: op closures and Act descriptors point into it
   bool tuned_done = false;
   int autotune = 1;
@@ -88,6 +90,7 @@ struct K22UNet {
   Slot *s_full, *s_pool, *s_imgemb, *s_tmpf, *s_tmpf2, *s_fullT;
   Slot *s_part, *s_coeff, *s_P1, *s_U1, *s_P2, *s_S, *s_N, *s_QKV, *s_KALL, *s_VT, *s_ATT, *s_splitk, *s_flush;
   Slot *s_U1st, *s_gsum;
+  Slot *s_ctxf = nullptr, *s_hint = nullptr, *s_hintin = nullptr, *s_hbuf[2] = {nullptr, nullptr};
   Slot* s_h[3];
   Slot* s_hst[3];
   std::vector<Slot*> s_ctxkv;  // one per attention block
@@ -378,9 +381,9 @@ struct K22UNet {
     if (nH % (1 << n_down) || nW % (1 << n_down)) return k22_set_error(K22_EINVAL, "unet: H, W must be divisible by 2^(levels-1)");
     if (nB > 8) return k22_set_error(K22_EINVAL, "unet: batch (2*bs) must be <= 8 per engine call");
     B = nB; H = nH; W = nW;
-    slots.clear(); ops.clear(); cond_ops.clear(); s_ctxkv.clear(); gsum_bytes = 0; n_attn = 0; err.clear();
+    slots.clear(); ops.clear(); cond_ops.clear(); hint_ops.clear(); s_ctxkv.clear(); gsum_bytes = 0; n_attn = 0; err.clear();
     tuned.clear(); tuned_done = false;
-    ws = nullptr; cond_set = false;
+    ws = nullptr; cond_set = false; hint_set = false;
     if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
     const int mc = cfg.model_channels, ted = 4 * mc;
 
@@ -407,11 +410,18 @@ struct K22UNet {
     s_temb = new_slot((size_t)B * mc * 4); s_e1 = new_slot((size_t)B * ted * 4); s_emb = new_slot((size_t)B * ted * 4);
     s_film = new_slot((size_t)B * film_total * 4); s_xfproj = new_slot((size_t)B * ted * 4);
     s_ctx = new_slot((size_t)B * cfg.ctx_len * cfg.ctx_dim * esz);
-    s_full = new_slot((size_t)B * 77 * cfg.text_dim1 * 4); s_pool = new_slot((size_t)B * cfg.text_dim2 * 4);
+    const int ntext_p = cfg.ctx_len - cfg.n_image_embs;   // text tokens (0 for the 2.2 head)
+    s_full = new_slot((size_t)B * (ntext_p > 0 ? ntext_p : 1) * cfg.text_dim1 * 4); s_pool = new_slot((size_t)B * cfg.text_dim2 * 4);
     s_imgemb = new_slot((size_t)B * cfg.image_dim * 4);
     s_tmpf = new_slot((size_t)B * cfg.n_image_embs * cfg.ctx_dim * 4 + (size_t)B * ted * 4);
     s_tmpf2 = new_slot((size_t)B * ted * 4);
-    s_fullT = new_slot((size_t)B * 77 * cfg.text_dim1 * esz);
+    s_fullT = new_slot((size_t)B * (ntext_p > 0 ? ntext_p : 1) * cfg.text_dim1 * esz);
+    s_ctxf = new_slot(cfg.head_type == 1 ? (size_t)B * cfg.ctx_len * cfg.ctx_dim * 4 : 0);
+    if (cfg.hint_channels) {
+      s_hint = new_slot((size_t)B * 4 * H * W * 4);
+      s_hintin = new_slot((size_t)B * cfg.hint_channels * 64 * H * W * 4);
+      for (int i = 0; i < 2; ++i) s_hbuf[i] = new_slot((size_t)B * 16 * 64 * H * W * 4);   // widest stage: 16 ch at 8H x 8W
+    }
     s_part = new_slot(); s_coeff = new_slot(); s_P1 = new_slot(); s_U1 = new_slot(); s_P2 = new_slot(); s_S = new_slot();
     s_N = new_slot(); s_QKV = new_slot(); s_KALL = new_slot(); s_VT = new_slot(); s_ATT = new_slot();
     s_splitk = new_slot(256);
@@ -423,7 +433,8 @@ struct K22UNet {
     auto next_h = [&]() { hcur = hrot; hrot = (hrot + 1) % 3; return s_h[hcur]; };
     auto cur_hst = [&]() { return s_hst[hcur]; };
 
-    build_cond_ops();
+    if (cfg.head_type == 1) build_cond_ops_22(); else build_cond_ops();
+    if (cfg.hint_channels) build_hint_ops();
 
     // ---- time embedding + all FiLM vectors -------------------------------------------------
     {
@@ -460,10 +471,12 @@ struct K22UNet {
       ConvInParams cp = {};
       cp.w = Wf("input_blocks.0.0.weight"); cp.bias = Wf("input_blocks.0.0.bias");
       cp.B = B; cp.H = H; cp.W = W; cp.Cin = cfg.in_channels; cp.Cout = ch;
-      const int dt = dtype; const bool inpaint = cfg.in_channels == 9;
+      const int dt = dtype; const bool inpaint = cfg.in_channels == 9, hinted = cfg.in_channels == 8;
+      const int premul = (hinted || cfg.head_type == 1) ? 1 : 0;   // 2.2: channels 4-7 arrive as they are (hint latent / masked image)
       ops.push_back([=](hipStream_t st) {
         ConvInParams q = cp;
-        q.x = ptr<float>(s_xin); q.img = inpaint ? ptr<float>(s_img) : nullptr; q.mask = inpaint ? ptr<float>(s_mask) : nullptr;
+        q.x = ptr<float>(s_xin); q.img = inpaint ? ptr<float>(s_img) : (hinted ? ptr<float>(s_hint) : nullptr);
+        q.mask = inpaint ? ptr<float>(s_mask) : nullptr; q.img_premul = premul;
         q.out = ptr(d);
         return launch_conv_in(q, dt, st);
       });
@@ -544,6 +557,59 @@ struct K22UNet {
     return K22_OK;
   }
 
+  // Kandinsky 2.2 conditioning head (the UNet2DConditionModel injected at kandinsky2_2_model.py:26-41; arithmetic of diffusers'
+  // ImageProjection / ImageTimeEmbedding, restated in oracle/unet22_ref.py): image-only.
+  //   ctx[b][0:S] = LayerNorm_768( Linear(image_dim -> S*768)(image_emb[b]) viewed [S][768] )      (encoder_hid_proj)
+  //   emb        += LayerNorm_1536( Linear(image_dim -> 1536)(image_emb[b]) )                       (add_embedding)
+  void build_cond_ops_22() {
+    const int mc = cfg.model_channels, ted = 4 * mc, Bn = B, dt = dtype;
+    const int cd = cfg.ctx_dim, S = cfg.ctx_len, di = cfg.image_dim;
+    const float* w_cp = Wf("head22.ctx_proj.weight"); const float* b_cp = Wf("head22.ctx_proj.bias");
+    const float* g_cn = Wf("head22.ctx_norm.weight"); const float* b_cn = Wf("head22.ctx_norm.bias");
+    const float* w_ep = Wf("head22.emb_proj.weight"); const float* b_ep = Wf("head22.emb_proj.bias");
+    const float* g_en = Wf("head22.emb_norm.weight"); const float* b_en = Wf("head22.emb_norm.bias");
+    cond_ops.push_back([=](hipStream_t st) {
+      float* proj = ptr<float>(s_tmpf);                       // [B][S*cd]
+      float* embp = ptr<float>(s_tmpf) + (size_t)Bn * S * cd;  // [B][ted]
+      LinearSmallParams lp = {};
+      lp.x = ptr<float>(s_imgemb); lp.ldx = di; lp.W = w_cp; lp.bias = b_cp; lp.out = proj; lp.ldo = S * cd;
+      lp.M = Bn; lp.N = S * cd; lp.K = di;
+      int rc = launch_linear_smallm(lp, K22_F32, st);
+      if (rc) return rc;
+      rc = launch_layernorm_f32(proj, g_cn, b_cn, ptr<float>(s_ctxf), Bn * S, cd, 1e-5f, st);
+      if (rc) return rc;
+      rc = launch_cast_rows(ptr<float>(s_ctxf), ptr(s_ctx), Bn * S, cd, cd, cd, dt, st);
+      if (rc) return rc;
+      lp.W = w_ep; lp.bias = b_ep; lp.out = embp; lp.ldo = ted; lp.N = ted;
+      rc = launch_linear_smallm(lp, K22_F32, st);
+      if (rc) return rc;
+      return launch_layernorm_f32(embp, g_en, b_en, ptr<float>(s_xfproj), Bn, ted, 1e-5f, st);
+    });
+  }
+
+  // input_hint_block of diffusers' ImageHintTimeEmbedding (ControlNet-depth UNet of Kandinsky 2.2): eight 3x3 convolutions,
+  // SiLU between them, three of them stride 2: [B,3,8H,8W] -> [B,4,H,W].
+  void build_hint_ops() {
+    static const int chans[9] = {0, 16, 16, 32, 32, 96, 96, 256, 4};
+    static const int strides[8] = {1, 1, 2, 1, 2, 1, 2, 1};
+    int hin = 8 * H, win = 8 * W, cin = cfg.hint_channels;
+    for (int k = 0; k < 8; ++k) {
+      const float* w = Wf("hint." + std::to_string(k) + ".weight");
+      const float* b = Wf("hint." + std::to_string(k) + ".bias");
+      const int cout = chans[k + 1], stride = strides[k], Bn = B, ci = cin, hi = hin, wi = win;
+      Slot* src = k == 0 ? s_hintin : s_hbuf[(k - 1) & 1];
+      Slot* dst = k == 7 ? s_hint : s_hbuf[k & 1];
+      hint_ops.push_back([=](hipStream_t st) {
+        ConvDirectParams q = {};
+        q.x = ptr<float>(src); q.w = w; q.bias = b; q.y = ptr<float>(dst);
+        q.B = Bn; q.Cin = ci; q.Cout = cout; q.Hin = hi; q.Win = wi; q.stride = stride; q.act = k == 7 ? K22_ACT_NONE : K22_ACT_SILU;
+        return launch_conv3x3_direct(q, st);
+      });
+      cin = cout;
+      if (stride == 2) { hin = (hin - 1) / 2 + 1; win = (win - 1) / 2 + 1; }
+    }
+  }
+
   // Text2ImUNet.get_text_emb (text2im_model2_1.py:57-80), pooling_type == "from_model".
   void build_cond_ops() {
     const int mc = cfg.model_channels, ted = 4 * mc, Bn = B, dt = dtype;
@@ -612,7 +678,11 @@ int k22_unet_create(const K22UNetConfig* cfg, const K22Weight* weights, int n_we
   if (cfg->num_head_channels != 64) return k22_set_error(K22_EINVAL, "unet_create: only num_head_channels == 64");
   if (cfg->model_channels % 128) return k22_set_error(K22_EINVAL, "unet_create: model_channels % 128");
   if (cfg->n_levels < 1 || cfg->n_levels > 8) return k22_set_error(K22_EINVAL, "unet_create: n_levels");
-  if (cfg->in_channels != 4 && cfg->in_channels != 9) return k22_set_error(K22_EINVAL, "unet_create: in_channels must be 4 or 9");
+  if (cfg->in_channels != 4 && cfg->in_channels != 9 && cfg->in_channels != 8) return k22_set_error(K22_EINVAL, "unet_create: in_channels must be 4, 8 or 9");
+  if (cfg->head_type != 0 && cfg->head_type != 1) return k22_set_error(K22_EINVAL, "unet_create: head_type must be 0 (2.1) or 1 (2.2)");
+  if ((cfg->hint_channels != 0) != (cfg->in_channels == 8) || (cfg->hint_channels != 0 && cfg->hint_channels != 3))
+    return k22_set_error(K22_EINVAL, "unet_create: hint_channels = 3 goes with in_channels = 8 (latent + hint latent), else 0");
+  if (cfg->head_type == 1 && cfg->n_image_embs != cfg->ctx_len) return k22_set_error(K22_EINVAL, "unet_create: the 2.2 head has image tokens only (n_image_embs == ctx_len)");
   K22UNet* u = new K22UNet();
   u->cfg = *cfg; u->dtype = cfg->dtype; u->esz = cfg->dtype == K22_BF16 ? 2 : 4;
   {
@@ -647,7 +717,7 @@ int k22_unet_bind(K22UNet* u, void* workspace, size_t workspace_bytes) {
   if (workspace_bytes < u->ws_bytes) return k22_set_error(K22_ENOMEM, "unet_bind: workspace too small");
   if ((uintptr_t)workspace % 256) return k22_set_error(K22_EINVAL, "unet_bind: workspace must be 256-byte aligned");
   u->ws = reinterpret_cast<char*>(workspace);
-  u->cond_set = false;
+  u->cond_set = false; u->hint_set = false;
   if (u->graph_exec) { (void)hipGraphExecDestroy(u->graph_exec); u->graph_exec = nullptr; }
   return K22_OK;
 }
@@ -657,15 +727,31 @@ int k22_unet_set_condition(K22UNet* u, const float* full_emb, const float* poole
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const K22UNetConfig& c = u->cfg;
   const int ntext = c.ctx_len - c.n_image_embs;
+  if (!image_emb) return k22_set_error(K22_EINVAL, "unet_set_condition: image_emb is required");
+  if (c.head_type == 0 && (!full_emb || !pooled_emb)) return k22_set_error(K22_EINVAL, "unet_set_condition: the 2.1 head needs full_emb and pooled_emb");
   hipError_t e;
-  e = hipMemcpyAsync(u->ptr(u->s_full), full_emb, (size_t)u->B * ntext * c.text_dim1 * 4, hipMemcpyDeviceToDevice, st);
-  if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-  e = hipMemcpyAsync(u->ptr(u->s_pool), pooled_emb, (size_t)u->B * c.text_dim2 * 4, hipMemcpyDeviceToDevice, st);
-  if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+  if (c.head_type == 0) {
+    e = hipMemcpyAsync(u->ptr(u->s_full), full_emb, (size_t)u->B * ntext * c.text_dim1 * 4, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+    e = hipMemcpyAsync(u->ptr(u->s_pool), pooled_emb, (size_t)u->B * c.text_dim2 * 4, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+  }
   e = hipMemcpyAsync(u->ptr(u->s_imgemb), image_emb, (size_t)u->B * c.image_dim * 4, hipMemcpyDeviceToDevice, st);
   if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
   for (auto& op : u->cond_ops) { int rc = op(st); if (rc) return rc; }
   u->cond_set = true;
+  return K22_OK;
+}
+
+int k22_unet_set_hint(K22UNet* u, const float* hint, void* stream) {
+  if (!u || !u->ws) return k22_set_error(K22_EINVAL, "unet_set_hint: bind a workspace first");
+  if (!u->cfg.hint_channels) return k22_set_error(K22_EINVAL, "unet_set_hint: this UNet has no hint input (hint_channels == 0)");
+  if (!hint) return k22_set_error(K22_EINVAL, "unet_set_hint: null hint");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipError_t e = hipMemcpyAsync(u->ptr(u->s_hintin), hint, (size_t)u->B * u->cfg.hint_channels * 64 * u->H * u->W * 4, hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+  for (auto& op : u->hint_ops) { int rc = op(st); if (rc) return rc; }
+  u->hint_set = true;
   return K22_OK;
 }
 
@@ -674,6 +760,7 @@ int k22_unet_forward(K22UNet* u, const float* x, const float* timesteps, const f
   if (!u || !u->ws) return k22_set_error(K22_EINVAL, "unet_forward: bind a workspace first");
   if (!u->cond_set) return k22_set_error(K22_EINVAL, "unet_forward: call k22_unet_set_condition first");
   if (u->cfg.in_channels == 9 && (!inpaint_image || !inpaint_mask)) return k22_set_error(K22_EINVAL, "unet_forward: inpainting UNet needs inpaint_image and inpaint_mask");
+  if (u->cfg.hint_channels && !u->hint_set) return k22_set_error(K22_EINVAL, "unet_forward: call k22_unet_set_hint first");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const size_t hw = (size_t)u->H * u->W;
   hipError_t e;

@@ -35,6 +35,11 @@ def _pad_rows(w: torch.Tensor, mult: int = 64) -> torch.Tensor:
 def packed_entries(arch: UNetArch, sd: Dict[str, torch.Tensor], tdtype: torch.dtype, device) -> "OrderedDict[str, torch.Tensor]":
     f32 = torch.float32
     out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    head22 = arch.head == "2.2"
+    if head22:
+        # Kandinsky 2.2 UNet (diffusers keys): same blocks, another conditioning head; to_q / to_k / to_v are already planes
+        from .unet22 import sd22_to_internal
+        sd = sd22_to_internal(arch, sd)
 
     def get(name):
         return sd[name].detach().to(device=device, dtype=f32)
@@ -49,13 +54,16 @@ def packed_entries(arch: UNetArch, sd: Dict[str, torch.Tensor], tdtype: torch.dt
 
     half = arch.model_channels // 2
     out["time_freqs"] = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=f32) / half).to(device)
-    for n in ("time_embed.0", "time_embed.2", "clip_to_seq", "proj_n", "img_layer"):
+    head = (["head22.ctx_proj", "head22.ctx_norm", "head22.emb_proj", "head22.emb_norm"] + [f"hint.{k}" for k in range(8 if arch.hint_channels else 0)]
+            if head22 else ["clip_to_seq", "proj_n", "img_layer"])
+    for n in ["time_embed.0", "time_embed.2"] + head:
         out[n + ".weight"] = get(n + ".weight").contiguous()
         out[n + ".bias"] = get(n + ".bias").contiguous()
-    out["ln_model_n.weight"] = get("ln_model_n.weight")
-    out["ln_model_n.bias"] = get("ln_model_n.bias")
-    out["to_model_dim_n.weight"] = mat("to_model_dim_n.weight")
-    out["to_model_dim_n.bias"] = get("to_model_dim_n.bias")
+    if not head22:
+        out["ln_model_n.weight"] = get("ln_model_n.weight")
+        out["ln_model_n.bias"] = get("ln_model_n.bias")
+        out["to_model_dim_n.weight"] = mat("to_model_dim_n.weight")
+        out["to_model_dim_n.bias"] = get("to_model_dim_n.bias")
 
     emb_w, emb_b = [], []
     for b in arch.blocks:
@@ -81,12 +89,18 @@ def packed_entries(arch: UNetArch, sd: Dict[str, torch.Tensor], tdtype: torch.dt
             h = c // arch.num_head_channels
             out[pfx + ".norm.weight"] = get(pfx + ".norm.weight")
             out[pfx + ".norm.bias"] = get(pfx + ".norm.bias")
-            wq = get(pfx + ".qkv.weight").reshape(h, 3, 64, c).permute(1, 0, 2, 3).reshape(3 * c, c)
+            if head22:   # [to_q | to_k | to_v] and [add_k_proj | add_v_proj]: head hh is rows hh*64 .. of each plane already
+                wq, bq = get(pfx + ".qkv.weight"), get(pfx + ".qkv.bias")
+                wk, bk = get(pfx + ".encoder_kv.weight"), get(pfx + ".encoder_kv.bias")
+            else:
+                wq = get(pfx + ".qkv.weight").reshape(h, 3, 64, c).permute(1, 0, 2, 3).reshape(3 * c, c)
+                bq = get(pfx + ".qkv.bias").reshape(h, 3, 64).permute(1, 0, 2).reshape(-1)
+                wk = get(pfx + ".encoder_kv.weight").reshape(h, 2, 64, arch.model_dim).permute(1, 0, 2, 3).reshape(2 * c, -1)
+                bk = get(pfx + ".encoder_kv.bias").reshape(h, 2, 64).permute(1, 0, 2).reshape(-1)
             out[pfx + ".qkv.weight"] = _pad_rows(wq).to(tdtype).contiguous()
-            out[pfx + ".qkv.bias"] = get(pfx + ".qkv.bias").reshape(h, 3, 64).permute(1, 0, 2).reshape(-1).contiguous()
-            wk = get(pfx + ".encoder_kv.weight").reshape(h, 2, 64, arch.model_dim).permute(1, 0, 2, 3).reshape(2 * c, -1)
+            out[pfx + ".qkv.bias"] = bq.contiguous()
             out[pfx + ".encoder_kv.weight"] = _pad_rows(wk).to(tdtype).contiguous()
-            out[pfx + ".encoder_kv.bias"] = get(pfx + ".encoder_kv.bias").reshape(h, 2, 64).permute(1, 0, 2).reshape(-1).contiguous()
+            out[pfx + ".encoder_kv.bias"] = bk.contiguous()
             out[pfx + ".proj_out.weight"] = mat(pfx + ".proj_out.weight")
             out[pfx + ".proj_out.bias"] = get(pfx + ".proj_out.bias")
     out["emb_layers.weight"] = torch.cat(emb_w, 0).to(tdtype).contiguous()

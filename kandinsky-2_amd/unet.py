@@ -142,6 +142,8 @@ class Text2ImUNetHIP(nn.Module):
         cfg.text_dim1 = a.text_dim1
         cfg.text_dim2 = a.text_dim2
         cfg.image_dim = a.image_dim
+        cfg.head_type = 1 if a.head == "2.2" else 0
+        cfg.hint_channels = a.hint_channels
         base = arena.data_ptr()
         arr = (_lib.K22Weight * len(table))()
         names = []

@@ -1,0 +1,186 @@
+"""TEST INFRASTRUCTURE ONLY - CPU restatement (PyTorch fp32) of the Kandinsky 2.2 decoder path that the reference delegates to
+`diffusers` (kandinsky2/kandinsky2_2_model.py:8-12 imports, :24-42 construction, :69-80 calls):
+
+    UNet2DConditionModel.forward        (kandinsky-2-2-decoder / -controlnet-depth / -decoder-inpaint `unet`)
+    KandinskyV22[Controlnet]Pipeline    denoising loop with classifier-free guidance
+    DDPMScheduler.step                  variance_type = "learned_range", prediction_type = "epsilon", clip_sample +-2
+
+PARITY UNPINNED.  `diffusers` is a third-party dependency of the reference that is neither vendored under /root/reference, nor
+pinned (setup.py:27 lists it without a version; the notebooks install huggingface/diffusers at commit
+e3d71ad89abfee3817340b2245a49eec894a1705, notebooks/kandinsky2_2_controlnet.ipynb:8258), nor installed in this image, and no
+checkpoint config can be fetched.  This file restates the published algorithm of that commit FROM MEMORY of its source
+(models/unet_2d_condition.py, models/unet_2d_blocks.py, models/resnet.py, models/attention_processor.py: AttnAddedKVProcessor,
+models/embeddings.py: Timesteps / TimestepEmbedding / ImageProjection / ImageTimeEmbedding / ImageHintTimeEmbedding,
+schedulers/scheduling_ddpm.py, pipelines/kandinsky2_2/pipeline_kandinsky2_2.py).  It has not been checked against a diffusers
+run; the structural anchors available offline are (a) the 2.1 UNet in the reference tree, of which this is block for block the
+same network, (b) the parameter count of the architecture described here, 1.253 B, the size of the published
+2.2 decoder UNet.  Re-pin against real diffusers outputs (and the checkpoint's unet/config.json, scheduler_config.json) as soon as
+they are reachable; until then every test that uses this oracle reports "parity unpinned".
+
+Deliberately written on the DIFFUSERS state_dict keys with its own walk over the blocks (not through the 2.1 oracle and not
+through kandinsky2_amd's key mapping), so that it checks the engine's name mapping and head independently.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _gn(sd, name, x, eps=1e-5):
+    return F.group_norm(x.float(), 32, sd[name + ".weight"], sd[name + ".bias"], eps)
+
+
+def _lin(sd, name, x):
+    return F.linear(x, sd[name + ".weight"], sd[name + ".bias"])
+
+
+def _conv(sd, name, x, stride=1):
+    return F.conv2d(x, sd[name + ".weight"], sd[name + ".bias"], stride=stride, padding=1)
+
+
+def timesteps_embedding(t, dim):
+    """Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): cat([cos, sin]) of t * exp(-ln(10000) * i / half)."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+    args = t.float()[:, None] * freqs[None]
+    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+
+
+def resnet(sd, p, x, temb, up=False, down=False):
+    """ResnetBlock2D, time_embedding_norm="scale_shift", up / down = nearest x2 / avg_pool2d(2) applied to BOTH branches."""
+    h = F.silu(_gn(sd, p + ".norm1", x))
+    if up:
+        x, h = F.interpolate(x, scale_factor=2.0, mode="nearest"), F.interpolate(h, scale_factor=2.0, mode="nearest")
+    elif down:
+        x, h = F.avg_pool2d(x, 2), F.avg_pool2d(h, 2)
+    h = _conv(sd, p + ".conv1", h)
+    scale, shift = torch.chunk(_lin(sd, p + ".time_emb_proj", F.silu(temb))[:, :, None, None], 2, dim=1)
+    h = _gn(sd, p + ".norm2", h) * (1 + scale) + shift
+    h = _conv(sd, p + ".conv2", F.silu(h))
+    if (p + ".conv_shortcut.weight") in sd:
+        x = F.conv2d(x, sd[p + ".conv_shortcut.weight"], sd[p + ".conv_shortcut.bias"])
+    return x + h
+
+
+def attention(sd, p, x, ctx, head_dim=64):
+    """Attention with AttnAddedKVProcessor: GroupNorm, q/k/v of the tokens, add_k/add_v of the context PREPENDED to k/v,
+    softmax(q k^T / sqrt(head_dim)) v, to_out, residual."""
+    B, C, H, W = x.shape
+    res = x
+    hs = _gn(sd, p + ".group_norm", x.view(B, C, H * W)).transpose(1, 2)            # [B, T, C]
+    heads = C // head_dim
+
+    def split(t):   # head_to_batch_dim
+        return t.reshape(B, -1, heads, head_dim).permute(0, 2, 1, 3)
+
+    q = split(_lin(sd, p + ".to_q", hs))
+    k = split(torch.cat([_lin(sd, p + ".add_k_proj", ctx), _lin(sd, p + ".to_k", hs)], dim=1))
+    v = split(torch.cat([_lin(sd, p + ".add_v_proj", ctx), _lin(sd, p + ".to_v", hs)], dim=1))
+    probs = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) * head_dim ** -0.5, dim=-1)
+    o = torch.matmul(probs, v).permute(0, 2, 1, 3).reshape(B, H * W, C)
+    o = _lin(sd, p + ".to_out.0", o)
+    return o.transpose(-1, -2).reshape(B, C, H, W) + res
+
+
+def hint_block(sd, hint):
+    """ImageHintTimeEmbedding.input_hint_block: Conv(3,16) SiLU Conv(16,16) SiLU Conv(16,32,s2) SiLU Conv(32,32) SiLU
+    Conv(32,96,s2) SiLU Conv(96,96) SiLU Conv(96,256,s2) SiLU Conv(256,4)."""
+    strides = (1, 1, 2, 1, 2, 1, 2, 1)
+    h = hint
+    for k, s in enumerate(strides):
+        h = _conv(sd, f"add_embedding.input_hint_block.{2 * k}", h, stride=s)
+        if k != 7:
+            h = F.silu(h)
+    return h
+
+
+@torch.no_grad()
+def unet22_forward(sd, cfg, sample, timestep, image_embeds, hint=None):
+    """UNet2DConditionModel.forward(sample, timestep, encoder_hidden_states=None, added_cond_kwargs={"image_embeds", ["hint"]}).
+    cfg: the dict of kandinsky2_amd.unet22.UNET_CONFIG_2_2 (block_out_channels, layers_per_block, down_block_types ...)."""
+    boc, n = tuple(cfg["block_out_channels"]), cfg["layers_per_block"]
+    B = sample.shape[0]
+    t = torch.as_tensor(timestep).float().reshape(-1).expand(B)
+    emb = _lin(sd, "time_embedding.linear_2", F.silu(_lin(sd, "time_embedding.linear_1", timesteps_embedding(t, boc[0]))))
+    # add_embedding: ImageTimeEmbedding / ImageHintTimeEmbedding
+    aug = F.layer_norm(_lin(sd, "add_embedding.image_proj", image_embeds.float()), (emb.shape[1],),
+                       sd["add_embedding.image_norm.weight"], sd["add_embedding.image_norm.bias"], 1e-5)
+    emb = emb + aug
+    if hint is not None:
+        sample = torch.cat([sample, hint_block(sd, hint.float())], dim=1)
+    # encoder_hid_proj: ImageProjection
+    cd = cfg["cross_attention_dim"]
+    ctx = _lin(sd, "encoder_hid_proj.image_embeds", image_embeds.float()).reshape(B, -1, cd)
+    ctx = F.layer_norm(ctx, (cd,), sd["encoder_hid_proj.norm.weight"], sd["encoder_hid_proj.norm.bias"], 1e-5)
+
+    h = _conv(sd, "conv_in", sample.float())
+    skips = [h]
+    types = cfg["down_block_types"]
+    for lvl in range(len(boc)):
+        for i in range(n):
+            h = resnet(sd, f"down_blocks.{lvl}.resnets.{i}", h, emb)
+            if "CrossAttn" in types[lvl]:
+                h = attention(sd, f"down_blocks.{lvl}.attentions.{i}", h, ctx, cfg["attention_head_dim"])
+            skips.append(h)
+        if lvl != len(boc) - 1:
+            h = resnet(sd, f"down_blocks.{lvl}.downsamplers.0", h, emb, down=True)
+            skips.append(h)
+    h = resnet(sd, "mid_block.resnets.0", h, emb)
+    h = attention(sd, "mid_block.attentions.0", h, ctx, cfg["attention_head_dim"])
+    h = resnet(sd, "mid_block.resnets.1", h, emb)
+    utypes = cfg["up_block_types"]
+    for u in range(len(boc)):
+        for i in range(n + 1):
+            h = resnet(sd, f"up_blocks.{u}.resnets.{i}", torch.cat([h, skips.pop()], dim=1), emb)
+            if "CrossAttn" in utypes[u]:
+                h = attention(sd, f"up_blocks.{u}.attentions.{i}", h, ctx, cfg["attention_head_dim"])
+        if u != len(boc) - 1:
+            h = resnet(sd, f"up_blocks.{u}.upsamplers.0", h, emb, up=True)
+    h = F.silu(_gn(sd, "conv_norm_out", h))
+    return _conv(sd, "conv_out", h)
+
+
+class RefDDPMScheduler:
+    """DDPMScheduler(beta_schedule="linear", beta_start=0.00085, beta_end=0.012, variance_type="learned_range",
+    prediction_type="epsilon", clip_sample=True, clip_sample_range=2.0, thresholding=False, timestep_spacing="leading")."""
+
+    def __init__(self, num_inference_steps, num_train=1000, beta_start=0.00085, beta_end=0.012, clip=2.0):
+        self.betas = torch.linspace(beta_start, beta_end, num_train, dtype=torch.float32)
+        self.alphas_cumprod = torch.cumprod(1.0 - self.betas, dim=0)
+        self.ratio = num_train // num_inference_steps
+        self.timesteps = (torch.arange(0, num_inference_steps) * self.ratio).flip(0)
+        self.clip = clip
+
+    def step(self, model_output, t, sample, noise):
+        t = int(t)
+        prev_t = t - self.ratio
+        eps, pv = model_output[:, :4], model_output[:, 4:]
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else torch.tensor(1.0)
+        b_t, b_prev = 1 - a_t, 1 - a_prev
+        cur_alpha = a_t / a_prev
+        cur_beta = 1 - cur_alpha
+        x0 = ((sample - b_t ** 0.5 * eps) / a_t ** 0.5).clamp(-self.clip, self.clip)
+        mean = (a_prev ** 0.5 * cur_beta) / b_t * x0 + cur_alpha ** 0.5 * b_prev / b_t * sample
+        if t > 0:
+            var = torch.clamp(b_prev / b_t * cur_beta, min=1e-20)
+            frac = (pv + 1) / 2
+            logvar = frac * torch.log(cur_beta) + (1 - frac) * torch.log(var)
+            mean = mean + torch.exp(0.5 * logvar) * noise
+        return mean
+
+
+@torch.no_grad()
+def decoder_loop(unet_fn, latents, image_embeds, negative_image_embeds, num_steps, guidance_scale, noise_seq, hint=None):
+    """KandinskyV22Pipeline.__call__ denoising loop: batch [uncond | cond], variance of the conditional half."""
+    sch = RefDDPMScheduler(num_steps)
+    emb = torch.cat([negative_image_embeds, image_embeds], 0)
+    hint2 = None if hint is None else torch.cat([hint, hint], 0)
+    for k, t in enumerate(sch.timesteps):
+        out = unet_fn(torch.cat([latents] * 2), t, emb, hint2)
+        eps, var = out.split(latents.shape[1], dim=1)
+        eps_u, eps_c = eps.chunk(2)
+        _, var_c = var.chunk(2)
+        eps = eps_u + guidance_scale * (eps_c - eps_u)
+        latents = sch.step(torch.cat([eps, var_c], dim=1), t, latents, noise_seq[k])
+    return latents

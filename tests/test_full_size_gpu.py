@@ -31,8 +31,8 @@ pytestmark = pytest.mark.gpu
 #   traj: (max-abs, rms) over every stored latent of the 50-step loop  (C2 measured 2.8e-2 at step 25, 3.6e-3 rms at step 50)
 BF16_BOUNDS = {
     "c2_text2img": {"first_forward_rel": 1.5e-2, "traj": (0.06, 0.0075)},
-    "c4_inpaint": {"first_forward_rel": 1.5e-2, "traj": (0.06, 0.0075)},
-    "c3_forward": {"first_forward_rel": 1.5e-2},
+    "c4_inpaint": {"first_forward_rel": 1.7e-2, "traj": (0.04, 0.003)},        # measured 8.1e-3; 1.85e-2 at step 25, 1.3e-3 rms
+    "c3_forward": {"first_forward_rel": 1.5e-2},                                 # measured 7.4e-3
 }
 
 _SD = {}

@@ -346,3 +346,57 @@ def test_ddim_schedule_matches_oracle():
     assert s.table[0, 1] == np.float32(ac[0]) and (s.table[:, 2] == 0).all()
     s.make_schedule(50, init_step=500)
     assert s.ddim_timesteps.max() <= 500
+
+
+def test_unet22_key_mapping_covers_every_diffusers_key_once():
+    """Kandinsky 2.2 UNet (diffusers keys): the mapping onto the engine's packed layout uses every key exactly once, for the plain,
+    the ControlNet-depth and the inpainting variant; the architecture has the published size (1.25 B parameters)."""
+    from kandinsky2_amd.unet22 import sd22_to_internal, names22
+    from kandinsky2_amd.pack import pack_arena
+    for kw in (dict(), dict(controlnet=True), dict(inpainting=True)):
+        arch = k22.make_arch22(k22.tiny_unet22_config(), **kw)
+        shapes = k22.param_shapes22(arch)
+        sd = {k: torch.empty(v, device="meta") for k, v in shapes.items()}
+        used = set()
+
+        class Spy(dict):
+            def __getitem__(self, k):
+                used.add(k)
+                return dict.__getitem__(self, k)
+
+        internal = sd22_to_internal(arch, Spy(sd))
+        assert used == set(shapes.keys()), sorted(set(shapes.keys()) - used)[:5]
+        arena, table = pack_arena(arch, sd, torch.bfloat16, "meta")
+        assert "head22.ctx_proj.weight" in table and ("hint.7.weight" in table) == bool(arch.hint_channels)
+        assert len(set(names22(arch).values())) == len(names22(arch))
+    full = k22.make_arch22()
+    n = sum(int(np.prod(v)) for v in k22.param_shapes22(full).values())
+    assert 1.24e9 < n < 1.27e9
+    assert k22.param_shapes22(k22.make_arch22(controlnet=True))["conv_in.weight"] == (384, 8, 3, 3)
+    assert k22.param_shapes22(k22.make_arch22(inpainting=True))["conv_in.weight"] == (384, 9, 3, 3)
+
+
+def test_unet22_oracle_runs_and_scheduler_tables_agree():
+    """oracle/unet22_ref.py (parity unpinned) executes on the tiny configuration; DDPMSchedulerHIP's step table equals the
+    oracle scheduler's per-step scalars; with 'leading' spacing the table is improved-DDPM respacing over the same timesteps."""
+    from oracle import unet22_ref
+    cfg = k22.tiny_unet22_config()
+    arch = k22.make_arch22(cfg, controlnet=True)
+    sd = k22.init_unet22_state_dict(arch, seed=0)
+    g = torch.Generator().manual_seed(1)
+    x, emb, hint = torch.randn(2, 4, 8, 8, generator=g), torch.randn(2, 1280, generator=g), torch.rand(2, 3, 64, 64, generator=g)
+    out = unet22_ref.unet22_forward(sd, cfg, x, torch.tensor([980, 0]), emb, hint)
+    assert out.shape == (2, 8, 8, 8) and torch.isfinite(out).all() and out.abs().max() > 1e-3
+    sch = k22.DDPMSchedulerHIP().set_timesteps(50, device="cpu")
+    ref = unet22_ref.RefDDPMScheduler(50)
+    assert sch.timesteps.tolist() == ref.timesteps.tolist()
+    tab = sch._table_host
+    ac = ref.alphas_cumprod.double().numpy()
+    for row, t in enumerate(sch.timesteps.tolist()):
+        prev = t - 20
+        a_prev = ac[prev] if prev >= 0 else 1.0
+        assert abs(tab[row, 0] - (1 / ac[t]) ** 0.5) < 1e-5 * tab[row, 0]
+        assert abs(tab[row, 5] - np.log(1 - ac[t] / a_prev)) < 1e-4
+    # respacing identity: betas' = 1 - abar_t / abar_prev over the retained timesteps
+    d = k22.create_gaussian_diffusion(**dict(k22.DIFFUSION_CONFIG_2_1, timestep_respacing="50"))
+    assert d.num_timesteps == 50

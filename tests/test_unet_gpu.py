@@ -2,8 +2,9 @@
 golden fixtures produced by the REFERENCE's own modules and (b) the CPU oracle on the same seeded inputs.
 
 Tolerances (stated per the north star): fp32 engine (exact-fp32 MFMA) must reproduce the reference's
-p_sampler final latent within 1e-3 max-abs; the bf16 engine is checked per forward at 4e-2 of the output
-scale and its end-to-end drift is reported (bf16 rounding of activations, not an algorithmic difference).
+p_sampler final latent within 1e-3 max-abs; the bf16 engine is bounded at 2x what was measured on MI355X with
+the shipped tile table: 2e-2 of the output scale per forward (measured 7.6e-3 .. 9.3e-3) and, for the 6-step tiny
+loop, 0.08 max-abs / 0.014 rms on the final latent (measured 4.0e-2 / 7.0e-3; profiles/r02_parity.json).
 """
 import os
 
@@ -54,7 +55,7 @@ def _setup(fx, backend_dtype, use_graph=False):
 
 
 @pytest.mark.parametrize("name", ["tiny_text2img", "tiny_inpaint", "full_c1_text2img"])
-@pytest.mark.parametrize("backend,tol", [(torch.float32, 2e-4), (torch.bfloat16, 4e-2)])
+@pytest.mark.parametrize("backend,tol", [(torch.float32, 2e-4), (torch.bfloat16, 2e-2)])
 def test_unet_forward_vs_reference_golden(golden_dir, name, backend, tol):
     fx = _load(golden_dir, name)
     arch, sd, m, x, img, mask, kw = _setup(fx, backend)
@@ -92,7 +93,7 @@ def test_p_sampler_final_latent_vs_reference_golden_fp32(golden_dir, name):
     assert err <= 1e-3
 
 
-def test_p_sampler_bf16_drift_reported(golden_dir):
+def test_p_sampler_bf16_drift_bounded(golden_dir):
     fx = _load(golden_dir, "tiny_text2img")
     arch, sd, m, _x, img, mask, kw = _setup(fx, torch.bfloat16, use_graph=True)
     g = torch.Generator().manual_seed(42)
@@ -104,8 +105,9 @@ def test_p_sampler_bf16_drift_reported(golden_dir):
     err = (final - fx["final"]).abs().max().item()
     rms = (final - fx["final"]).pow(2).mean().sqrt().item()
     print(f"bf16 engine vs fp32 reference p_sampler final latent max|d| = {err:.3e}, rms {rms:.3e} (reported; latent range [-1, 1])")
-    # the drift moves with the tile table the tuner picked (0.09-0.19 max-abs observed): the bound separates rounding from wrong
-    assert torch.isfinite(final).all() and err <= 0.6 and rms <= 0.12
+    # bounds = 2x the values measured with the shipped tile table (the table fixes the summation orders, so the number is
+    # the same on every box)
+    assert torch.isfinite(final).all() and err <= 0.08 and rms <= 0.014
 
 
 def test_forward_matches_oracle_on_fresh_seed():
