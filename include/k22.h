@@ -115,6 +115,12 @@ int k22_unet_num_ops(const K22UNet* u);
 int k22_unet_set_autotune(K22UNet* u, int on);
 int k22_unet_tuning_report(const K22UNet* u, char* buf, size_t cap);
 
+/* Multi-GPU: one process per GPU, prompts sharded by rank, the packed weight arena of rank `root` broadcast ONCE
+ * at start-up over the caller's RCCL communicator (ncclComm_t passed as void*), in <= 1 GiB pieces on `stream`; no collective
+ * in the step loop.  Replaces nothing in the reference (it has no inference parallelism); mirrors what
+ * kandinsky2_amd.parallel.broadcast_arena does through torch.distributed for hosts that own their communicator. */
+int k22_comm_broadcast_weights(void* arena, size_t bytes, int root, void* nccl_comm, void* stream);
+
 /* Tile table: the process-wide map  conv / GEMM problem -> tile configuration  that every engine consults BEFORE it
  * measures anything (csrc/tuning.h).  The package ships kandinsky-2_amd/tiles_gfx950.txt (measured on an MI355X for the
  * shapes of BASELINE.json's configs); the Python binding loads it when the library is opened, so those shapes get the

@@ -51,6 +51,7 @@ SIGNATURES = {
     "k22_version": (_I, []),
     "k22_last_error": (C.c_char_p, []),
     "k22_set_option": (_I, [C.c_char_p, _I]),
+    "k22_comm_broadcast_weights": (_I, [_P, _Z, _I, _P, _P]),
     "k22_tile_table_load": (_I, [C.c_char_p]),
     "k22_tile_table_save": (_I, [C.c_char_p]),
     "k22_tile_table_size": (_I, []),

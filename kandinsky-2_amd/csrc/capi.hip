@@ -3,6 +3,7 @@
 #include "elementwise.h"
 #include "../../include/k22.h"
 #include "tuning.h"
+#include <dlfcn.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -29,6 +30,36 @@ int k22_set_option(const char* name, int value) {
   return k22_set_error(K22_EINVAL, "k22_set_option: unknown option");
 }
 const char* k22_last_error(void) { return g_err; }
+
+// ---- multi-GPU: the ONE collective of a job -------------------------------------------------------------
+// Broadcast of the packed weight arena from `root` over an RCCL communicator the caller owns (one process per GPU; prompts are
+// sharded by rank and nothing is exchanged in the step loop).  ncclBroadcast is resolved at call time from the RCCL that is
+// already in the process (the one the communicator was created with - PyTorch's, or the host program's), else from
+// librccl.so.1: libk22hip.so itself carries no link-time dependency on a second RCCL copy.  Sent in <= 1 GiB pieces: xGMI rings
+// are per-link bound, large messages amortise the latency and keep any one call below RCCL's int-count limits.
+int k22_comm_broadcast_weights(void* arena, size_t bytes, int root, void* nccl_comm, void* stream) {
+  if (!arena || !nccl_comm) return k22_set_error(K22_EINVAL, "k22_comm_broadcast_weights: null arena / communicator");
+  typedef int (*bcast_fn)(const void*, void*, size_t, int /*ncclDataType_t*/, int, void*, hipStream_t);
+  static bcast_fn fn = nullptr;
+  if (!fn) {
+    void* sym = dlsym(RTLD_DEFAULT, "ncclBroadcast");
+    if (!sym) {
+      void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+      if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+      if (h) sym = dlsym(h, "ncclBroadcast");
+    }
+    if (!sym) return k22_set_error(K22_EINVAL, "k22_comm_broadcast_weights: RCCL (ncclBroadcast) is not loadable in this process");
+    fn = reinterpret_cast<bcast_fn>(sym);
+  }
+  const size_t piece = (size_t)1 << 30;
+  char* base = reinterpret_cast<char*>(arena);
+  for (size_t off = 0; off < bytes; off += piece) {
+    const size_t n = bytes - off < piece ? bytes - off : piece;
+    const int rc = fn(base + off, base + off, n, /*ncclUint8*/ 1, root, nccl_comm, reinterpret_cast<hipStream_t>(stream));
+    if (rc != 0) { char msg[96]; snprintf(msg, sizeof msg, "k22_comm_broadcast_weights: ncclBroadcast returned %d", rc); return k22_set_error(K22_EHIP, msg); }
+  }
+  return K22_OK;
+}
 
 // ---- tile table (tuning.h) ---------------------------------------------------------------------------------------
 int k22_tile_table_load(const char* path) {

@@ -40,7 +40,7 @@ struct GnApply3Params {
 };
 struct ConvInParams {
   const float* x; const float* img; const float* mask;  // NCHW fp32; img/mask only for Cin == 9
-  const float* w; const float* bias;                    // [Cout][Cin][3][3], [Cout] fp32
+  const float* w; const float* bias;                    // [Cin*3*3][Cout] (pack.py transposes the reference's [Cout][Cin][3][3]), [Cout] fp32
   void* out;                                            // NHWC T [B][H][W][Cout]
   int B, H, W, Cin, Cout;
   int img_premul;                                       // channels 4-7 = img as is (2.2: hint latent / already masked image); else img*mask

@@ -395,16 +395,19 @@ __global__ __launch_bounds__(256) void resample_kernel(const void* xin, void* yo
 }
 
 // ---- stem: conv3x3 over the fp32 NCHW latent (4 ch, or 9 = [x, img*mask, mask] for inpainting)
-// (unet.py:426 input_blocks[0]; text2im_model2_1.py:146-155).  One block = 32 pixels of one row.
+// (unet.py:426 input_blocks[0]; text2im_model2_1.py:146-155).  One block = PT pixels of one row (8: at 96x96, B = 2 that is
+// 2304 workgroups; with 32-pixel tiles the 576 workgroups left most of the 256 CUs with a single 128-thread block).
+constexpr int CONV_IN_PT = 8;
 template <typename T, int CIN>
 __global__ __launch_bounds__(128) void conv_in_kernel(ConvInParams p) {
-  __shared__ float patch[CIN][3][34];
+  constexpr int PT = CONV_IN_PT, PW = PT + 2;
+  __shared__ float patch[CIN][3][PW];
   const int tid = threadIdx.x;
   const int xt = blockIdx.x, y = blockIdx.y, b = blockIdx.z;
-  const int x0 = xt * 32;
+  const int x0 = xt * PT;
   const int hw = p.H * p.W;
-  for (int i = tid; i < CIN * 3 * 34; i += 128) {
-    const int c = i / 102, r = (i / 34) % 3, xx = i % 34;
+  for (int i = tid; i < CIN * 3 * PW; i += 128) {
+    const int c = i / (3 * PW), r = (i / PW) % 3, xx = i % PW;
     const int yy = y + r - 1, xs = x0 + xx - 1;
     float v = 0.f;
     if (yy >= 0 && yy < p.H && xs >= 0 && xs < p.W) {
@@ -420,9 +423,9 @@ __global__ __launch_bounds__(128) void conv_in_kernel(ConvInParams p) {
   for (int n = tid; n < p.Cout; n += 128) {
     float w[CIN * 9];
 #pragma unroll
-    for (int k = 0; k < CIN * 9; ++k) w[k] = p.w[(int64_t)n * CIN * 9 + k];
+    for (int k = 0; k < CIN * 9; ++k) w[k] = p.w[(int64_t)k * p.Cout + n];   // packed [Cin*9][Cout]: coalesced over n
     const float bias = p.bias[n];
-    for (int px = 0; px < 32 && x0 + px < p.W; ++px) {
+    for (int px = 0; px < PT && x0 + px < p.W; ++px) {
       float acc = bias;
 #pragma unroll
       for (int c = 0; c < CIN; ++c)
@@ -685,7 +688,7 @@ int launch_resample(const void* x, void* y, int B, int H, int W, int C, int mode
   return K22_OK;
 }
 int launch_conv_in(const ConvInParams& p, int dtype, hipStream_t s) {
-  dim3 grid((p.W + 31) / 32, p.H, p.B);
+  dim3 grid((p.W + CONV_IN_PT - 1) / CONV_IN_PT, p.H, p.B);
   if (p.Cin == 4) {
     if (dtype == K22_BF16) hipLaunchKernelGGL((conv_in_kernel<bf16_t, 4>), grid, dim3(128), 0, s, p);
     else hipLaunchKernelGGL((conv_in_kernel<float, 4>), grid, dim3(128), 0, s, p);

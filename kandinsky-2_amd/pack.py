@@ -7,7 +7,8 @@ Layouts (T = engine dtype, bf16 or fp32; everything else fp32):
   AttentionBlock.encoder_kv rows       head*128 + {k,v}*64 + d    ->  {k,v}*C + head*64 + d
      (the reference keeps per-head [q|k|v] interleaved, unet.py:296-300; the engine wants Q, K, V planes)
   all ResBlock emb_layers.1 concatenated in module order -> T [sum 2*Cout][time_embed_dim] (one GEMV/step)
-  GroupNorm / LayerNorm affine, biases, time_embed.*, stem conv, clip_to_seq, proj_n, img_layer: fp32 as is
+  stem conv [O,I,3,3] -> fp32 [I*9][O]
+  GroupNorm / LayerNorm affine, biases, time_embed.*, clip_to_seq, proj_n, img_layer: fp32 as is
   time_freqs: exp(-ln(10000) * arange(half)/half) exactly as nn.py:113-117 builds it.
 The arena is ONE contiguous uint8 tensor (256-byte aligned entries): rank 0 packs, the other ranks
 receive it with a single RCCL broadcast (parallel.py) and rebuild the same offset table from the shapes.
@@ -69,7 +70,8 @@ def packed_entries(arch: UNetArch, sd: Dict[str, torch.Tensor], tdtype: torch.dt
     for b in arch.blocks:
         if b[0] == "stem":
             pfx = b[1]
-            out[pfx + ".weight"] = get(pfx + ".weight").contiguous()
+            w = get(pfx + ".weight")               # [O, I, 3, 3] -> [I*9][O]: the stem kernel reads one weight per thread, coalesced over O
+            out[pfx + ".weight"] = w.reshape(w.shape[0], -1).t().contiguous()
             out[pfx + ".bias"] = get(pfx + ".bias")
         elif b[0] == "res":
             _, pfx, cin, cout, _ud = b
