@@ -62,7 +62,8 @@ __device__ __forceinline__ void hist_add_aggregated(int* hist, bool valid, uint3
   // (low contention) and goes through plain LDS atomics.
   for (int round = 0; round < 4 && todo; ++round) {
     const int leader = __ffsll((unsigned long long)todo) - 1;
-    const uint32_t lb = __shfl(bin, leader, 64);
+    // leader is wave-uniform (derived from a ballot): v_readlane_b32, not a ds_bpermute round trip through the LDS crossbar
+    const uint32_t lb = (uint32_t)__builtin_amdgcn_readlane((int)bin, leader);
     const uint64_t same = __ballot(valid && bin == lb) & todo;
     if (lane == leader) atomicAdd(&hist[lb], __popcll(same));
     todo &= ~same;

@@ -47,6 +47,26 @@ def unet(cfg, inpainting, shapes, dtypes=(torch.bfloat16, torch.float32)):
         torch.cuda.empty_cache()
 
 
+def unet22(cfg, controlnet, shapes, dtypes=(torch.bfloat16, torch.float32)):
+    arch = k22.make_arch22(cfg, controlnet=controlnet)
+    sd = k22.init_unet22_state_dict(arch, seed=0)
+    for dt in dtypes:
+        m = k22.UNet2DConditionHIP(arch, backend_dtype=dt, use_graph=False)
+        m.load_state_dict(sd)
+        m = m.to("cuda")
+        m.prepare(free_params=True)
+        for (B, h, w) in shapes:
+            ack = {"image_embeds": torch.randn(B, arch.image_dim, device="cuda")}
+            if controlnet:
+                ack["hint"] = torch.rand(B, 3, 8 * h, 8 * w, device="cuda")
+            m.del_cache()
+            m(torch.randn(B, 4, h, w, device="cuda"), 500, added_cond_kwargs=ack)
+            torch.cuda.synchronize()
+            print(f"unet22 {'controlnet ' if controlnet else ''}C={arch.model_channels} {dt} B={B} {h}x{w}: table = {_lib.lib().k22_tile_table_size()} entries", flush=True)
+        del m
+        torch.cuda.empty_cache()
+
+
 def prior(hp, batches, dtypes=(torch.bfloat16, torch.float32)):
     sd = k22.init_prior_state_dict(hp, seed=0)
     for dt in dtypes:
@@ -68,8 +88,11 @@ def main():
     quick = "--quick" in sys.argv
     tiny = k22.tiny_model_config()
     # smoke() / parity-test shapes of the 1/3-width model
-    unet(tiny, False, [(2, 16, 16), (4, 8, 24)])
-    unet(tiny, True, [(4, 16, 24)])
+    unet(tiny, False, [(2, 16, 16), (4, 8, 24), (4, 16, 16)])
+    unet(tiny, True, [(4, 16, 24), (2, 16, 16), (4, 16, 16)])
+    t22 = k22.tiny_unet22_config()
+    unet22(t22, False, [(4, 16, 24), (4, 16, 16)])
+    unet22(t22, True, [(4, 16, 24), (4, 16, 16)])
     # BASELINE.json configs: C1 (256^2 bs 1), C2 (768^2 bs 1: the bench line), 512^2, C3 per-GPU (1024^2 bs 4), 768^2 bs 2 / bs 4
     if quick:
         unet(k22.MODEL_CONFIG_2_1, False, [(2, 96, 96)], dtypes=(torch.bfloat16,))
@@ -80,6 +103,10 @@ def main():
         unet(k22.MODEL_CONFIG_2_1, False, [(2, 32, 32), (2, 96, 96), (8, 128, 128)], dtypes=(torch.float32,))
         unet(k22.MODEL_CONFIG_2_1, True, [(8, 96, 96), (2, 96, 96)], dtypes=(torch.bfloat16,))   # C4 (inpainting 768^2 bs 4) and bs 1
         unet(k22.MODEL_CONFIG_2_1, True, [(8, 96, 96)], dtypes=(torch.float32,))
+        # Kandinsky 2.2 head (32 context tokens): C2 shape, C5 (ControlNet-depth 768^2 bs 2), and the full-width parity shape
+        unet22(k22.UNET_CONFIG_2_2, False, [(2, 96, 96), (2, 32, 32)], dtypes=(torch.bfloat16,))
+        unet22(k22.UNET_CONFIG_2_2, False, [(2, 32, 32)], dtypes=(torch.float32,))
+        unet22(k22.UNET_CONFIG_2_2, True, [(4, 96, 96)], dtypes=(torch.bfloat16,))
         prior(k22.tiny_prior_hparams(), [4])
         prior(k22.PRIOR_HPARAMS_2_1, [2, 4, 8], dtypes=(torch.bfloat16,))
         prior(k22.PRIOR_HPARAMS_2_1, [4], dtypes=(torch.float32,))
