@@ -115,11 +115,13 @@ template <int NBST> constexpr int halo_count_a(int t) {
 // on 128-byte rows), then the epilogue through LDS (bias, residual, one rounding, 16-byte stores, GroupNorm partials).
 // PLAIN = false: rows are positions v of the padded plane (3x3 convolution); PLAIN = true: rows are the pixels
 // v < H*W of image `img` themselves (gemm8_kernel), and the qkv-projection output mode is available.
-template <typename T, int BM, bool PLAIN = false>
-__device__ __forceinline__ void halo_tail(const IgemmParams& p, f32x16_t (&acc)[BM / 128][2], char* smem, int bx, int bz, int img, int v0, int n0) {
+// SPEC = true (conv3_halo_spec_kernel): only waves 0-3 hold accumulators, 2 x 2 over the tile with (BM/2) x 64 each; waves 4-7
+// were the producers of the main loop.  All eight waves issue the skip loop's LDS-DMA and run the store / statistics epilogue.
+template <typename T, int BM, bool PLAIN = false, bool SPEC = false>
+__device__ __forceinline__ void halo_tail(const IgemmParams& p, f32x16_t (&acc)[SPEC ? BM / 64 : BM / 128][2], char* smem, int bx, int bz, int img, int v0, int n0) {
   using TR = TT<T>;
   constexpr int BK = TR::BK, EPC = TR::EPC, KSTEPS = TR::KSTEPS;
-  constexpr int BN = HALO_BN, NW = HALO_NW, WM = 4, WN = 2;
+  constexpr int BN = HALO_BN, NW = HALO_NW, WM = SPEC ? 2 : 4, WN = 2;
   constexpr int MI = BM / (WM * 32), NI = BN / (WN * 32);
   constexpr int B_SLOTS = BN / 8 / NW;
   constexpr int B_BYTES = BN * 128;
@@ -127,6 +129,7 @@ __device__ __forceinline__ void halo_tail(const IgemmParams& p, f32x16_t (&acc)[
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
+  const bool cw = !SPEC || wave < 4;      // this wave holds accumulators (wave-uniform)
   const int h = lane >> 5, l31 = lane & 31;
   const int W2 = PLAIN ? 1 : p.W + 2;
   const int VR = PLAIN ? (p.H > 0 ? p.H * p.W : p.M) : p.H * W2;
@@ -194,6 +197,7 @@ __device__ __forceinline__ void halo_tail(const IgemmParams& p, f32x16_t (&acc)[
         if (q + 1 < q1) K22_ISSUE_SKIP(q + 1, buf ^ 1);
         const char* sA = smem + buf * SBUF;
         const char* sB = sA + BM * 128;
+        if (cw) {
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
           Frag<T> a[MI], b[NI];
@@ -206,6 +210,7 @@ __device__ __forceinline__ void halo_tail(const IgemmParams& p, f32x16_t (&acc)[
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], b[ni], a[mi]);
         }
+        }
         buf ^= 1;
       }
 #undef K22_ISSUE_SKIP
@@ -215,6 +220,7 @@ __device__ __forceinline__ void halo_tail(const IgemmParams& p, f32x16_t (&acc)[
   __syncthreads();  // every wave is done with the operand buffers: the LDS becomes the fp32 output tile
 
   // ---- epilogue 1: accumulators -> LDS tile [BM][BN] fp32 (lane = pixel, 4 consecutive channels per quad) ----
+  if (cw)
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int row = wm * (BM / WM) + mi * 32 + l31;
@@ -608,6 +614,238 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const IgemmParams p) {
       for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], pb[ni], pa[mi]);
   }
   halo_tail<T, BM>(p, acc, smem, bx, bz, img, v0, n0);
+}
+
+// ================================================================================================================
+// conv3_halo_spec_kernel (p.algo == 11 / 12): the same tile, LDS images and epilogue with the eight waves SPECIALISED.
+//   waves 0-3 ("consumers", one per SIMD): 2 x 2 over the BM x 128 tile, (BM/2) x 64 per wave (BM = 256: 128 x 64 = 8
+//              accumulators, 6 fragment reads per 8 MFMAs instead of 4 per 4); per tap they do nothing but read fragments and
+//              issue MFMAs - no LDS-DMA instruction, no vmcnt wait;
+//   waves 4-7 ("producers", the second wave of every SIMD): issue all the LDS-DMA of a tap (4 weight pieces + 2 halo pieces
+//              each) right after its barrier and sit in the counted vmcnt wait for the next tap's tile.
+// Producers and consumers execute the same barriers (one per tap): the ring-slot / halo-buffer reuse argument of
+// conv3_halo_kernel holds unchanged.
+// PIPE (p.algo == 12): explicit fragment pipeline in the consumers.  The fragments of k-step ks+1 are read while the MFMAs of
+// k-step ks are issued (two register sets), and the last k-step of a tap is multiplied after the next tap's barrier, where
+// its eight MFMAs cover the latency of that tap's first fragment reads.  Within a block the reads and the MFMAs are
+// INTERLEAVED one read behind every MFMA (sched_group_barrier): issued as a read burst and an MFMA burst, the matrix pipe
+// idles while the one wave that owns it spends its issue slots on ds_read_b128s.  Measured (bench_kernels, all 3x3
+// convolutions of one step): 4.09 ms against 4.51 ms for the best lock-step variant at BM = 256, 4.43 against 4.77 at
+// BM = 128; the specialisation alone (algo 11, compiler-scheduled consumers) is +-0 - it is the interleaved pipeline that the
+// one-owner matrix pipe makes worthwhile.
+// DBG = 1 (p.algo == 13, measurement only, wrong results): the producers issue nothing inside the tap loop - what is left is
+// the consumers' speed limit under the same barriers (1.43 PFLOP/s at 96x96 768->768 against 1.14-1.23 with the loads).
+// ================================================================================================================
+template <typename T, int BM, int NBST, bool PIPE = false, int DBG = 0>
+__global__ __launch_bounds__(512) void conv3_halo_spec_kernel(const IgemmParams p) {
+  using TR = TT<T>;
+  constexpr int BK = TR::BK, EPC = TR::EPC, KSTEPS = TR::KSTEPS;
+  constexpr int BN = HALO_BN, NWL = 4, WM = 2, WN = 2;
+  constexpr int MI = BM / (WM * 32), NI = BN / (WN * 32);
+  constexpr int B_SLOTS = BN / 8 / NWL;        // 4 weight LDS-DMA instructions per producer per tap
+  constexpr int B_BYTES = BN * 128;
+  constexpr int APT = 2;                       // halo pieces per producer per tap (taps 0 .. 9-NBST)
+  constexpr int A_SLOTS = (10 - NBST) * APT;
+  constexpr int GM = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave >= 4;             // wave-uniform
+  const int h = lane >> 5, l31 = lane & 31;
+
+  const int W2 = p.W + 2;
+  const int VR = p.H * W2;
+  const int TPI = (VR + BM - 1) / BM;
+  const int HRp = (BM + 2 * W2 + 2 + 7) & ~7;
+  const int NP = HRp >> 3;
+  const int A_BYTES = HRp * 128;
+  const int PR_MAX = (p.H + 2) * W2 - 1;
+  const int B = p.M / (p.H * p.W);
+
+  const int gx = B * TPI, gy = (p.N + BN - 1) / BN;
+  int L = p.xcd_remap ? xcd_remap_h(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int per_z = gx * gy;
+  const int bz = L / per_z;
+  L -= bz * per_z;
+  const int grp = L / (GM * gy);
+  const int first_m = grp * GM;
+  const int gsz = gx - first_m < GM ? gx - first_m : GM;
+  const int lin = L - grp * GM * gy;
+  const int bx = first_m + lin % gsz, by = lin / gsz;
+  const int img = bx / TPI, v0 = (bx - img * TPI) * BM;
+  const int n0 = by * BN;
+
+  const int nslab = p.Kc / BK;
+  int s0 = 0, s1 = nslab;
+  if (p.splitk > 1) {
+    const int per = (nslab + p.splitk - 1) / p.splitk;
+    s0 = bz * per;
+    s1 = s0 + per < nslab ? s0 + per : nslab;
+  }
+
+  f32x16_t acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  char* const Bst = smem + 2 * A_BYTES;
+  if (s0 < s1) {
+    if (producer) {
+      // ---------------------------------------- producers: LDS-DMA only -----------------------------------------------
+      const int lw = wave - 4;
+      const T* __restrict__ Aimg = reinterpret_cast<const T*>(p.A0) + (int64_t)img * (p.H + 2) * W2 * p.Kc;
+      const T* __restrict__ Wp = reinterpret_cast<const T*>(p.Wp);
+      int aoff[A_SLOTS];
+#pragma unroll
+      for (int q = 0; q < A_SLOTS; ++q) {
+        int j = q * NWL + lw;
+        if (j > NP - 1) j = NP - 1;   // surplus slots re-load the last piece (same bytes, same place): uniform counting
+        const int hr = 8 * j + (lane >> 3);
+        int pr = v0 + hr;
+        if (pr > PR_MAX) pr = PR_MAX;
+        aoff[q] = pr * p.Kc + ((lane & 7) ^ ((hr >> 1) & 7)) * EPC;
+      }
+      int boff[B_SLOTS];
+#pragma unroll
+      for (int i = 0; i < B_SLOTS; ++i) {
+        const int row = 8 * (lw + NWL * i) + (lane >> 3);
+        int n = n0 + row;
+        if (n > p.Npad - 1) n = p.Npad - 1;
+        boff[i] = n * 9 * p.Kc + ((lane & 7) ^ ((row >> 1) & 7)) * EPC;
+      }
+      const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
+#define K22_SP_A(Q, SLAB, DSTOFF)                                                                          \
+      {                                                                                                    \
+        int j_ = (Q) * NWL + lw;                                                                           \
+        if (j_ > NP - 1) j_ = NP - 1;                                                                      \
+        glds16_asm(Aimg + aoff[Q] + (SLAB) * BK, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(DSTOFF) + j_ * 1024)); \
+      }
+#define K22_SP_B(SLAB, TAP, STAGE)                                                                         \
+      {                                                                                                    \
+        const int kofs_ = (TAP) * p.Kc + (SLAB) * BK;                                                      \
+        const unsigned d_ = lds0 + 2 * A_BYTES + (STAGE) * B_BYTES + lw * 1024;                            \
+        _Pragma("unroll") for (int i = 0; i < B_SLOTS; ++i)                                                \
+            glds16_asm(Wp + boff[i] + kofs_, __builtin_amdgcn_readfirstlane(d_ + i * NWL * 1024));         \
+      }
+#pragma unroll
+      for (int q = 0; q < A_SLOTS; ++q) K22_SP_A(q, s0, 0);
+#pragma unroll
+      for (int t = 0; t < NBST - 1; ++t) K22_SP_B(s0, t, t);
+      int fill = NBST - 1;
+      for (int s = s0; s < s1; ++s) {
+        const int anext_off = (((s - s0) & 1) ^ 1) * A_BYTES;
+        const int sn = s + 1 < s1 ? s + 1 : s1 - 1;   // past-the-end loads re-read the last slab (uniform counting)
+#define K22_SP_PTAP(TAP)                                                                                   \
+        {                                                                                                  \
+          if constexpr (DBG != 1) wait_vmcnt<B_SLOTS * (NBST - 2) + APT * halo_count_a<NBST>(TAP)>();      \
+          raw_barrier();                                                                                   \
+          constexpr int ta_ = ((TAP) + NBST - 1) % 9;                                                      \
+          const int sa_ = ((TAP) + NBST - 1 >= 9) ? sn : s;                                                \
+          if constexpr (DBG != 1) K22_SP_B(sa_, ta_, fill);                                                \
+          if constexpr ((TAP) <= 9 - NBST && DBG != 1) {                                                   \
+            _Pragma("unroll") for (int a_ = 0; a_ < APT; ++a_) {                                           \
+              constexpr int qb_ = ((TAP) <= 9 - NBST ? (TAP) : 0) * APT;                                   \
+              K22_SP_A(qb_ + a_, sn, anext_off);                                                           \
+            }                                                                                              \
+          }                                                                                                \
+          fill = (fill + 1 == NBST) ? 0 : fill + 1;                                                        \
+        }
+        K22_SP_PTAP(0) K22_SP_PTAP(1) K22_SP_PTAP(2) K22_SP_PTAP(3) K22_SP_PTAP(4) K22_SP_PTAP(5) K22_SP_PTAP(6) K22_SP_PTAP(7) K22_SP_PTAP(8)
+#undef K22_SP_PTAP
+      }
+#undef K22_SP_A
+#undef K22_SP_B
+    } else {
+      // ---------------------------------------- consumers: fragments + MFMA only --------------------------------------
+      const int wm = wave >> 1, wn = wave & 1;
+      const int abase = wm * (BM / WM) + l31;
+      int brow[NI];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) brow[ni] = (wn * (BN / WN) + ni * 32 + l31) * 128;
+      const int bsw = (l31 >> 1) & 7;
+      int cur = 0;
+      Frag<T> pa[MI], pb[NI];   // PIPE: fragments read but not yet multiplied (zero = a no-op group before the first tap)
+      if constexpr (PIPE) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) pa[mi] = Frag<T>{};
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) pb[ni] = Frag<T>{};
+      }
+      // One block of the pipeline = NRD fragment reads (of the NEXT group) + NMF MFMAs (of the group read one block ago), which
+      // are independent of each other: one read is scheduled behind every MPR MFMAs (0x008 = MFMA, 0x100 = DS read), so that
+      // each ds_read_b128 issues under the 32 cycles the MFMA before it occupies the pipe.
+      constexpr int NRD = (MI + NI) * (sizeof(T) == 2 ? 1 : 2);
+      constexpr int NMF = MI * NI * (sizeof(T) == 2 ? 1 : 8);
+      constexpr int MPR = NMF / NRD;
+#define K22_SP_INTERLEAVE()                                                                                \
+      {                                                                                                    \
+        _Pragma("unroll") for (int i_ = 0; i_ < NRD; ++i_) {                                               \
+          __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);                                             \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                               \
+        }                                                                                                  \
+        if constexpr (NMF - MPR * NRD > 0) __builtin_amdgcn_sched_group_barrier(0x008, NMF - MPR * NRD, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+      }
+      for (int s = s0; s < s1; ++s) {
+        const char* const Acur = smem + ((s - s0) & 1) * A_BYTES;
+#define K22_SP_CTAP(TAP)                                                                                   \
+        {                                                                                                  \
+          raw_barrier();                                                                                   \
+          const char* Bcur = Bst + cur * B_BYTES;                                                          \
+          const int shift = ((TAP) / 3) * W2 + ((TAP) % 3);                                                \
+          const char* arow[MI];                                                                            \
+          int asw[MI];                                                                                     \
+          _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                              \
+            const int ar = abase + mi * 32 + shift;                                                        \
+            arow[mi] = Acur + ar * 128;                                                                    \
+            asw[mi] = (ar >> 1) & 7;                                                                       \
+          }                                                                                                \
+          if constexpr (PIPE) {                                                                            \
+            Frag<T> ca[MI], cb[NI];                                                                        \
+            _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ks += 2) {                                     \
+              _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) ld_frag_at(ca[mi], arow[mi], asw[mi], ks, h); \
+              _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) ld_frag_at(cb[ni], Bcur + brow[ni], bsw, ks, h); \
+              _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                            \
+                _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], pb[ni], pa[mi]);   \
+              K22_SP_INTERLEAVE();                                                                         \
+              _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) ld_frag_at(pa[mi], arow[mi], asw[mi], ks + 1, h); \
+              _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) ld_frag_at(pb[ni], Bcur + brow[ni], bsw, ks + 1, h); \
+              _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                            \
+                _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], cb[ni], ca[mi]);   \
+              K22_SP_INTERLEAVE();                                                                         \
+            }                                                                                              \
+          } else {                                                                                         \
+          _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks) {                                          \
+            Frag<T> a[MI], b[NI];                                                                          \
+            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) ld_frag_at(a[mi], arow[mi], asw[mi], ks, h); \
+            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) ld_frag_at(b[ni], Bcur + brow[ni], bsw, ks, h); \
+            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                              \
+              _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], b[ni], a[mi]);       \
+          }                                                                                                \
+          }                                                                                                \
+          /* Fragment reads may not stay in flight across the next barrier when the producers refill what they read right    \
+             after it: with a 2-deep ring that is THIS tap's weight slot, and after tap 8 the halo buffer of the slab before. \
+             (The MFMAs that use them can sink below the barrier - registers only - in both forms.) */                      \
+          if constexpr (NBST == 2 || (TAP) == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        \
+          cur = (cur + 1 == NBST) ? 0 : cur + 1;                                                           \
+        }
+        K22_SP_CTAP(0) K22_SP_CTAP(1) K22_SP_CTAP(2) K22_SP_CTAP(3) K22_SP_CTAP(4) K22_SP_CTAP(5) K22_SP_CTAP(6) K22_SP_CTAP(7) K22_SP_CTAP(8)
+#undef K22_SP_CTAP
+      }
+#undef K22_SP_INTERLEAVE
+      if constexpr (PIPE) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], pb[ni], pa[mi]);
+      }
+    }
+  }
+  halo_tail<T, BM, false, true>(p, acc, smem, bx, bz, img, v0, n0);
 }
 
 // ================================================================================================================
@@ -1265,6 +1503,27 @@ static int launch_halo_nbst(const IgemmParams& p, int nbst, int splitk, hipStrea
   return launch_halo_cfg<T, BM, 6, LW, MODE>(p, splitk, stream);
 }
 
+template <typename T, int BM, int NBST, bool PIPE, int DBG = 0>
+static int launch_halo_spec_cfg(const IgemmParams& p, int splitk, hipStream_t stream) {
+  const size_t smem = halo_smem_bytes(p, BM, NBST);
+  static LdsAttrGuard attr_guard;
+  if (int rc_ = k22_ensure_lds_attr(attr_guard, reinterpret_cast<const void*>(&conv3_halo_spec_kernel<T, BM, NBST, PIPE, DBG>), 160 * 1024, __FILE__, __LINE__)) return rc_;
+  IgemmParams q = p;
+  q.splitk = splitk;
+  const int B = p.M / (p.H * p.W);
+  const int nblocks = B * conv3_halo_tiles_per_image(p, BM) * ((p.N + HALO_BN - 1) / HALO_BN) * splitk;
+  hipLaunchKernelGGL((conv3_halo_spec_kernel<T, BM, NBST, PIPE, DBG>), dim3(nblocks), dim3(512), smem, stream, q);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+template <typename T, int BM, bool PIPE>
+static int launch_halo_spec_nbst(const IgemmParams& p, int nbst, int splitk, hipStream_t stream) {
+  if (nbst == 2) return launch_halo_spec_cfg<T, BM, 2, PIPE>(p, splitk, stream);
+  if (nbst == 3) return launch_halo_spec_cfg<T, BM, 3, PIPE>(p, splitk, stream);
+  if (nbst <= 5) return launch_halo_spec_cfg<T, BM, 4, PIPE>(p, splitk, stream);
+  return launch_halo_spec_cfg<T, BM, 6, PIPE>(p, splitk, stream);
+}
+
 template <typename T, int BM, int RB>
 static int launch_halo3_cfg(const IgemmParams& p, int splitk, hipStream_t stream) {
   const size_t smem = halo3_smem_bytes(p, BM, RB);
@@ -1345,6 +1604,20 @@ int launch_conv3_halo(const IgemmParams& p, int dtype, int bm, int splitk, hipSt
   }
   int nbst = halo_pick_nbst(p, bm);
   if (p.stages >= 2 && p.stages < nbst) nbst = p.stages == 5 ? 4 : p.stages;  // tuning knob: shallower ring on request
+  if (p.algo == 11) {  // producer / consumer wave specialisation (conv3_halo_spec_kernel), compiler-scheduled consumers
+    if (dtype == K22_BF16) return bm == 256 ? launch_halo_spec_nbst<bf16_t, 256, false>(p, nbst, splitk, stream) : launch_halo_spec_nbst<bf16_t, 128, false>(p, nbst, splitk, stream);
+    return bm == 256 ? launch_halo_spec_nbst<float, 256, false>(p, nbst, splitk, stream) : launch_halo_spec_nbst<float, 128, false>(p, nbst, splitk, stream);
+  }
+  if (p.algo == 12) {  // the same with the explicit, interleaved fragment pipeline in the consumers
+    if (dtype == K22_BF16) return bm == 256 ? launch_halo_spec_nbst<bf16_t, 256, true>(p, nbst, splitk, stream) : launch_halo_spec_nbst<bf16_t, 128, true>(p, nbst, splitk, stream);
+    // fp32, BM = 256: two fragment sets of 8 registers per fragment do not fit beside 128 accumulators (the pipelined form spills):
+    // the compiler-scheduled consumer is used there
+    return bm == 256 ? launch_halo_spec_nbst<float, 256, false>(p, nbst, splitk, stream) : launch_halo_spec_nbst<float, 128, true>(p, nbst, splitk, stream);
+  }
+  if (p.algo == 13) {  // measurement-only form of algo 12 (wrong results): no LDS-DMA inside the tap loop
+    if (dtype != K22_BF16 || bm != 256) return k22_set_error(K22_EINVAL, "conv3_halo: the debug variant is bf16, BM = 256 only");
+    return nbst == 2 ? launch_halo_spec_cfg<bf16_t, 256, 2, true, 1>(p, splitk, stream) : launch_halo_spec_cfg<bf16_t, 256, 4, true, 1>(p, splitk, stream);
+  }
   if (p.algo == 5) {  // loader-wave specialisation (waves 0-3 issue all LDS-DMA)
     if (dtype == K22_BF16) return bm == 256 ? launch_halo_nbst<bf16_t, 256, 4, 0>(p, nbst, splitk, stream) : launch_halo_nbst<bf16_t, 128, 4, 0>(p, nbst, splitk, stream);
     return bm == 256 ? launch_halo_nbst<float, 256, 4, 0>(p, nbst, splitk, stream) : launch_halo_nbst<float, 128, 4, 0>(p, nbst, splitk, stream);

@@ -112,7 +112,8 @@ inline void tuned_make_candidates(Tuned& t, int dtype) {
     // deep split-K); 4 = two-phase kernel (measured 12-20 % slower than 2 on every shape: not a candidate)
     // 5 = loader-wave specialisation (measured 2-5 % slower: not a candidate); 7 = LDS-DMA from inline asm (exact
     // lgkmcnt for the fragment reads, +1-3 %); 6 = 7 + explicit fragment pipeline across the barrier
-    for (int algo : {2, 7, 6, 3}) {
+    // 11 = producer / consumer wave specialisation (conv3_halo_spec_kernel)
+    for (int algo : {2, 7, 6, 3, 11, 12}) {
       if (algo == 3 && p.H > 16) continue;
       IgemmParams ph = p;
       ph.algo = algo;
@@ -303,7 +304,7 @@ inline std::string tuning_report_text(const std::deque<Tuned>& tuned) {
   for (auto& t : tuned) {
     char line[256];
     snprintf(line, sizeof line, "%4d %6d %5d %5d %4d %4d %5d | %4s %3d %3d %6d %3d | %8.1f", t.p.taps, t.p.M, t.p.N, t.p.Kc,
-             t.p.H, t.p.W, t.want_stats ? 1 : 0, t.cfg.algo == 2 ? "halo" : (t.cfg.algo == 3 ? "hal3" : (t.cfg.algo == 4 ? "hal4" : (t.cfg.algo == 5 ? "hal5" : (t.cfg.algo == 6 ? "hal6" : (t.cfg.algo == 7 ? "hal7" : (t.cfg.algo == 10 ? "gem8" : (t.cfg.algo == 1 ? "gen" : "auto"))))))), t.cfg.bm, t.cfg.bn,
+             t.p.H, t.p.W, t.want_stats ? 1 : 0, t.cfg.algo == 2 ? "halo" : (t.cfg.algo == 3 ? "hal3" : (t.cfg.algo == 4 ? "hal4" : (t.cfg.algo == 5 ? "hal5" : (t.cfg.algo == 6 ? "hal6" : (t.cfg.algo == 7 ? "hal7" : (t.cfg.algo == 10 ? "gem8" : (t.cfg.algo == 11 ? "spec" : (t.cfg.algo == 12 ? "spcp" : (t.cfg.algo == 1 ? "gen" : "auto"))))))))), t.cfg.bm, t.cfg.bn,
              t.cfg.splitk, t.cfg.stages, t.best_us);
     if (!seen.count(line)) order.push_back(line);
     seen[line]++;

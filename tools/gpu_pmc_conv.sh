@@ -7,7 +7,7 @@ REPO=$PWD
 TAG=${1:-sq}
 OUT=$REPO/gpurun_out/pmc_$TAG
 rm -rf $OUT
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT -- python $REPO/tools/bench_kernels.py --reps 2 --configs h256x1,h128x1 --filter "384,384,96;768,768,48;768,768,96" > $REPO/gpurun_out/pmc_${TAG}.log 2>&1 )
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT -- python $REPO/tools/bench_kernels.py --reps 2 --configs ${PMC_CONFIGS:-h256x1,h128x1} --filter "384,384,96;768,768,48;768,768,96" > $REPO/gpurun_out/pmc_${TAG}.log 2>&1 )
 tail -5 $REPO/gpurun_out/pmc_${TAG}.log | cut -c1-200
 python - "$OUT" > gpurun_out/pmc_${TAG}_summary.txt <<'PY'
 import csv, sys, glob, collections, re
@@ -15,8 +15,9 @@ root = sys.argv[1]
 rows = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f"{root}/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        name = re.sub(r"\s+", " ", r.get("Kernel_Name", ""))[:48]
+        name = re.sub(r"\s+", " ", r.get("Kernel_Name", ""))[:70]
         if "conv3_halo" not in name: continue
+        name = re.sub(r"void |unsigned short", "", name)
         key = (name, r.get("Grid_Size", r.get("Grid_Size_X", "")))
         rows[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 ctrs = ["SQ_WAVE_CYCLES","SQ_BUSY_CYCLES","SQ_WAIT_ANY","SQ_WAIT_INST_ANY","SQ_ACTIVE_INST_ANY","SQ_VALU_MFMA_BUSY_CYCLES","SQ_LDS_BANK_CONFLICT","SQ_LDS_IDX_ACTIVE"]
