@@ -30,6 +30,7 @@
 //     block input's channels (A rows = the tile's own pixels, no halo) that accumulates into the same registers,
 //     so the skip tensor is never written, re-read or launched separately
 #include "kernels.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -633,8 +634,13 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const IgemmParams p) {
 // convolutions of one step): 4.09 ms against 4.51 ms for the best lock-step variant at BM = 256, 4.43 against 4.77 at
 // BM = 128; the specialisation alone (algo 11, compiler-scheduled consumers) is +-0 - it is the interleaved pipeline that the
 // one-owner matrix pipe makes worthwhile.
-// DBG = 1 (p.algo == 13, measurement only, wrong results): the producers issue nothing inside the tap loop - what is left is
-// the consumers' speed limit under the same barriers (1.43 PFLOP/s at 96x96 768->768 against 1.14-1.23 with the loads).
+// DBG (measurement only, wrong results): 1 (p.algo == 13) = the producers issue nothing inside the tap loop - what is left is
+// the consumers' speed limit under the same barriers; 2 (p.algo == 14) = the LDS-DMA is issued but never waited for.  At 96x96
+// 768->768, same box: 1.08 PFLOP/s complete, 1.22 without the waits, 1.39 without the loads - half of what the loads cost
+// there is the ONE tap a tile has to land in (2-slot ring: the LDS holds the double-buffered halo), half is contention;
+// where four slots fit (48x48) the waits cost nothing and the contention is the same 12-14 %.  Staging the weight tiles
+// through producer registers (global_load two taps ahead, ds_write_b128 into the 2-slot ring) was built and measured equal
+// to the LDS-DMA form at 96x96 and slower elsewhere; removed.
 // ================================================================================================================
 template <typename T, int BM, int NBST, bool PIPE = false, int DBG = 0>
 __global__ __launch_bounds__(512) void conv3_halo_spec_kernel(const IgemmParams p) {
@@ -741,7 +747,7 @@ __global__ __launch_bounds__(512) void conv3_halo_spec_kernel(const IgemmParams 
         const int sn = s + 1 < s1 ? s + 1 : s1 - 1;   // past-the-end loads re-read the last slab (uniform counting)
 #define K22_SP_PTAP(TAP)                                                                                   \
         {                                                                                                  \
-          if constexpr (DBG != 1) wait_vmcnt<B_SLOTS * (NBST - 2) + APT * halo_count_a<NBST>(TAP)>();      \
+          if constexpr (DBG == 0) wait_vmcnt<B_SLOTS * (NBST - 2) + APT * halo_count_a<NBST>(TAP)>();      \
           raw_barrier();                                                                                   \
           constexpr int ta_ = ((TAP) + NBST - 1) % 9;                                                      \
           const int sa_ = ((TAP) + NBST - 1 >= 9) ? sn : s;                                                \
@@ -768,6 +774,7 @@ __global__ __launch_bounds__(512) void conv3_halo_spec_kernel(const IgemmParams 
       for (int ni = 0; ni < NI; ++ni) brow[ni] = (wn * (BN / WN) + ni * 32 + l31) * 128;
       const int bsw = (l31 >> 1) & 7;
       int cur = 0;
+      // (s_setprio 3 in the consumers, so that they win issue arbitration against the producer on their SIMD: measured +-1 %)
       Frag<T> pa[MI], pb[NI];   // PIPE: fragments read but not yet multiplied (zero = a no-op group before the first tap)
       if constexpr (PIPE) {
 #pragma unroll
@@ -1614,9 +1621,10 @@ int launch_conv3_halo(const IgemmParams& p, int dtype, int bm, int splitk, hipSt
     // the compiler-scheduled consumer is used there
     return bm == 256 ? launch_halo_spec_nbst<float, 256, false>(p, nbst, splitk, stream) : launch_halo_spec_nbst<float, 128, true>(p, nbst, splitk, stream);
   }
-  if (p.algo == 13) {  // measurement-only form of algo 12 (wrong results): no LDS-DMA inside the tap loop
-    if (dtype != K22_BF16 || bm != 256) return k22_set_error(K22_EINVAL, "conv3_halo: the debug variant is bf16, BM = 256 only");
-    return nbst == 2 ? launch_halo_spec_cfg<bf16_t, 256, 2, true, 1>(p, splitk, stream) : launch_halo_spec_cfg<bf16_t, 256, 4, true, 1>(p, splitk, stream);
+  if (p.algo == 13 || p.algo == 14) {  // measurement-only forms of algo 12 (wrong results): 13 = no LDS-DMA inside the tap loop, 14 = LDS-DMA issued but never waited for
+    if (dtype != K22_BF16 || bm != 256) return k22_set_error(K22_EINVAL, "conv3_halo: the debug variants are bf16, BM = 256 only");
+    if (p.algo == 13) return nbst == 2 ? launch_halo_spec_cfg<bf16_t, 256, 2, true, 1>(p, splitk, stream) : launch_halo_spec_cfg<bf16_t, 256, 4, true, 1>(p, splitk, stream);
+    return nbst == 2 ? launch_halo_spec_cfg<bf16_t, 256, 2, true, 2>(p, splitk, stream) : launch_halo_spec_cfg<bf16_t, 256, 4, true, 2>(p, splitk, stream);
   }
   if (p.algo == 5) {  // loader-wave specialisation (waves 0-3 issue all LDS-DMA)
     if (dtype == K22_BF16) return bm == 256 ? launch_halo_nbst<bf16_t, 256, 4, 0>(p, nbst, splitk, stream) : launch_halo_nbst<bf16_t, 128, 4, 0>(p, nbst, splitk, stream);

@@ -82,9 +82,9 @@ def main():
     for c in a.configs.split(","):
         if c == "auto":
             cfgs.append((0, 0, 0, 0))
-        elif c[0] in "hgklpaxystu":   # h256 / h128x2 : halo kernel (g = 64-byte-row variant), BM, split-K
+        elif c[0] in "hgklpaxystuv":   # h256 / h128x2 : halo kernel (g = 64-byte-row variant), BM, split-K
             parts = c[1:].split("x")
-            cfgs.append((int(parts[0]), 0, int(parts[1]) if len(parts) > 1 else 0, {"h": 2, "g": 3, "k": 4, "l": 5, "p": 6, "a": 7, "x": 8, "y": 9, "s": 11, "t": 12, "u": 13}[c[0]]))
+            cfgs.append((int(parts[0]), 0, int(parts[1]) if len(parts) > 1 else 0, {"h": 2, "g": 3, "k": 4, "l": 5, "p": 6, "a": 7, "x": 8, "y": 9, "s": 11, "t": 12, "u": 13, "v": 14}[c[0]]))
         else:                            # 128x64x8 : generic implicit GEMM
             parts = c.split("x")
             cfgs.append((int(parts[0]), int(parts[1]), int(parts[2]) if len(parts) > 2 else 1, 1))
