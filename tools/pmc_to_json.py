@@ -17,7 +17,7 @@ src, rnd = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "r02")
 fetch = write = 0.0
 calls = 0
 for line in open(src):
-    if "conv3_halo_kernel" not in line:
+    if "conv3_halo" not in line or "kernel<" not in line:
         continue
     m = re.match(r"(.{60})\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)", line)
     if not m:
