@@ -7,5 +7,5 @@ it; the product path has no CPU fallback.
 Parity pinning: the reference ships no tests or golden vectors, so the restatement is
 pinned against the reference's OWN modules, imported from /root/reference in the build container by
 oracle/ref_loader.py (oracle/make_golden.py writes tests/golden/*.pt from those runs, and
-tests/test_oracle_golden.py re-checks the restatement against the committed fixtures everywhere).
+tests/test_host_cpu.py re-checks the restatement against the committed fixtures everywhere).
 """
