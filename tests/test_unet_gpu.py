@@ -232,3 +232,31 @@ def test_rank_nonzero_path_adopts_a_broadcast_arena():
     x = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(1)).cuda()
     t = torch.tensor([500.0, 500.0]).cuda()
     assert torch.equal(m0(x, t, **kw), m1(x, t, **kw))
+
+
+def test_bf16_engine_against_the_reference_fp16_yardstick(golden_dir):
+    """The reference's own fp16 mode vs its own fp32 mode (oracle/ref_fp16_drift.py, CPU, C1 shape, 10 steps, same injected noise;
+    tests/golden/ref_fp16_drift.json) is the yardstick for what reduced-precision storage costs.  bf16 has 3 fewer mantissa bits
+    than fp16 (x8): the bf16 engine's distance from the fp32 reference on the SAME run must stay within 8x the reference's own
+    fp16 distance, per forward and on the final latent."""
+    import json
+    p = os.path.join(golden_dir, "ref_fp16_drift.json")
+    if not os.path.exists(p):
+        pytest.skip("ref_fp16_drift.json not generated")
+    with open(p) as f:
+        yard = json.load(f)
+    fx = _load(golden_dir, "full_c1_text2img")
+    arch, sd, m, _x, img, mask, kw = _setup(fx, torch.bfloat16, use_graph=True)
+    g = torch.Generator().manual_seed(42)
+    x_T = torch.randn(fx["B"], 4, fx["h"], fx["w"], generator=g)
+    noise_seq = torch.randn(fx["steps"], fx["B"], 4, fx["h"], fx["w"], generator=g)
+    d = k22.create_gaussian_diffusion(**dict(k22.DIFFUSION_CONFIG_2_1, timestep_respacing=str(fx["steps"])))
+    final = d.p_sample_loop(m, (fx["B"], 4, fx["h"], fx["w"]), model_kwargs=kw, guidance_scale=fx["guidance"], noise=x_T.cuda(),
+                            noise_seq=noise_seq.cuda()).cpu()
+    err = (final - fx["final"]).abs().max().item()
+    rms = (final - fx["final"]).pow(2).mean().sqrt().item()
+    ref_last = yard["steps"][str(fx["steps"])]
+    ref_worst = max(v["max_abs"] for v in yard["steps"].values())
+    print(f"C1 10-step final latent: bf16 engine {err:.3e} / rms {rms:.3e};  reference fp16 mode {ref_last['max_abs']:.3e} / rms {ref_last['rms']:.3e} "
+          f"(worst step {ref_worst:.3e})")
+    assert err <= 8 * ref_worst and rms <= 8 * ref_last["rms"]
