@@ -863,6 +863,9 @@ __global__ __launch_bounds__(512) void conv3_halo_spec_kernel(const IgemmParams 
 // partial sums of the stored values, or the qkv-projection layout.  Against igemm_kernel (4 waves, <= 128 x 128):
 // twice the FLOPs per L2->LDS byte at 256 x 128 and two waves per SIMD; m-tiles never straddle an image (rows of a
 // tile past the image are masked), so the per-tile statistics are per-image statistics.
+// (Round 2: a variant that staged both operands through registers - plain global_load two slabs ahead, ds_write_b128 into a
+// two-stage LDS ring, no LDS-DMA - was built, parity-green, and measured equal: 1.29 ms against 1.26-1.31 ms for the GEMMs of one
+// step.  The K loop of these GEMMs is not bound by the LDS-DMA issue cost; removed.)
 // ================================================================================================================
 // RS = true (cfg.stages == 5, NST must be 2): the operands are staged through REGISTERS - plain global_load of slab s+2 into one of
 // two register sets while slab s is multiplied, ds_write_b128 of the set holding slab s+1 into the LDS stage slab s-1 just
