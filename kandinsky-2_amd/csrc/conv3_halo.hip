@@ -867,14 +867,8 @@ __global__ __launch_bounds__(512) void conv3_halo_spec_kernel(const IgemmParams 
 // two-stage LDS ring, no LDS-DMA - was built, parity-green, and measured equal: 1.29 ms against 1.26-1.31 ms for the GEMMs of one
 // step.  The K loop of these GEMMs is not bound by the LDS-DMA issue cost; removed.)
 // ================================================================================================================
-// RS = true (cfg.stages == 5, NST must be 2): the operands are staged through REGISTERS - plain global_load of slab s+2 into one of
-// two register sets while slab s is multiplied, ds_write_b128 of the set holding slab s+1 into the LDS stage slab s-1 just
-// vacated - instead of LDS-DMA.  A GEMM has no operand reuse across K iterations (every slab moves BM + 128 fresh rows), so each
-// wave issues 4-6 LDS-DMA pieces per slab for 8-16 MFMAs, and an LDS-DMA piece costs ~100-185 issue cycles in this phase
-// (MI355X_MICROARCH.md) where a global_load + ds_write_b128 pair costs ~30.
-template <typename T, int BM, int NST, bool RS = false>
+template <typename T, int BM, int NST>
 __global__ __launch_bounds__(512) void gemm8_kernel(const IgemmParams p) {
-  static_assert(!RS || NST == 2, "register staging uses two LDS stages");
   using TR = TT<T>;
   constexpr int BK = TR::BK, EPC = TR::EPC, KSTEPS = TR::KSTEPS;
   constexpr int BN = HALO_BN, NW = HALO_NW, WM = 4, WN = 2;
@@ -956,75 +950,6 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const IgemmParams p) {
   for (int ni = 0; ni < NI; ++ni) brow[ni] = A_BYTES + (wn * (BN / WN) + ni * 32 + l31) * 128;
   const int sw = (l31 >> 1) & 7;
 
-  if constexpr (RS) {
-    if (s0 < s1) {
-      // slab j is staged in set j & 1; explicit scalars (indexed arrays of staged data went to scratch): a0..a3 = A pieces
-      // (a2, a3 only at BM = 256), b0, b1 = weight pieces
-      uint4 r0a0, r0a1, r0a2, r0a3, r0b0, r0b1, r1a0, r1a1, r1a2, r1a3, r1b0, r1b1;
-      char* const wA = smem + wave * 1024 + lane * 16;
-      static_assert(B_SLOTS == 2 && (A_SLOTS == 2 || A_SLOTS == 4), "piece counts of the 8-wave frame");
-#define K22_RS_LOAD(R, SLAB)                                                                               \
-      {                                                                                                    \
-        const int sl_ = (SLAB) > s1 - 1 ? s1 - 1 : (SLAB);   /* past-the-end loads re-read the last slab */  \
-        R##a0 = *reinterpret_cast<const uint4*>(A + aoff[0] + sl_ * BK);                                   \
-        R##a1 = *reinterpret_cast<const uint4*>(A + aoff[1] + sl_ * BK);                                   \
-        if constexpr (A_SLOTS == 4) {                                                                      \
-          R##a2 = *reinterpret_cast<const uint4*>(A + aoff[A_SLOTS - 2] + sl_ * BK);                       \
-          R##a3 = *reinterpret_cast<const uint4*>(A + aoff[A_SLOTS - 1] + sl_ * BK);                       \
-        }                                                                                                  \
-        R##b0 = *reinterpret_cast<const uint4*>(Wp + boff[0] + sl_ * BK);                                  \
-        R##b1 = *reinterpret_cast<const uint4*>(Wp + boff[1] + sl_ * BK);                                  \
-      }
-#define K22_RS_STORE(R, STAGE)                                                                             \
-      {                                                                                                    \
-        char* d_ = wA + (STAGE) * BUF;                                                                     \
-        *reinterpret_cast<uint4*>(d_) = R##a0;                                                             \
-        *reinterpret_cast<uint4*>(d_ + NW * 1024) = R##a1;                                                 \
-        if constexpr (A_SLOTS == 4) {                                                                      \
-          *reinterpret_cast<uint4*>(d_ + 2 * NW * 1024) = R##a2;                                           \
-          *reinterpret_cast<uint4*>(d_ + 3 * NW * 1024) = R##a3;                                           \
-        }                                                                                                  \
-        *reinterpret_cast<uint4*>(d_ + A_BYTES) = R##b0;                                                   \
-        *reinterpret_cast<uint4*>(d_ + A_BYTES + NW * 1024) = R##b1;                                       \
-      }
-      auto compute = [&](int stage) __attribute__((always_inline)) {
-        const char* St = smem + stage * BUF;
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-          Frag<T> a[MI], b[NI];
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) ld_frag_at(a[mi], St + arow[mi], sw, ks, h);
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) ld_frag_at(b[ni], St + brow[ni], sw, ks, h);
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], b[ni], a[mi]);
-        }
-      };
-      K22_RS_LOAD(r0, s0);
-      K22_RS_LOAD(r1, s0 + 1);
-      K22_RS_STORE(r0, 0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      raw_barrier();
-      for (int s = s0; s < s1; s += 2) {
-        // even iteration: slab s is in stage 0, slab s+1 in set 1 (in flight or landed)
-        K22_RS_LOAD(r0, s + 2);
-        compute(0);
-        K22_RS_STORE(r1, 1);         // stage 1 was last read in the iteration before: every wave is past its barrier
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        raw_barrier();
-        if (s + 1 >= s1) break;
-        K22_RS_LOAD(r1, s + 3);
-        compute(1);
-        K22_RS_STORE(r0, 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        raw_barrier();
-      }
-#undef K22_RS_LOAD
-#undef K22_RS_STORE
-    }
-  } else
   if (s0 < s1) {
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t) K22_ISSUE_G(s0 + t, t);
@@ -1523,16 +1448,16 @@ bool gemm8_supported(const IgemmParams& p, int dtype, int bm) {
   return true;
 }
 
-template <typename T, int BM, int NST, bool RS = false>
+template <typename T, int BM, int NST>
 static int launch_gemm8_cfg(const IgemmParams& p, int splitk, hipStream_t stream) {
   const size_t smem = gemm8_smem_bytes(BM, NST);
   static LdsAttrGuard attr_guard;
-  if (int rc_ = k22_ensure_lds_attr(attr_guard, reinterpret_cast<const void*>(&gemm8_kernel<T, BM, NST, RS>), 160 * 1024, __FILE__, __LINE__)) return rc_;
+  if (int rc_ = k22_ensure_lds_attr(attr_guard, reinterpret_cast<const void*>(&gemm8_kernel<T, BM, NST>), 160 * 1024, __FILE__, __LINE__)) return rc_;
   IgemmParams q = p;
   q.splitk = splitk;
   const int hw = p.H > 0 ? p.H * p.W : p.M;
   const int nblocks = (p.M / hw) * gemm8_tiles_per_image(p, BM) * ((p.N + HALO_BN - 1) / HALO_BN) * splitk;
-  hipLaunchKernelGGL((gemm8_kernel<T, BM, NST, RS>), dim3(nblocks), dim3(512), smem, stream, q);
+  hipLaunchKernelGGL((gemm8_kernel<T, BM, NST>), dim3(nblocks), dim3(512), smem, stream, q);
   K22_CHECK_LAUNCH();
   return K22_OK;
 }
@@ -1540,10 +1465,6 @@ static int launch_gemm8_cfg(const IgemmParams& p, int splitk, hipStream_t stream
 // Launches gemm8_kernel only (a split-K reduction, if any, is the caller's: launch_igemm).
 int launch_gemm8(const IgemmParams& p, int dtype, int bm, int splitk, hipStream_t stream) {
   if (!gemm8_supported(p, dtype, bm)) return k22_set_error(K22_EINVAL, "gemm8: unsupported problem");
-  if (p.stages == 5) {   // register-staged operands, two LDS stages
-    if (dtype == K22_BF16) return bm == 256 ? launch_gemm8_cfg<bf16_t, 256, 2, true>(p, splitk, stream) : launch_gemm8_cfg<bf16_t, 128, 2, true>(p, splitk, stream);
-    return bm == 256 ? launch_gemm8_cfg<float, 256, 2, true>(p, splitk, stream) : launch_gemm8_cfg<float, 128, 2, true>(p, splitk, stream);
-  }
   const int nst = gemm8_nst(bm, p.stages);
   if (dtype == K22_BF16) {
     if (bm == 256) return launch_gemm8_cfg<bf16_t, 256, 3>(p, splitk, stream);

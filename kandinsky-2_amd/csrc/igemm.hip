@@ -425,7 +425,7 @@ struct IgemmPlan { int halo, bm, bn, splitk, stages; };  // halo: conv3_halo.hip
 static int g_stages_override = -1;
 static int g_xcd_remap = 1;
 static int g_conv_algo = 0;
-void igemm_set_default_stages(int v) { g_stages_override = (v >= 2 && v <= 5) ? v : -1; }   // 5: gemm8 register-staged variant only
+void igemm_set_default_stages(int v) { g_stages_override = (v >= 2 && v <= 4) ? v : -1; }
 void igemm_set_xcd_remap(int v) { g_xcd_remap = v ? 1 : 0; }
 void igemm_set_conv_algo(int v) { g_conv_algo = ((v >= 0 && v <= 9) || (v >= 11 && v <= 14)) ? v : 0; }
 static int g_gemm_algo = 0;   // 0 = generic igemm_kernel, 10 = gemm8_kernel where it applies (unit tests / kernel benches)
@@ -433,7 +433,7 @@ void igemm_set_gemm_algo(int v) { g_gemm_algo = (v == 10) ? 10 : 0; }
 
 static int g_default_stages() {
   static int v = -1;
-  if (g_stages_override >= 2 && g_stages_override <= 4) return g_stages_override;
+  if (g_stages_override >= 0) return g_stages_override;
   if (v < 0) {
     const char* e = getenv("K22_IGEMM_STAGES");  // 2..4 = LDS-DMA pipeline depth
     v = e ? atoi(e) : 2;

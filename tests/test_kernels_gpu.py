@@ -254,7 +254,7 @@ def _with_gemm8(fn):
     (256, 256, 128, 256, 1), (300, 192, 192, 128, 1), (77, 768, 1024, 128, 1), (1000, 136, 384, 256, 1),
     (288, 384, 1152, 128, 4), (512, 128, 64, 0, 1), (4608, 768, 768, 256, 2), (150, 1536, 1536, 256, 3),
 ])
-@pytest.mark.parametrize("stages", [-1, 2, 5])   # 2: two workgroups per CU (BM = 128); 5: register-staged operands
+@pytest.mark.parametrize("stages", [-1, 2])
 def test_gemm8(dtype, M, N, K, bm, splitk, stages):
     A, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
     bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
