@@ -220,3 +220,42 @@ def test_generate_text2img_bf16_runs_and_is_close():
     lat = (p32.last_latent - pbf.last_latent).abs().max().item()
     print(f"bf16 chain vs fp32 chain: latent max|d| {lat:.3e}; uint8 mean |d| {d.mean():.2f}, max {d.max()}")
     assert np.isfinite(lat) and d.mean() < 12.0
+
+
+def test_generate_img2img_and_mix_images_compose_the_same_pieces():
+    """generate_img2img = MOVQ.encode * scale -> q_sample at the loop's start step -> loop from init_step (kandinsky2_1_model.py:428-483);
+    mix_images = weighted sum of prior / image embeddings -> generate_img (:353-426).  Both must equal the same pieces called by hand
+    with the same injected noise (bit for bit: same engines, same order), and produce an image of the requested size."""
+    pipe = _pipe("text2img")
+    steps, bs, prompt = 6, 1, "a blue bird"
+    g = torch.Generator().manual_seed(11)
+    img = (torch.randn(1, 3, H, W, generator=g) * 0.5).clamp(-1, 1).cuda()
+    qn = torch.randn(1, 4, H // 8, W // 8, generator=g).cuda()
+    nz = torch.randn(steps, 2, 4, H // 8, W // 8, generator=g).cuda()
+    out = pipe.generate_img2img(prompt, img, strength=0.5, num_steps=steps, batch_size=bs, guidance_scale=4.0, h=H, w=W, sampler="p_sampler",
+                                prior_steps=str(PRIOR_STEPS), q_noise=qn, noise_seq=nz, output_type="uint8")
+    lat1, emb = pipe.last_latent.clone(), pipe._last_image_emb.clone()
+    # by hand
+    cfg, diffusion = pipe._diffusion("p_sampler", steps)
+    start = int(diffusion.num_timesteps * (1 - 0.5))
+    lat0 = pipe.image_encoder.encode(img) * pipe.scale
+    x0 = k22.prestep.q_sample(lat0, torch.tensor(diffusion.timestep_map[start - 1]), schedule_name="linear", num_steps=1000, noise=qn)
+    out2 = pipe.generate_img(prompt=prompt, img_prompt=emb, batch_size=bs, guidance_scale=4.0, h=H, w=W, sampler="p_sampler", num_steps=steps,
+                             diffusion=diffusion, noise=x0.repeat(2, 1, 1, 1), init_step=start, noise_seq=nz, output_type="uint8")
+    assert out.shape == (bs, H, W, 3) and torch.equal(lat1, pipe.last_latent) and np.array_equal(out, out2)
+    # fewer steps were run than a full loop: the result differs from a text2img run with the same noise
+    full = pipe.generate_img(prompt=prompt, img_prompt=emb, batch_size=bs, guidance_scale=4.0, h=H, w=W, sampler="p_sampler", num_steps=steps,
+                             diffusion=diffusion, noise=x0.repeat(2, 1, 1, 1), noise_seq=nz, output_type="uint8")
+    assert not np.array_equal(full, out)
+
+    # mix_images: 0.3 * prior("a") + 0.7 * clip_image(img)
+    torch.manual_seed(5)
+    mixed = pipe.mix_images(["a castle", img], [0.3, 0.7], num_steps=4, batch_size=2, guidance_scale=4.0, h=H, w=W, sampler="ddim_sampler",
+                            prior_steps=str(PRIOR_STEPS), output_type="uint8")
+    emb_used = pipe._last_image_emb
+    assert mixed.shape == (2, H, W, 3) and emb_used.shape == (4, 768)
+    want_img_part = 0.7 * pipe.encode_images(img)
+    # rows 0-1 = the mixed embedding repeated, rows 2-3 = the zero-image embedding (kandinsky2_1_model.py:391-403)
+    assert torch.equal(emb_used[0], emb_used[1]) and torch.equal(emb_used[2], emb_used[3])
+    assert torch.allclose(emb_used[2], pipe.create_zero_img_emb(1)[0])
+    assert (emb_used[0] - want_img_part[0]).abs().max().item() > 0      # the prior's part is in there too
