@@ -241,6 +241,12 @@ class Kandinsky2_1HIP:
                      noise_seq: Optional[torch.Tensor] = None, output_type: str = "pil"):
         new_h, new_w = self.get_new_h_w(h, w)
         full_batch_size = batch_size * 2
+        if full_batch_size > 8:
+            # The engine plans CFG batches of at most 8.  A larger batch cannot simply be split here: the reference's dynamic
+            # threshold scales the WHOLE batch by the percentile of its element 0 (gaussian_diffusion.py:288-292), so chunks
+            # would not reproduce one reference call.  Independent calls of <= 4 images (one per GPU stream / rank,
+            # kandinsky2_amd.parallel.shard_range) are the supported way to a large batch.
+            raise ValueError("batch_size must be <= 4 per call (CFG batch <= 8); shard larger batches over calls / ranks")
         model_kwargs = {}
         model_kwargs["full_emb"], model_kwargs["pooled_emb"] = self.encode_text(prompt, batch_size)
         model_kwargs["image_emb"] = img_prompt.to(self.device).float()

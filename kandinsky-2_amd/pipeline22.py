@@ -52,6 +52,8 @@ class KandinskyV22DecoderHIP:
         if dev.type != "cuda":
             raise RuntimeError("KandinskyV22DecoderHIP runs on the GPU only (no CPU fallback)")
         bs = image_embeds.shape[0]
+        if 2 * bs > 8:
+            raise ValueError("at most 4 images per call (CFG batch <= 8); shard larger batches over calls / ranks")
         f = self.movq_scale_factor
         h, w = (height // f ** 2 + (1 if height % f ** 2 else 0)) * f, (width // f ** 2 + (1 if width % f ** 2 else 0)) * f   # downscale_height_and_width
         emb = torch.cat([image_embeds, negative_image_embeds], 0).float().contiguous()
