@@ -775,28 +775,26 @@ __global__ __launch_bounds__(512) void conv3_halo_spec_kernel(const IgemmParams 
       const int bsw = (l31 >> 1) & 7;
       int cur = 0;
       // (s_setprio 3 in the consumers, so that they win issue arbitration against the producer on their SIMD: measured +-1 %)
-      // PIPE: fragments read but not yet multiplied.  (pa, qb) = the last k-step of a tap, multiplied after the next barrier
-      // (zero = a no-op group before the first tap); pb = the weight fragments of k-step 1 in the four-block form
-      Frag<T> pa[MI], pb[NI], qb[NI];
+      Frag<T> pa[MI], pb[NI];   // PIPE: fragments read but not yet multiplied (zero = a no-op group before the first tap)
       if constexpr (PIPE) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) pa[mi] = Frag<T>{};
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) { pb[ni] = Frag<T>{}; qb[ni] = Frag<T>{}; }
+        for (int ni = 0; ni < NI; ++ni) pb[ni] = Frag<T>{};
       }
       // One block of the pipeline = NRD fragment reads (of the NEXT group) + NMF MFMAs (of the group read one block ago), which
       // are independent of each other: one read is scheduled behind every MPR MFMAs (0x008 = MFMA, 0x100 = DS read), so that
       // each ds_read_b128 issues under the 32 cycles the MFMA before it occupies the pipe.
-      constexpr int RPF = sizeof(T) == 2 ? 1 : 2;            // ds_read_b128 per fragment
-      constexpr int NMF = MI * NI * (sizeof(T) == 2 ? 1 : 8);  // MFMAs per block
-#define K22_SP_INTERLEAVE(NREADS)                                                                          \
+      constexpr int NRD = (MI + NI) * (sizeof(T) == 2 ? 1 : 2);
+      constexpr int NMF = MI * NI * (sizeof(T) == 2 ? 1 : 8);
+      constexpr int MPR = NMF / NRD;
+#define K22_SP_INTERLEAVE()                                                                                \
       {                                                                                                    \
-        constexpr int nrd_ = (NREADS), mpr_ = NMF / nrd_ > 0 ? NMF / nrd_ : 1;                             \
-        _Pragma("unroll") for (int i_ = 0; i_ < nrd_; ++i_) {                                              \
-          __builtin_amdgcn_sched_group_barrier(0x008, mpr_, 0);                                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < NRD; ++i_) {                                               \
+          __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);                                             \
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                               \
         }                                                                                                  \
-        if constexpr (NMF - mpr_ * nrd_ > 0) __builtin_amdgcn_sched_group_barrier(0x008, NMF - mpr_ * nrd_, 0); \
+        if constexpr (NMF - MPR * NRD > 0) __builtin_amdgcn_sched_group_barrier(0x008, NMF - MPR * NRD, 0); \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
       }
       for (int s = s0; s < s1; ++s) {
@@ -813,45 +811,19 @@ __global__ __launch_bounds__(512) void conv3_halo_spec_kernel(const IgemmParams 
             arow[mi] = Acur + ar * 128;                                                                    \
             asw[mi] = (ar >> 1) & 7;                                                                       \
           }                                                                                                \
-          if constexpr (PIPE && KSTEPS == 4) {                                                             \
-            /* four blocks; the WEIGHT fragments of the last k-step (qb) are read one block early, so that only halo     \
-               fragments (pa) are still in flight when the wave reaches the next barrier: the producers may refill this  \
-               tap's weight slot right after it (2-slot ring) and no wait is needed - the halo buffer is only reused      \
-               after tap 8. */                                                                                          \
-            Frag<T> ca[MI], cb[NI];                                                                        \
-            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) ld_frag_at(ca[mi], arow[mi], asw[mi], 0, h); \
-            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) ld_frag_at(cb[ni], Bcur + brow[ni], bsw, 0, h); \
-            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                              \
-              _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], qb[ni], pa[mi]);     \
-            K22_SP_INTERLEAVE((MI + NI) * RPF);                                                            \
-            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) ld_frag_at(pa[mi], arow[mi], asw[mi], 1, h); \
-            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) ld_frag_at(pb[ni], Bcur + brow[ni], bsw, 1, h); \
-            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                              \
-              _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], cb[ni], ca[mi]);     \
-            K22_SP_INTERLEAVE((MI + NI) * RPF);                                                            \
-            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) ld_frag_at(ca[mi], arow[mi], asw[mi], 2, h); \
-            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) ld_frag_at(cb[ni], Bcur + brow[ni], bsw, 2, h); \
-            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) ld_frag_at(qb[ni], Bcur + brow[ni], bsw, 3, h); \
-            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                              \
-              _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], pb[ni], pa[mi]);     \
-            K22_SP_INTERLEAVE((MI + 2 * NI) * RPF);                                                        \
-            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) ld_frag_at(pa[mi], arow[mi], asw[mi], 3, h); \
-            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                              \
-              _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], cb[ni], ca[mi]);     \
-            K22_SP_INTERLEAVE(MI * RPF);                                                                   \
-          } else if constexpr (PIPE) {                                                                     \
+          if constexpr (PIPE) {                                                                            \
             Frag<T> ca[MI], cb[NI];                                                                        \
             _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ks += 2) {                                     \
               _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) ld_frag_at(ca[mi], arow[mi], asw[mi], ks, h); \
               _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) ld_frag_at(cb[ni], Bcur + brow[ni], bsw, ks, h); \
               _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                            \
-                _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], qb[ni], pa[mi]);   \
-              K22_SP_INTERLEAVE((MI + NI) * RPF);                                                          \
+                _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], pb[ni], pa[mi]);   \
+              K22_SP_INTERLEAVE();                                                                         \
               _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) ld_frag_at(pa[mi], arow[mi], asw[mi], ks + 1, h); \
-              _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) ld_frag_at(qb[ni], Bcur + brow[ni], bsw, ks + 1, h); \
+              _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) ld_frag_at(pb[ni], Bcur + brow[ni], bsw, ks + 1, h); \
               _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                            \
                 _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], cb[ni], ca[mi]);   \
-              K22_SP_INTERLEAVE((MI + NI) * RPF);                                                          \
+              K22_SP_INTERLEAVE();                                                                         \
             }                                                                                              \
           } else {                                                                                         \
           _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks) {                                          \
@@ -863,12 +835,9 @@ __global__ __launch_bounds__(512) void conv3_halo_spec_kernel(const IgemmParams 
           }                                                                                                \
           }                                                                                                \
           /* Fragment reads may not stay in flight across the next barrier when the producers refill what they read right    \
-             after it: with a 2-deep ring that is THIS tap's weight slot (the four-block pipeline keeps only halo reads in    \
-             flight there and needs no wait), and after tap 8 the halo buffer of the slab before. */                       \
-          if constexpr ((TAP) == 8 || ((NBST == 2) && !(PIPE && KSTEPS == 4))) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-          /* four-block form, 2-slot ring: everything but the MI halo reads of the last block (the youngest: the blocks are    \
-             fenced) has returned - in particular the weight fragments qb, whatever order the scheduler gave block 3 */       \
-          else if constexpr (NBST == 2) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MI * RPF) : "memory");  \
+             after it: with a 2-deep ring that is THIS tap's weight slot, and after tap 8 the halo buffer of the slab before. \
+             (The MFMAs that use them can sink below the barrier - registers only - in both forms.) */                      \
+          if constexpr (NBST == 2 || (TAP) == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        \
           cur = (cur + 1 == NBST) ? 0 : cur + 1;                                                           \
         }
         K22_SP_CTAP(0) K22_SP_CTAP(1) K22_SP_CTAP(2) K22_SP_CTAP(3) K22_SP_CTAP(4) K22_SP_CTAP(5) K22_SP_CTAP(6) K22_SP_CTAP(7) K22_SP_CTAP(8)
@@ -879,7 +848,7 @@ __global__ __launch_bounds__(512) void conv3_halo_spec_kernel(const IgemmParams 
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], qb[ni], pa[mi]);
+          for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], pb[ni], pa[mi]);
       }
     }
   }
