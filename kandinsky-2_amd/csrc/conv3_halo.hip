@@ -640,7 +640,9 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const IgemmParams p) {
 // there is the ONE tap a tile has to land in (2-slot ring: the LDS holds the double-buffered halo), half is contention;
 // where four slots fit (48x48) the waits cost nothing and the contention is the same 12-14 %.  Staging the weight tiles
 // through producer registers (global_load two taps ahead, ds_write_b128 into the 2-slot ring) was built and measured equal
-// to the LDS-DMA form at 96x96 and slower elsewhere; removed.
+// to the LDS-DMA form at 96x96 and slower elsewhere; removed.  So was a four-block form of the consumer pipeline that reads the
+// weight fragments of the last k-step one block early (only halo reads in flight at the barrier, no full read wait with the
+// 2-slot ring): same-box A/B/A/B 1.718-1.740 ms for all three forms on the 96x96 / 48x48 shapes.
 // ================================================================================================================
 template <typename T, int BM, int NBST, bool PIPE = false, int DBG = 0>
 __global__ __launch_bounds__(512) void conv3_halo_spec_kernel(const IgemmParams p) {
