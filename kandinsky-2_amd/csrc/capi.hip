@@ -8,7 +8,6 @@
 #include <string.h>
 
 static thread_local char g_err[512] = "";
-static int g_gn_fused = 0;   // "gn_fused" option: k22_groupnorm finalises + applies in one launch (unit tests of gn_fused_kernel)
 
 int k22_set_error(int code, const char* msg) {
   snprintf(g_err, sizeof(g_err), "%s", msg ? msg : "");
@@ -28,7 +27,6 @@ int k22_set_option(const char* name, int value) {
   if (name && !strcmp(name, "igemm_xcd_remap")) { igemm_set_xcd_remap(value); return K22_OK; }
   if (name && !strcmp(name, "conv_algo")) { igemm_set_conv_algo(value); return K22_OK; }
   if (name && !strcmp(name, "gemm_algo")) { igemm_set_gemm_algo(value); return K22_OK; }
-  if (name && !strcmp(name, "gn_fused")) { g_gn_fused = value ? 1 : 0; return K22_OK; }
   return k22_set_error(K22_EINVAL, "k22_set_option: unknown option");
 }
 const char* k22_last_error(void) { return g_err; }
@@ -196,15 +194,6 @@ int k22_groupnorm(const void* x0, const void* x1, int C0, int C1, int B, int H, 
   sp.x0 = x0; sp.x1 = x1; sp.C0 = C0; sp.C1 = C1; sp.HW = HW; sp.B = B; sp.groups = 32; sp.nsplit = nsplit; sp.partial = partial;
   int rc = launch_gn_stats(sp, dtype, st);
   if (rc) return rc;
-  if (g_gn_fused) {
-    GnFusedParams q = {};
-    GnApplyParams& fa = q.a;
-    fa.x0 = x0; fa.x1 = x1; fa.C0 = C0; fa.C1 = C1; fa.B = B; fa.H = H; fa.W = W; fa.mode = mode; fa.pad = pad; fa.act = act;
-    fa.coeff = nullptr; fa.out = out;
-    q.src[0].st = partial; q.src[0].rpi = nsplit; q.src[0].C = C;    // gn_stats writes the partials of the (virtual) concat as one tensor
-    q.eps = eps; q.gamma = gamma; q.beta = beta; q.film = film; q.film_ld = film_ld;
-    return launch_gn_fused(q, dtype, st);
-  }
   GnCoeffParams cp = {};
   cp.src[0].st = partial; cp.src[0].rpi = nsplit; cp.src[0].C = C; cp.src[1].st = nullptr; cp.src[1].rpi = 0; cp.src[1].C = 0;
   cp.HW = HW; cp.C = C; cp.groups = 32; cp.eps = eps; cp.gamma = gamma; cp.beta = beta;

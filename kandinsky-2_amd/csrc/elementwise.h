@@ -38,22 +38,6 @@ struct GnApply3Params {
   const float* gamma; const float* beta;   // [C]
   const float* film; int64_t film_ld;      // optional [B][film_ld]: scale at +c, shift at +C+c
 };
-// GroupNorm32 (+FiLM, +act, +resample, +zero border) in ONE launch from the producer's per-channel partial sums: a workgroup
-// owns a chunk of one or two whole groups of one image and a block of output positions, reduces just that chunk's partials
-// (rows-per-image x channels-per-group x 2 values: a few hundred loads) while its first activation loads are in flight, and
-// applies.  For the small tensors (<= 48 x 48) a GroupNorm is two ~5 us latency-bound launches (gn_coeff + gn_apply); this is one.
-struct GnFusedParams {
-  GnApplyParams a;                          // a.coeff unused
-  GnSrc src[2];                             // src[1].C == 0 when the input is not a virtual concat
-  float eps;
-  const float* gamma; const float* beta;   // [C]
-  const float* film; int64_t film_ld;      // optional [B][film_ld]: scale at +c, shift at +C+c
-  int gpc;                                  // groups per chunk (set by the launcher)
-  int pos_per_block;                        // output positions per workgroup (set by the launcher)
-};
-bool gn_fused_supported(int C, int dtype);
-int launch_gn_fused(const GnFusedParams& q, int dtype, hipStream_t s);
-
 struct ConvInParams {
   const float* x; const float* img; const float* mask;  // NCHW fp32; img/mask only for Cin == 9
   const float* w; const float* bias;                    // [Cin*3*3][Cout] (pack.py transposes the reference's [Cout][Cin][3][3]), [Cout] fp32

@@ -356,165 +356,6 @@ __global__ __launch_bounds__(256) void gn_apply3_kernel(GnApply3Params q) {
   }
 }
 
-// ---- GroupNorm32 in one launch from producer partial sums (GnFusedParams, elementwise.h) --------------------------------
-// grid (position blocks, chunks, B); 256 threads = VW 16-byte channel vectors x PPB positions per pass.
-// Statistics: the chunk's one or two groups are reduced in fp64 by fixed thread -> item assignment, shuffles and a fixed-order
-// fold of the per-wave sums (deterministic); with two groups threads 0-127 take the first, 128-255 the second.
-template <typename T>
-__global__ __launch_bounds__(256) void gn_fused_kernel(GnFusedParams q) {
-  constexpr int EPV = Vec16<T>::N;
-  typedef decltype(Vec16<T>().raw) raw_t;
-  __shared__ double red[4][2];
-  __shared__ float ms[2][2];
-  const GnApplyParams& p = q.a;
-  const int C = p.C0 + p.C1, cpg = C / 32, gpc = q.gpc, cc = gpc * cpg, VW = cc / EPV, PPB = 256 / VW;
-  const int chunk = blockIdx.y, b = blockIdx.z;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int Ho = p.mode == 1 ? p.H / 2 : (p.mode == 2 ? p.H * 2 : p.H);
-  const int Wo = p.mode == 1 ? p.W / 2 : (p.mode == 2 ? p.W * 2 : p.W);
-  const int pad = p.pad, Hp = Ho + 2 * pad, Wp = Wo + 2 * pad;
-  const int npos = Hp * Wp;
-  const int v = tid % VW, pp = tid / VW;
-  const bool active = pp < PPB;
-  const int c = chunk * cc + v * EPV;               // first channel of this thread's vector
-  const T* src; int cs, ld;
-  if (c < p.C0) { src = reinterpret_cast<const T*>(p.x0); cs = c; ld = p.C0; }
-  else { src = reinterpret_cast<const T*>(p.x1); cs = c - p.C0; ld = p.C1; }
-  const int p0 = blockIdx.x * q.pos_per_block;
-  const int p1 = p0 + q.pos_per_block < npos ? p0 + q.pos_per_block : npos;
-
-  // loads of one output position (0, 1 or 4 input vectors) - independent of the statistics
-  auto fetch = [&](int pos, raw_t (&r)[4], bool& inside) __attribute__((always_inline)) {
-    const int yp = pos / Wp, xp = pos - yp * Wp;
-    const int yo = yp - pad, xo = xp - pad;
-    inside = !(xo < 0 || yo < 0 || xo >= Wo || yo >= Ho);
-    if (!inside) return;
-    if (p.mode == 1) {
-#pragma unroll
-      for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 2; ++dx)
-          r[dy * 2 + dx] = *reinterpret_cast<const raw_t*>(src + ((int64_t)(b * p.H + 2 * yo + dy) * p.W + 2 * xo + dx) * ld + cs);
-    } else {
-      const int yi = p.mode == 2 ? yo >> 1 : yo, xi = p.mode == 2 ? xo >> 1 : xo;
-      r[0] = *reinterpret_cast<const raw_t*>(src + ((int64_t)(b * p.H + yi) * p.W + xi) * ld + cs);
-    }
-  };
-  raw_t first[4];
-  bool first_in = false;
-  const int pos_first = p0 + pp;
-  if (active && pos_first < p1) fetch(pos_first, first, first_in);
-
-  // affine / FiLM operands of this thread's channels
-  float gam[EPV], bet[EPV], fsc[EPV], fsh[EPV];
-#pragma unroll
-  for (int k = 0; k < EPV; k += 4) {
-    const float4 g4 = *reinterpret_cast<const float4*>(q.gamma + c + k);
-    const float4 b4 = *reinterpret_cast<const float4*>(q.beta + c + k);
-    gam[k] = g4.x; gam[k + 1] = g4.y; gam[k + 2] = g4.z; gam[k + 3] = g4.w;
-    bet[k] = b4.x; bet[k + 1] = b4.y; bet[k + 2] = b4.z; bet[k + 3] = b4.w;
-    if (q.film != nullptr) {
-      const float4 s4 = *reinterpret_cast<const float4*>(q.film + (int64_t)b * q.film_ld + c + k);
-      const float4 h4 = *reinterpret_cast<const float4*>(q.film + (int64_t)b * q.film_ld + C + c + k);
-      fsc[k] = s4.x; fsc[k + 1] = s4.y; fsc[k + 2] = s4.z; fsc[k + 3] = s4.w;
-      fsh[k] = h4.x; fsh[k + 1] = h4.y; fsh[k + 2] = h4.z; fsh[k + 3] = h4.w;
-    }
-  }
-
-  // group statistics of the chunk
-  const int tg = gpc == 2 ? (tid >> 7) : 0, tl = gpc == 2 ? (tid & 127) : tid, nth = gpc == 2 ? 128 : 256;
-  const int g = chunk * gpc + tg;
-  double s = 0.0, ss = 0.0;
-  int off = 0;
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const GnSrc sr = q.src[k];
-    if (sr.C > 0) {
-      const int cl = max(g * cpg, off), ch = min((g + 1) * cpg, off + sr.C);
-      const int nc = ch - cl;
-      if (nc > 0) {
-        const float* base = sr.st + ((int64_t)b * sr.rpi * sr.C + (cl - off)) * 2;
-        const int items = sr.rpi * nc;
-        for (int i = tl; i < items; i += nth) {
-          const int r = i / nc, x = i - r * nc;
-          const float2 t2 = *reinterpret_cast<const float2*>(base + ((int64_t)r * sr.C + x) * 2);
-          s += (double)t2.x;
-          ss += (double)t2.y;
-        }
-      }
-    }
-    off += sr.C;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    s += __shfl_xor(s, o, 64);
-    ss += __shfl_xor(ss, o, 64);
-  }
-  if (lane == 0) { red[wave][0] = s; red[wave][1] = ss; }
-  __syncthreads();
-  if (tid == 0 || (gpc == 2 && tid == 128)) {
-    double st, qt;
-    if (gpc == 2) { const int w0 = tid >> 6; st = red[w0][0] + red[w0 + 1][0]; qt = red[w0][1] + red[w0 + 1][1]; }
-    else { st = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]); qt = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]); }
-    const double n = (double)p.H * (double)p.W * (double)cpg;
-    const double mean = st / n;
-    double var = qt / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    ms[tg][0] = (float)mean;
-    ms[tg][1] = (float)(1.0 / sqrt(var + (double)q.eps));
-  }
-  __syncthreads();
-  float A[EPV], Bc[EPV];
-#pragma unroll
-  for (int k = 0; k < EPV; ++k) {
-    const int gi = (c + k) / cpg - chunk * gpc;      // 0 or 1
-    A[k] = ms[gi][1] * gam[k];
-    Bc[k] = bet[k] - ms[gi][0] * A[k];
-    if (q.film != nullptr) {
-      const float psc = 1.f + fsc[k];
-      A[k] *= psc;
-      Bc[k] = Bc[k] * psc + fsh[k];
-    }
-  }
-  if (!active) return;
-  T* outp = reinterpret_cast<T*>(p.out) + (int64_t)b * npos * C + c;
-  for (int pos = pos_first; pos < p1; pos += PPB) {
-    raw_t r[4];
-    bool inside;
-    if (pos == pos_first) {
-      inside = first_in;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) r[u] = first[u];
-    } else {
-      fetch(pos, r, inside);
-    }
-    Vec16<T> o;
-    if (!inside) {
-#pragma unroll
-      for (int k = 0; k < EPV / 2; ++k) o.set2(k, 0.f, 0.f);
-    } else {
-      float rr[EPV];
-      if (p.mode == 1) {
-#pragma unroll
-        for (int k = 0; k < EPV; ++k) {
-          float acc = 0.f;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) { Vec16<T> t; t.raw = r[u]; acc += apply_act(t.get(k) * A[k] + Bc[k], p.act); }
-          rr[k] = acc * 0.25f;
-        }
-      } else {
-        Vec16<T> t;
-        t.raw = r[0];
-#pragma unroll
-        for (int k = 0; k < EPV; ++k) rr[k] = apply_act(t.get(k) * A[k] + Bc[k], p.act);
-      }
-#pragma unroll
-      for (int k = 0; k < EPV / 2; ++k) o.set2(k, rr[2 * k], rr[2 * k + 1]);
-    }
-    *reinterpret_cast<raw_t*>(outp + (int64_t)pos * C) = o.raw;
-  }
-}
-
 // ---- raw 2x resample of the residual branch (x_upd), unpadded NHWC -> unpadded NHWC ------------
 template <typename T>
 __global__ __launch_bounds__(256) void resample_kernel(const void* xin, void* yout, int B, int H, int W, int C, int mode) {
@@ -834,38 +675,6 @@ int launch_gn_apply3(const GnApply3Params& q, int dtype, hipStream_t s) {
     if (pool) hipLaunchKernelGGL((gn_apply3_kernel<float, true>), grid, dim3(256), 0, s, q);
     else hipLaunchKernelGGL((gn_apply3_kernel<float, false>), grid, dim3(256), 0, s, q);
   }
-  K22_CHECK_LAUNCH();
-  return K22_OK;
-}
-bool gn_fused_supported(int C, int dtype) {
-  const int epv = dtype == K22_BF16 ? 8 : 4;
-  if (C % 32) return false;
-  const int cpg = C / 32;
-  const int gpc = (cpg % epv == 0) ? 1 : 2;
-  return (gpc * cpg) % epv == 0 && (gpc * cpg) / epv <= 256;
-}
-int launch_gn_fused(const GnFusedParams& q0, int dtype, hipStream_t s) {
-  GnFusedParams q = q0;
-  const GnApplyParams& p = q.a;
-  const int C = p.C0 + p.C1;
-  const int epv = dtype == K22_BF16 ? 8 : 4;
-  if (!gn_fused_supported(C, dtype) || p.C0 % epv || q.src[0].C + q.src[1].C != C || q.src[0].rpi <= 0 || (q.src[1].C > 0 && q.src[1].rpi <= 0))
-    return k22_set_error(K22_EINVAL, "gn_fused: 32 groups, vector-aligned channels and producer partial sums for every source");
-  const int cpg = C / 32;
-  q.gpc = (cpg % epv == 0) ? 1 : 2;
-  const int vw = q.gpc * cpg / epv, ppb = 256 / vw;
-  const int Ho = p.mode == 1 ? p.H / 2 : (p.mode == 2 ? p.H * 2 : p.H);
-  const int Wo = p.mode == 1 ? p.W / 2 : (p.mode == 2 ? p.W * 2 : p.W);
-  const int npos = (Ho + 2 * p.pad) * (Wo + 2 * p.pad);
-  const int nchunks = 32 / q.gpc;
-  // about four passes per workgroup, but no fewer than ~512 workgroups when the tensor allows it
-  int ppw = ppb * 4;
-  while (ppw > ppb && (int64_t)((npos + ppw - 1) / ppw) * nchunks * p.B < 512) ppw -= ppb;
-  q.pos_per_block = ppw;
-  if (p.B > 65535 || nchunks > 65535) return k22_set_error(K22_EINVAL, "gn_fused: tensor too large");
-  dim3 grid((npos + ppw - 1) / ppw, nchunks, p.B);
-  if (dtype == K22_BF16) hipLaunchKernelGGL(gn_fused_kernel<bf16_t>, grid, dim3(256), 0, s, q);
-  else hipLaunchKernelGGL(gn_fused_kernel<float>, grid, dim3(256), 0, s, q);
   K22_CHECK_LAUNCH();
   return K22_OK;
 }

@@ -77,7 +77,6 @@ struct K22UNet {
   int autotune = 1;
   int fuse_skip = 1;
   int gn_onepass = 0;
-  int gn_fused_maxhw = 48 * 48;   // GroupNorms over inputs of at most this many pixels run as one launch (gn_fused_kernel); 0 = never
   size_t ws_bytes = 0;
   char* ws = nullptr;
   bool cond_set = false;
@@ -159,22 +158,6 @@ struct K22UNet {
         return launch_gn_apply3(q, dt, st);
       }, OP_GN, 0.0, (double)Bn * HW * C * esz + (double)Bn * (Ho + 2 * pad) * (Wo + 2 * pad) * C * esz, 1));
         return;
-    }
-    if (fused && gn_fused_maxhw > 0 && HW <= gn_fused_maxhw && gn_fused_supported(C, dtype) && a.C0 % (dtype == K22_BF16 ? 8 : 4) == 0) {
-      // small tensor: statistics finalisation + apply in ONE launch (gn_fused_kernel) instead of gn_coeff + gn_apply
-      L.push_back(Op([=](hipStream_t st) {
-        GnFusedParams q = {};
-        GnApplyParams& ap = q.a;
-        ap.x0 = ptr(a.s0); ap.x1 = a.s1 ? ptr(a.s1) : nullptr; ap.C0 = a.C0; ap.C1 = a.C1; ap.B = Bn; ap.H = a.H; ap.W = a.W;
-        ap.mode = mode; ap.pad = pad; ap.act = act; ap.coeff = nullptr; ap.out = ptr(dst);
-        q.src[0].st = ptr<float>(a.st0); q.src[0].rpi = a.p0->rpi; q.src[0].C = a.C0;
-        if (a.s1) { q.src[1].st = ptr<float>(a.st1); q.src[1].rpi = a.p1->rpi; q.src[1].C = a.C1; }
-        if (q.src[0].rpi <= 0 || (a.s1 && q.src[1].rpi <= 0)) return k22_set_error(K22_EINVAL, "unet: producer delivered no GroupNorm partial sums");
-        q.eps = 1e-5f; q.gamma = gamma; q.beta = beta;
-        q.film = film_off >= 0 ? ptr<float>(s_film) + film_off : nullptr; q.film_ld = film_total;
-        return launch_gn_fused(q, dt, st);
-      }, OP_GN, 0.0, gn_bytes, 1));
-      return;
     }
     L.push_back(Op([=](hipStream_t st) {
       const void* x0 = ptr(a.s0);
@@ -719,8 +702,6 @@ int k22_unet_create(const K22UNetConfig* cfg, const K22Weight* weights, int n_we
     // re-deriving the coefficients in every thread costs more than the coefficient kernel it removes.  Off by default.
     const char* gf = getenv("K22_GN_ONEPASS");
     u->gn_onepass = gf ? (atoi(gf) != 0) : 0;
-    const char* gm = getenv("K22_GN_FUSED_MAXHW");  // largest input (pixels) whose GroupNorm runs as ONE launch; 0 = always gn_coeff + gn_apply
-    if (gm) u->gn_fused_maxhw = atoi(gm);
     const char* f = getenv("K22_FUSE_SKIP");  // 0 = 1x1 skip connections as separate GEMMs
     u->fuse_skip = f ? (atoi(f) != 0) : 1;
   }

@@ -164,31 +164,6 @@ def test_groupnorm(dtype, C0, C1, H, W, act, mode, pad, film):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("C0,C1,H,W,act,mode,pad,film", [
-    (128, 0, 16, 16, 1, 0, 1, False), (256, 128, 8, 8, 1, 0, 1, False), (384, 0, 12, 12, 1, 0, 1, True), (384, 0, 48, 48, 1, 0, 1, True),
-    (128, 0, 16, 16, 1, 1, 1, False), (128, 0, 8, 8, 1, 2, 1, False), (512, 0, 6, 6, 0, 0, 0, False), (768, 384, 24, 24, 1, 2, 1, True),
-    (1536, 1536, 4, 4, 1, 0, 1, True), (1152, 768, 12, 12, 1, 0, 1, False), (768, 0, 24, 24, 1, 1, 1, True), (1536, 768, 12, 12, 1, 0, 1, True),
-])
-def test_groupnorm_one_launch(dtype, C0, C1, H, W, act, mode, pad, film):
-    """gn_fused_kernel: fold of the producer's partial sums + normalise / FiLM / SiLU / resample / border in ONE launch
-    (what the engine uses for tensors of at most 48x48; `gn_fused` routes k22_groupnorm's second half through it)."""
-    B, C = 2, C0 + C1
-    x0 = rnd(B, C0, H, W, seed=1) * 1.7 + 0.3
-    x1 = (rnd(B, C1, H, W, seed=2) * 0.6 - 0.2) if C1 else None
-    gamma, beta = 1 + 0.1 * rnd(C, seed=3), 0.1 * rnd(C, seed=4)
-    fl = 0.3 * rnd(B, 2 * C + 64, seed=5) if film else None
-    _lib.check(_lib.lib().k22_set_option(b"gn_fused", 1))
-    try:
-        out, ref = hp.groupnorm(x0, gamma, beta, x1, None if fl is None else fl[:, : 2 * C].contiguous(), act, mode, pad, dtype)
-        torch.cuda.synchronize()
-    finally:
-        _lib.check(_lib.lib().k22_set_option(b"gn_fused", 0))
-    close(out, ref, dtype, "groupnorm one launch")
-    if pad:
-        assert (out[:, :, 0] == 0).all() and (out[:, :, -1] == 0).all() and (out[..., 0] == 0).all() and (out[..., -1] == 0).all()
-
-
-@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("B,H,T,S", [(2, 2, 64, 87), (1, 3, 144, 87), (2, 4, 576, 87), (2, 1, 100, 5), (1, 12, 2304, 87)])
 def test_attention(dtype, B, H, T, S):
     C = 64 * H
