@@ -16,6 +16,8 @@ from .unet22 import (UNET_CONFIG_2_2, DDPMSchedulerHIP, UNet2DConditionHIP, init
                      tiny_unet22_config)
 from .pipeline import (CONFIG_2_1, Kandinsky2_1HIP, ReferenceConditioner, SeededConditioner, get_kandinsky2, prepare_image,
                        process_images)
+from .encoders import (CLIP_VITL14, XLMR_LARGE, CLIPModelHIP, HIPConditioner, MultilingualCLIPHIP, TextEncoderHIP, clip_param_shapes,
+                       init_clip_state_dict, init_multiclip_state_dict, multiclip_param_shapes, tiny_clip_config, tiny_xlmr_config)
 from .movq import (MOVQ_CONFIG_2_1, MoVQArch, MoVQDecoderHIP, MoVQEncoderHIP, movq_param_shapes, init_movq_state_dict,
                    movq_encoder_param_shapes, init_movq_encoder_state_dict)
 
@@ -28,5 +30,7 @@ __all__ = [
     "MOVQ_CONFIG_2_1", "MoVQArch", "MoVQDecoderHIP", "MoVQEncoderHIP", "movq_param_shapes", "init_movq_state_dict",
     "movq_encoder_param_shapes", "init_movq_encoder_state_dict", "prestep",
     "UNET_CONFIG_2_2", "DDPMSchedulerHIP", "UNet2DConditionHIP", "init_unet22_state_dict", "make_arch22", "param_shapes22", "tiny_unet22_config",
+    "CLIP_VITL14", "XLMR_LARGE", "CLIPModelHIP", "HIPConditioner", "MultilingualCLIPHIP", "TextEncoderHIP", "clip_param_shapes",
+    "init_clip_state_dict", "init_multiclip_state_dict", "multiclip_param_shapes", "tiny_clip_config", "tiny_xlmr_config",
     "CONFIG_2_1", "Kandinsky2_1HIP", "ReferenceConditioner", "SeededConditioner", "get_kandinsky2", "prepare_image", "process_images",
 ]

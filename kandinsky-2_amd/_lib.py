@@ -40,6 +40,12 @@ class K22PriorConfig(C.Structure):
                 ("xf_final_ln", C.c_int), ("clip_dim", C.c_int), ("clip_xf_width", C.c_int)]
 
 
+class K22EncoderConfig(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("kind", C.c_int), ("width", C.c_int), ("layers", C.c_int), ("heads", C.c_int), ("n_ctx", C.c_int),
+                ("vocab", C.c_int), ("out_dim", C.c_int), ("image_size", C.c_int), ("patch", C.c_int), ("max_pos", C.c_int),
+                ("pad_id", C.c_int), ("ln_eps", C.c_float)]
+
+
 class K22Weight(C.Structure):
     _fields_ = [("name", C.c_char_p), ("ptr", C.c_void_p)]
 
@@ -75,6 +81,11 @@ SIGNATURES = {
     "k22_prior_tuning_report": (_I, [_P, C.c_char_p, _Z]),
     "k22_prior_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "k22_prior_sampler_step": (_I, [_P, _P, _P, _P, _P, _F, _P, _I, _I, _P]),
+    "k22_encoder_create": (_I, [C.POINTER(K22EncoderConfig), C.POINTER(K22Weight), _I, C.POINTER(_P)]),
+    "k22_encoder_destroy": (None, [_P]),
+    "k22_encoder_plan": (_I, [_P, _I, C.POINTER(_Z)]),
+    "k22_encoder_bind": (_I, [_P, _P, _Z]),
+    "k22_encoder_forward": (_I, [_P, _P, _P, _P, _P, _P, _P]),
     "k22_movq_create": (_I, [C.POINTER(K22MoVQConfig), C.POINTER(K22Weight), _I, C.POINTER(_P)]),
     "k22_movq_destroy": (None, [_P]),
     "k22_movq_plan": (_I, [_P, _I, _I, _I, C.POINTER(_Z)]),

@@ -1,0 +1,161 @@
+"""Golden fixtures of the conditioning encoders (build container only: imports /root/reference and the installed transformers).
+
+    python oracle/make_golden_encoders.py [--full]
+
+  enc_multiclip_{tiny,full}.pt   the REFERENCE's MultilingualCLIP (kandinsky2/model/text_encoders.py:108-122, running transformers'
+                                 XLMRobertaModel) on seeded weights / token batches; its state_dict keys -> ref_multiclip_keys.json
+  enc_clip_{tiny,full}.pt        transformers' CLIPTextModelWithProjection / CLIPVisionModelWithProjection (quick_gelu) holding the
+                                 same seeded weights as the OpenAI-keyed state dict (key map below) - see oracle/encoders_ref.py
+                                 for why the OpenAI clip package itself cannot be run here.
+Every case also asserts that the restatement in oracle/encoders_ref.py equals the module that produced the fixture (<= 2e-5 of the
+output scale: different but equivalent operation orders - SDPA attention, fused QKV).  "full" = the production widths / depths
+(xlm-roberta-large with the vocabulary cut to 4096 rows for fixture economy; CLIP ViT-L/14 complete).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import kandinsky2_amd as k22  # noqa: E402
+from oracle import encoders_ref, ref_loader  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def xlmr_tokens(n, n_ctx, vocab, seed):
+    """<s> w ... </s> <pad>...: lengths from the empty prompt (2 tokens) to the full context"""
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.full((n, n_ctx), 1, dtype=torch.long)
+    lens = [n_ctx, 2] + [int(torch.randint(3, n_ctx, (1,), generator=g)) for _ in range(max(0, n - 2))]
+    for b, L in enumerate(lens[:n]):
+        ids[b, 0] = 0
+        ids[b, 1:L - 1] = torch.randint(3, vocab, (L - 2,), generator=g)
+        ids[b, L - 1] = 2
+    return ids, ids.ne(1).long()
+
+
+def clip_tokens(n, n_ctx, vocab, seed):
+    """<sot> w ... <eot> 0...: as CustomizedTokenizer.padded_tokens_and_mask pads (prior.py:396-416); eot is the largest id"""
+    g = torch.Generator().manual_seed(seed)
+    tok = torch.zeros(n, n_ctx, dtype=torch.long)
+    lens = [n_ctx, 2] + [int(torch.randint(3, n_ctx, (1,), generator=g)) for _ in range(max(0, n - 2))]
+    for b, L in enumerate(lens[:n]):
+        tok[b, 0] = vocab - 2
+        tok[b, 1:L - 1] = torch.randint(1, vocab - 2, (L - 2,), generator=g)
+        tok[b, L - 1] = vocab - 1
+    return tok
+
+
+def rel(a, b):
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+
+
+def multiclip_case(name, cfg, in_f, out_f, n, seed_w=0):
+    te = ref_loader.ref("model.text_encoders")
+    sd = k22.init_multiclip_state_dict(cfg, in_f, out_f, seed=seed_w)
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "config.json"), "w") as f:
+            json.dump(dict(cfg, model_type="xlm-roberta", architectures=["XLMRobertaModel"], bos_token_id=0, eos_token_id=2,
+                           hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, initializer_range=0.02,
+                           position_embedding_type="absolute"), f)
+        model = te.MultilingualCLIP(d, in_features=in_f, out_features=out_f).eval()
+    ref_keys = {k: list(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(sd, strict=True)                       # the key / shape table of encoders.py IS the reference's
+    ids, am = xlmr_tokens(n, 77, cfg["vocab_size"], seed=11)
+    with torch.no_grad():
+        pooled, embs = model(input_ids=ids, attention_mask=am)
+    o_pooled, o_embs = encoders_ref.multiclip_forward(sd, cfg, ids, am)
+    print(f"{name}: oracle vs reference MultilingualCLIP: embs {rel(o_embs, embs):.2e} pooled {rel(o_pooled, pooled):.2e} (scale {embs.abs().max():.2f})")
+    assert rel(o_embs, embs) <= 2e-5 and rel(o_pooled, pooled) <= 2e-5
+    torch.save({"meta": {"source": "kandinsky2.model.text_encoders.MultilingualCLIP (reference) on transformers " + __import__("transformers").__version__,
+                         "cfg": cfg, "in_features": in_f, "out_features": out_f, "seed_w": seed_w},
+                "input_ids": ids.int(), "attention_mask": am.int(), "embs": embs.float(), "pooled": pooled.float()},
+               os.path.join(GOLD, name + ".pt"))
+    return ref_keys
+
+
+def _hf_block(out, sd, src, dst, W):
+    q, k, v = sd[src + ".attn.in_proj_weight"].split(W, 0)
+    qb, kb, vb = sd[src + ".attn.in_proj_bias"].split(W, 0)
+    for nm, w, b in (("q", q, qb), ("k", k, kb), ("v", v, vb)):
+        out[f"{dst}.self_attn.{nm}_proj.weight"] = w
+        out[f"{dst}.self_attn.{nm}_proj.bias"] = b
+    for a, b_ in (("attn.out_proj", "self_attn.out_proj"), ("ln_1", "layer_norm1"), ("ln_2", "layer_norm2"), ("mlp.c_fc", "mlp.fc1"),
+                  ("mlp.c_proj", "mlp.fc2")):
+        out[f"{dst}.{b_}.weight"] = sd[f"{src}.{a}.weight"]
+        out[f"{dst}.{b_}.bias"] = sd[f"{src}.{a}.bias"]
+
+
+def clip_to_hf(sd, cfg):
+    """OpenAI clip state_dict -> (CLIPTextModelWithProjection, CLIPVisionModelWithProjection) state dicts
+    (transformers/models/clip/convert_clip_original_pytorch_to_hf.py)."""
+    t, v = {}, {}
+    t["text_model.embeddings.token_embedding.weight"] = sd["token_embedding.weight"]
+    t["text_model.embeddings.position_embedding.weight"] = sd["positional_embedding"]
+    for l in range(cfg["transformer_layers"]):
+        _hf_block(t, sd, f"transformer.resblocks.{l}", f"text_model.encoder.layers.{l}", cfg["transformer_width"])
+    t["text_model.final_layer_norm.weight"], t["text_model.final_layer_norm.bias"] = sd["ln_final.weight"], sd["ln_final.bias"]
+    t["text_projection.weight"] = sd["text_projection"].t().contiguous()
+    v["vision_model.embeddings.class_embedding"] = sd["visual.class_embedding"]
+    v["vision_model.embeddings.patch_embedding.weight"] = sd["visual.conv1.weight"]
+    v["vision_model.embeddings.position_embedding.weight"] = sd["visual.positional_embedding"]
+    v["vision_model.pre_layrnorm.weight"], v["vision_model.pre_layrnorm.bias"] = sd["visual.ln_pre.weight"], sd["visual.ln_pre.bias"]
+    v["vision_model.post_layernorm.weight"], v["vision_model.post_layernorm.bias"] = sd["visual.ln_post.weight"], sd["visual.ln_post.bias"]
+    for l in range(cfg["vision_layers"]):
+        _hf_block(v, sd, f"visual.transformer.resblocks.{l}", f"vision_model.encoder.layers.{l}", cfg["vision_width"])
+    v["visual_projection.weight"] = sd["visual.proj"].t().contiguous()
+    return t, v
+
+
+def clip_case(name, cfg, n, seed_w=0):
+    from transformers import CLIPTextConfig, CLIPTextModelWithProjection, CLIPVisionConfig, CLIPVisionModelWithProjection
+    sd = k22.init_clip_state_dict(cfg, seed=seed_w)
+    ht, hv = clip_to_hf(sd, cfg)
+    tc = CLIPTextConfig(vocab_size=cfg["vocab_size"], hidden_size=cfg["transformer_width"], intermediate_size=4 * cfg["transformer_width"],
+                        projection_dim=cfg["embed_dim"], num_hidden_layers=cfg["transformer_layers"], num_attention_heads=cfg["transformer_heads"],
+                        max_position_embeddings=cfg["context_length"], hidden_act="quick_gelu", layer_norm_eps=1e-5, attention_dropout=0.0,
+                        eos_token_id=2, bos_token_id=0, pad_token_id=1)     # eos_token_id == 2: the pooled row is argmax(input_ids), as OpenAI clip
+    vc = CLIPVisionConfig(hidden_size=cfg["vision_width"], intermediate_size=4 * cfg["vision_width"], projection_dim=cfg["embed_dim"],
+                          num_hidden_layers=cfg["vision_layers"], num_attention_heads=cfg["vision_width"] // 64, image_size=cfg["image_resolution"],
+                          patch_size=cfg["vision_patch_size"], hidden_act="quick_gelu", layer_norm_eps=1e-5, attention_dropout=0.0)
+    tm, vm = CLIPTextModelWithProjection(tc).eval(), CLIPVisionModelWithProjection(vc).eval()
+    for m, hsd in ((tm, ht), (vm, hv)):
+        r = m.load_state_dict(hsd, strict=False)
+        assert not r.unexpected_keys and all("position_ids" in k for k in r.missing_keys), r
+    tok = clip_tokens(n, cfg["context_length"], cfg["vocab_size"], seed=12)
+    g = torch.Generator().manual_seed(13)
+    img = torch.randn(n, 3, cfg["image_resolution"], cfg["image_resolution"], generator=g)
+    with torch.no_grad():
+        to = tm(input_ids=tok)
+        txt_feat, txt_seq = to.text_embeds, to.last_hidden_state
+        img_feat = vm(pixel_values=img).image_embeds
+    o_feat, o_seq = encoders_ref.clip_text_forward(sd, cfg, tok)
+    o_img = encoders_ref.clip_image_forward(sd, cfg, img)
+    print(f"{name}: oracle vs transformers CLIP: txt_seq {rel(o_seq, txt_seq):.2e} txt_feat {rel(o_feat, txt_feat):.2e} img_feat {rel(o_img, img_feat):.2e}")
+    assert rel(o_seq, txt_seq) <= 2e-5 and rel(o_feat, txt_feat) <= 2e-5 and rel(o_img, img_feat) <= 2e-5
+    torch.save({"meta": {"source": "transformers " + __import__("transformers").__version__ + " CLIPTextModelWithProjection / CLIPVisionModelWithProjection "
+                                   "(quick_gelu) with the OpenAI-keyed seeded weights mapped to HF keys", "cfg": cfg, "seed_w": seed_w},
+                "tokens": tok.int(), "image": img, "txt_feat": txt_feat.float(), "txt_feat_seq": txt_seq.float(), "img_feat": img_feat.float()},
+               os.path.join(GOLD, name + ".pt"))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true")
+    a = ap.parse_args()
+    torch.manual_seed(0)
+    keys = multiclip_case("enc_multiclip_tiny", k22.tiny_xlmr_config(), 128, 64, n=4)
+    clip_case("enc_clip_tiny", k22.tiny_clip_config(), n=3)
+    if a.full:
+        full = dict(k22.XLMR_LARGE, vocab_size=4096)
+        keys = multiclip_case("enc_multiclip_full", full, 1024, 768, n=2)
+        keys["transformer.embeddings.word_embeddings.weight"][0] = k22.XLMR_LARGE["vocab_size"]
+        with open(os.path.join(GOLD, "ref_multiclip_keys.json"), "w") as f:
+            json.dump(keys, f, indent=0)
+        clip_case("enc_clip_full", k22.CLIP_VITL14, n=2)
