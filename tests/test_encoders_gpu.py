@@ -2,9 +2,10 @@
 HIPConditioner) against fixtures made from the REFERENCE's MultilingualCLIP (running transformers' XLMRobertaModel) and from
 transformers' CLIP port holding the same weights (oracle/make_golden_encoders.py; oracle/encoders_ref.py explains the pinning).
 
-Tolerances: fp32 engine 2e-4 of the output scale (exact-fp32 MFMA, different summation order); bf16 engine 3e-2 of the scale on the
-tiny towers, 5e-2 on the 24-layer production towers (bf16 weights and GEMM operands, fp32 residual stream and LayerNorm; the
-reference itself runs these towers in fp16 when use_fp16 is set, kandinsky2_1_model.py:60-62).
+Tolerances: fp32 engine 2e-5 of the output scale (exact-fp32 MFMA, different summation order; measured <= 1.9e-6); bf16 engine
+1.5e-2 of the scale on the tiny towers, 2.5e-2 on the 24-layer production towers = 2x the measured distances (bf16 weights and
+GEMM operands, fp32 residual stream and LayerNorm; the reference itself runs these towers in fp16 when use_fp16 is set,
+kandinsky2_1_model.py:60-62).
 """
 import os
 
@@ -15,7 +16,8 @@ import kandinsky2_amd as k22
 
 pytestmark = pytest.mark.gpu
 
-BACKENDS = [(torch.float32, 2e-4, 2e-4), (torch.bfloat16, 3e-2, 5e-2)]
+# measured on MI355X (profiles/r02_parity_lines.txt): fp32 <= 1.9e-6; bf16 tiny 3.4e-3..7.0e-3, production towers 5.5e-3..1.27e-2
+BACKENDS = [(torch.float32, 2e-5, 2e-5), (torch.bfloat16, 1.5e-2, 2.5e-2)]
 
 
 def _fx(golden_dir, name):
@@ -72,7 +74,7 @@ def test_more_than_eight_rows_run_in_chunks(golden_dir):
     m = m.to("cuda")
     tok = fx["tokens"].repeat(4, 1)[:11]
     feat, seq = m.encode_text_with_sequence(tok.cuda())
-    assert feat.shape[0] == 11 and _rel(feat, fx["txt_feat"].repeat(4, 1)[:11]) <= 2e-4 and _rel(seq, fx["txt_feat_seq"].repeat(4, 1, 1)[:11]) <= 2e-4
+    assert feat.shape[0] == 11 and _rel(feat, fx["txt_feat"].repeat(4, 1)[:11]) <= 2e-5 and _rel(seq, fx["txt_feat_seq"].repeat(4, 1, 1)[:11]) <= 2e-5
 
 
 class _Tok1:
@@ -109,9 +111,76 @@ def test_hip_conditioner_calls(golden_dir):
     clip.load_state_dict(k22.init_clip_state_dict(cfgc, seed=fxc["meta"]["seed_w"]))
     cond = k22.HIPConditioner(te, _Tok1(fxm["input_ids"], fxm["attention_mask"]), _Tok2(fxc["tokens"]), clip.to("cuda"))
     full, pooled = cond.encode_text("a cat", 2, "cuda")
-    assert full.shape == (4, 77, 128) and _rel(full[0:1], fxm["embs"][0:1]) <= 2e-4 and _rel(full[3:4], fxm["embs"][1:2]) <= 2e-4
-    assert _rel(pooled[1:2], fxm["pooled"][0:1]) <= 2e-4
+    assert full.shape == (4, 77, 128) and _rel(full[0:1], fxm["embs"][0:1]) <= 2e-5 and _rel(full[3:4], fxm["embs"][1:2]) <= 2e-5
+    assert _rel(pooled[1:2], fxm["pooled"][0:1]) <= 2e-5
     feat, seq, mask = cond.clip_text(["a cat"], "", "cuda")
-    assert feat.shape == (2, 64) and mask.shape == (2, 77) and _rel(feat, fxc["txt_feat"][:2]) <= 2e-4 and _rel(seq, fxc["txt_feat_seq"][:2]) <= 2e-4
+    assert feat.shape == (2, 64) and mask.shape == (2, 77) and _rel(feat, fxc["txt_feat"][:2]) <= 2e-5 and _rel(seq, fxc["txt_feat_seq"][:2]) <= 2e-5
     z = cond.zero_image_emb("cuda")
     assert z.shape == (1, 64) and torch.isfinite(z).all()
+
+
+class _OracleConditioner:
+    """the same conditioner interface on the CPU restatements (oracle/encoders_ref.py) - the checker of the end-to-end test"""
+
+    def __init__(self, xcfg, xsd, ccfg, csd, tok1, tok2):
+        self.xcfg, self.xsd, self.ccfg, self.csd, self.tok1, self.tok2 = xcfg, xsd, ccfg, csd, tok1, tok2
+
+    def encode_text(self, prompt, batch_size, device):
+        from oracle import encoders_ref
+        enc = self.tok1([prompt] * batch_size + [""] * batch_size, max_length=77, padding="max_length", return_tensors="pt")
+        pooled, embs = encoders_ref.multiclip_forward(self.xsd, self.xcfg, enc["input_ids"], enc["attention_mask"])
+        return embs.to(device), pooled.to(device)
+
+    def clip_text(self, prompts, negative_prompt, device):
+        from oracle import encoders_ref
+        tok, mask = self.tok2.padded_tokens_and_mask(list(prompts), 77)
+        ct, cm = self.tok2.padded_tokens_and_mask([negative_prompt], 77)
+        tok, mask = torch.cat([tok, ct.expand(tok.shape[0], -1)], 0), torch.cat([mask, cm.expand(tok.shape[0], -1)], 0)
+        feat, seq = encoders_ref.clip_text_forward(self.csd, self.ccfg, tok)
+        return feat.to(device), seq.to(device), mask.to(device)
+
+    def zero_image_emb(self, device):
+        from oracle import encoders_ref
+        r = self.ccfg["image_resolution"]
+        return encoders_ref.clip_image_forward(self.csd, self.ccfg, torch.zeros(1, 3, r, r)).to(device)
+
+
+def test_prompt_to_image_with_hip_towers_matches_oracle_towers(golden_dir):
+    """tokens -> XLM-R / CLIP towers -> prior -> CFG denoise loop -> MoVQ -> uint8 with NO PyTorch model on the way
+    (Kandinsky2_1HIP + HIPConditioner, fp32 engines), against the same pipeline fed by the CPU oracle towers.  Towers: production
+    widths (1024 / 768, what the prior and the UNet consume) x 2 layers; 1/3-width UNet, 512x4 prior, full MoVQ, 128x128 px."""
+    import copy
+    import numpy as np
+    fxm, fxc = _fx(golden_dir, "enc_multiclip_tiny"), _fx(golden_dir, "enc_clip_tiny")
+    xcfg = dict(k22.XLMR_LARGE, vocab_size=1000, num_hidden_layers=2)
+    ccfg = dict(k22.CLIP_VITL14, vocab_size=1000, transformer_layers=2, vision_layers=2, vision_width=128, image_resolution=56)
+    xsd, csd = k22.init_multiclip_state_dict(xcfg, seed=3), k22.init_clip_state_dict(ccfg, seed=4)
+    tok1, tok2 = _Tok1(fxm["input_ids"], fxm["attention_mask"]), _Tok2(fxc["tokens"])
+    te = k22.TextEncoderHIP(xlmr_config=xcfg, state_dict=xsd, backend_dtype=torch.float32).to("cuda")
+    clip = k22.CLIPModelHIP(ccfg, backend_dtype=torch.float32)
+    clip.load_state_dict(csd)
+    cfg = copy.deepcopy(k22.CONFIG_2_1)
+    cfg["model_config"] = k22.tiny_model_config()
+    hp = k22.tiny_prior_hparams()
+    cfg["prior"]["params"]["model"]["hparams"] = hp
+    g = torch.Generator().manual_seed(17)
+    cfg["prior"]["clip_mean_std_path"] = (torch.randn(768, generator=g) * 0.1, torch.rand(768, generator=g) + 0.5)
+    marc = k22.MoVQArch(k22.MOVQ_CONFIG_2_1["ddconfig"])
+    cfg["image_enc_params"]["ckpt_path"] = dict(k22.init_movq_state_dict(marc, seed=0))
+    unet_sd = k22.init_unet_state_dict(k22.make_arch(cfg["model_config"]), seed=0)
+    prior_sd = k22.init_prior_state_dict(hp, seed=0)
+    bs, steps, psteps, HW = 2, 5, 3, 128
+    x_T = torch.randn(2 * bs, 4, HW // 8, HW // 8, generator=g).cuda()
+    nz = torch.randn(steps, 2 * bs, 4, HW // 8, HW // 8, generator=g).cuda()
+    p_xT, p_nz = torch.randn(2 * bs, 768, generator=g).cuda(), torch.randn(psteps, 2 * bs, 768, generator=g).cuda()
+    out, lat = [], []
+    for cond in (k22.HIPConditioner(te, tok1, tok2, clip.to("cuda")), _OracleConditioner(xcfg, xsd, ccfg, csd, tok1, tok2)):
+        pipe = k22.Kandinsky2_1HIP(cfg, unet_sd, prior_sd, "cuda", task_type="text2img", conditioner=cond, backend_dtype=torch.float32)
+        out.append(pipe.generate_text2img("a red cat", num_steps=steps, batch_size=bs, guidance_scale=4, h=HW, w=HW, sampler="p_sampler",
+                                          prior_cf_scale=4, prior_steps=str(psteps), noise=x_T, noise_seq=nz, prior_noise=p_xT,
+                                          prior_noise_seq=p_nz, output_type="uint8"))
+        lat.append(pipe.last_latent.cpu())
+    e = (lat[0] - lat[1]).abs().max().item()
+    d = np.abs(out[0].astype(np.int32) - out[1].astype(np.int32))
+    print(f"prompt -> image, HIP towers vs oracle towers: final latent max|d| {e:.3e} (scale {lat[1].abs().max().item():.2f}), uint8 max diff {d.max()}")
+    assert out[0].shape == (bs, HW, HW, 3) and e <= 1e-3 and d.max() <= 1
