@@ -152,6 +152,12 @@ struct K22Encoder {
   size_t ws_bytes = 0;
   char* ws = nullptr;
   std::string err;
+  hipGraphExec_t graph_exec = nullptr;   // the 150-300 launches of one tower pass, replayed as one graph
+  hipStream_t cap_stream = nullptr;
+  ~K22Encoder() {
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    if (cap_stream) (void)hipStreamDestroy(cap_stream);
+  }
   ESlot *s_tok, *s_valid, *s_img, *s_patch, *s_pout, *s_inp, *s_ln, *s_qkv, *s_att, *s_fc, *s_fc32, *s_seq, *s_pool_in, *s_pooled, *s_splitk,
       *s_kall, *s_vtall;
 
@@ -202,6 +208,7 @@ struct K22Encoder {
   int plan(int nB) {
     B = nB;
     slots.clear(); ops.clear(); err.clear(); ws = nullptr;
+    if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
     const int D = cfg.width, n = cfg.n_ctx, M = B * n, heads = cfg.heads, od = cfg.out_dim, kind = cfg.kind;
     if (B < 1 || B > 8) return k22_set_error(K22_EINVAL, "encoder: 1..8 sequences / images per call");
     if (D % 64 || D / heads != 64 || D > 2048) return k22_set_error(K22_EINVAL, "encoder: 64 channels per head, width <= 2048");
@@ -364,6 +371,7 @@ int k22_encoder_bind(K22Encoder* m, void* workspace, size_t workspace_bytes) {
   if (workspace_bytes < m->ws_bytes) return k22_set_error(K22_ENOMEM, "encoder_bind: workspace too small");
   if ((uintptr_t)workspace % 256) return k22_set_error(K22_EINVAL, "encoder_bind: workspace must be 256-byte aligned");
   m->ws = reinterpret_cast<char*>(workspace);
+  if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
   return K22_OK;
 }
 
@@ -385,7 +393,27 @@ int k22_encoder_forward(K22Encoder* m, const int* tokens, const float* key_valid
   if (vision) { K22_CPY(m->ptr(m->s_img), image, (size_t)m->B * 3 * c.image_size * c.image_size * 4); }
   else { K22_CPY(m->ptr(m->s_tok), tokens, M * 4); }
   if (xlmr) { K22_CPY(m->ptr(m->s_valid), key_valid, M * 4); }
-  for (auto& op : m->ops) { int rc = op(st); if (rc) return rc; }
+  if (!m->graph_exec) {
+    // first pass on this plan: run eagerly once (function attributes, code load), then capture the launch list
+    for (auto& op : m->ops) { int rc = op(st); if (rc) return rc; }
+    if (!m->cap_stream) {
+      e = hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking);
+      if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+    }
+    hipGraph_t g = nullptr;
+    e = hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+    int rc = K22_OK;
+    for (auto& op : m->ops) { rc = op(m->cap_stream); if (rc) break; }
+    e = hipStreamEndCapture(m->cap_stream, &g);
+    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+    e = hipGraphInstantiate(&m->graph_exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) { m->graph_exec = nullptr; return k22_set_error_hip(e, __FILE__, __LINE__); }
+  }
+  e = hipGraphLaunch(m->graph_exec, st);
+  if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
   if (seq_out) { K22_CPY(seq_out, m->ptr(m->s_seq), M * c.width * 4); }
   K22_CPY(pooled_out, m->ptr(m->s_pooled), (size_t)m->B * c.out_dim * 4);
 #undef K22_CPY
