@@ -348,6 +348,15 @@ int k22_encoder_bind(K22Encoder* m, void* workspace, size_t workspace_bytes);
 int k22_encoder_forward(K22Encoder* m, const int* tokens, const float* key_valid, const float* image, float* seq_out, float* pooled_out,
                         void* stream);
 
+/* ---- img2img / inpainting latent arithmetic ----------------------------------------------------
+ * out = mask * (sa*init + sb*noise) + (1 - mask) * x   [N][C][HW] fp32; mask [N][1][HW] (1 = keep the known region).
+ * mask == NULL (x ignored): out = sa*init + sb*noise = DDPMScheduler.add_noise / q_sample (kandinsky2/utils.py:43-54) with
+ * sa = sqrt(alphas_cumprod[t]), sb = sqrt(1 - alphas_cumprod[t]); noise == NULL: the un-noised init.  With a mask it is the
+ * per-step re-imposition of the known region in the Kandinsky 2.2 inpainting pipeline (kandinsky2/kandinsky2_2_model.py:150-173 ->
+ * diffusers KandinskyV22InpaintPipeline).  broadcast_first != 0: init / noise / mask are those of image 0 for every n. */
+int k22_blend_noised(const float* x, const float* init, const float* noise, const float* mask, float sa, float sb, float* out,
+                     int N, int C, int HW, int broadcast_first, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,6 +95,7 @@ SIGNATURES = {
     "k22_movq_encode": (_I, [_P, _P, _P, _P]),
     "k22_movq_num_ops": (_I, [_P]),
     "k22_ddim_step": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _I, _I, _P]),
+    "k22_blend_noised": (_I, [_P, _P, _P, _P, _F, _F, _P, _I, _I, _I, _I, _P]),
     "k22_prepare_mask": (_I, [_P, _P, _I, _I, _I, _P]),
     "k22_plms_step": (_I, [_P, _P, _P, _P, _P, _I, _P, _F, _I, _P, _P, _P, _I, _I, _P]),
     "k22_sampler_scratch_bytes": (_Z, [_I, _I]),

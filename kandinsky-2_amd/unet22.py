@@ -338,6 +338,20 @@ class DDPMSchedulerHIP:
         return sample
 
     @torch.no_grad()
+    def add_noise(self, original_samples, noise, timesteps):
+        """DDPMScheduler.add_noise: sqrt(alphas_cumprod[t]) * x + sqrt(1 - alphas_cumprod[t]) * noise (one timestep per call)."""
+        t = int(torch.as_tensor(timesteps).reshape(-1)[0])
+        x, nz = original_samples.detach().float().contiguous(), noise.detach().float().contiguous()
+        if x.shape != nz.shape or x.dim() != 4:
+            raise ValueError("add_noise: samples and noise must both be [N, C, h, w]")
+        out = torch.empty_like(x)
+        N, Cc, H, W = x.shape
+        a = float(self.alphas_cumprod[t])
+        _lib.check(_lib.lib().k22_blend_noised(None, x.data_ptr(), nz.data_ptr(), None, math.sqrt(a), math.sqrt(1.0 - a), out.data_ptr(),
+                                               N, Cc, H * W, 0, _lib.current_stream()))
+        return out
+
+    @torch.no_grad()
     def step(self, model_output, timestep, sample, generator=None, noise: Optional[torch.Tensor] = None, return_dict: bool = True,
              guidance_scale: Optional[float] = None):
         """model_output [N,8,h,w] = (eps | learned variance) already guided, sample [N,4,h,w] -> prev_sample.  With

@@ -184,3 +184,56 @@ def decoder_loop(unet_fn, latents, image_embeds, negative_image_embeds, num_step
         eps = eps_u + guidance_scale * (eps_c - eps_u)
         latents = sch.step(torch.cat([eps, var_c], dim=1), t, latents, noise_seq[k])
     return latents
+
+
+def add_noise(sch, x, noise, t):
+    """DDPMScheduler.add_noise at one timestep"""
+    a = sch.alphas_cumprod[int(t)]
+    return a ** 0.5 * x + (1 - a) ** 0.5 * noise
+
+
+def _cfg_step(sch, unet_fn, latents, emb, t, guidance_scale, nz, extra=None):
+    inp = torch.cat([latents] * 2)
+    if extra is not None:
+        inp = torch.cat([inp, extra], dim=1)
+    out = unet_fn(inp, t, emb, None)
+    eps, var = out.split(latents.shape[1], dim=1)
+    eps_u, eps_c = eps.chunk(2)
+    _, var_c = var.chunk(2)
+    eps = eps_u + guidance_scale * (eps_c - eps_u)
+    return sch.step(torch.cat([eps, var_c], dim=1), t, latents, nz)
+
+
+@torch.no_grad()
+def img2img_loop(unet_fn, image_latents, image_embeds, negative_image_embeds, num_steps, strength, guidance_scale, noise, noise_seq):
+    """KandinskyV22Img2ImgPipeline.__call__ (PARITY UNPINNED, recalled): get_timesteps(strength), add_noise(movq latents, noise,
+    timesteps[0]), then the text2img loop over the retained timesteps."""
+    sch = RefDDPMScheduler(num_steps)
+    t_start = max(num_steps - min(int(num_steps * strength), num_steps), 0)
+    ts = sch.timesteps[t_start:]
+    emb = torch.cat([negative_image_embeds, image_embeds], 0)
+    latents = add_noise(sch, image_latents, noise, ts[0])
+    for k, t in enumerate(ts):
+        latents = _cfg_step(sch, unet_fn, latents, emb, t, guidance_scale, noise_seq[k])
+    return latents
+
+
+@torch.no_grad()
+def inpaint_loop(unet_fn, image_latents, mask, latents, image_embeds, negative_image_embeds, num_steps, guidance_scale, noise_seq):
+    """KandinskyV22InpaintPipeline.__call__ denoising loop (PARITY UNPINNED, recalled).  image_latents [1,4,h,w] = movq.encode(image);
+    mask [1,1,h,w] after nearest resize + prepare_mask (1 = keep); latents [bs,4,h,w] = the initial noise, also the noise the known
+    region is re-noised with."""
+    sch = RefDDPMScheduler(num_steps)
+    bs = latents.shape[0]
+    emb = torch.cat([negative_image_embeds, image_embeds], 0)
+    masked = image_latents * mask
+    extra = torch.cat([masked, mask], 1).repeat(2 * bs, 1, 1, 1)
+    noise = latents.clone()
+    ts = sch.timesteps
+    for i, t in enumerate(ts):
+        latents = _cfg_step(sch, unet_fn, latents, emb, t, guidance_scale, noise_seq[i], extra)
+        proper = image_latents[:1]
+        if i < len(ts) - 1:
+            proper = add_noise(sch, proper, noise, ts[i + 1])
+        latents = mask[:1] * proper + (1 - mask[:1]) * latents
+    return mask[:1] * image_latents[:1] + (1 - mask[:1]) * latents

@@ -120,3 +120,121 @@ def test_unet22_full_width_forward_vs_oracle_fp32():
     err = (out - ref).abs().max().item()
     print(f"unet22 full width ({n_params / 1e9:.3f} B params) fp32: max|d| {err:.3e} = {err / scale:.3e} of scale {scale:.3f} (oracle unpinned)")
     assert err <= 2e-4 * scale
+
+
+def _movq_pair(backend=torch.float32):
+    marc = k22.MoVQArch(k22.MOVQ_CONFIG_2_1["ddconfig"])
+    sd = dict(k22.init_movq_state_dict(marc, seed=0))
+    sd.update(k22.init_movq_encoder_state_dict(marc, seed=0))
+    dec, enc = k22.MoVQDecoderHIP(backend_dtype=backend), k22.MoVQEncoderHIP(backend_dtype=backend)
+    dec.load_state_dict(sd, strict=True)
+    enc.load_state_dict(sd, strict=True)
+    return sd, dec.to("cuda"), enc.to("cuda")
+
+
+def test_scheduler_add_noise_and_blend_kernel():
+    """k22_blend_noised: DDPMScheduler.add_noise and the inpainting re-imposition, against the torch expressions"""
+    from kandinsky2_amd import _lib
+    g = torch.Generator().manual_seed(9)
+    sch = k22.DDPMSchedulerHIP().set_timesteps(10)
+    ref = unet22_ref.RefDDPMScheduler(10)
+    x, nz = torch.randn(3, 4, 12, 20, generator=g), torch.randn(3, 4, 12, 20, generator=g)
+    for t in (900, 400, 0):
+        got = sch.add_noise(x.cuda(), nz.cuda(), torch.tensor([t])).cpu()
+        assert (got - unet22_ref.add_noise(ref, x, nz, t)).abs().max().item() <= 1e-6
+    m = (torch.rand(1, 1, 12, 20, generator=g) > 0.4).float()
+    cur = torch.randn(1, 4, 12, 20, generator=g)
+    out = torch.empty(1, 4, 12, 20, device="cuda")
+    a = float(ref.alphas_cumprod[300])
+    xc, ic, nc, mc = cur.cuda(), x[:1].contiguous().cuda(), nz[:1].contiguous().cuda(), m.cuda()
+    _lib.check(_lib.lib().k22_blend_noised(xc.data_ptr(), ic.data_ptr(), nc.data_ptr(), mc.data_ptr(), a ** 0.5, (1 - a) ** 0.5, out.data_ptr(),
+                                           1, 4, 240, 0, _lib.current_stream()))
+    want = m * (a ** 0.5 * x[:1] + (1 - a) ** 0.5 * nz[:1]) + (1 - m) * cur
+    assert (out.cpu() - want).abs().max().item() <= 1e-6
+    with pytest.raises(RuntimeError):
+        _lib.check(_lib.lib().k22_blend_noised(None, ic.data_ptr(), nc.data_ptr(), mc.data_ptr(), 1.0, 0.0, out.data_ptr(), 1, 4, 240, 0, _lib.current_stream()))
+
+
+def test_img2img_decoder_vs_oracle_fp32():
+    """KandinskyV22Img2ImgPipeline path: movq.encode -> add_noise -> loop over timesteps[t_start:] (oracle unpinned)."""
+    cfg, sd, m = _unet(False, torch.float32)
+    msd, dec, enc = _movq_pair()
+    bs, h, w, steps, strength, gs = 2, 16, 16, 10, 0.5, 4.0
+    g = torch.Generator().manual_seed(10)
+    img = (torch.randn(1, 3, 8 * h, 8 * w, generator=g) * 0.5).clamp(-1, 1)
+    pos, neg = torch.randn(bs, 1280, generator=g), torch.randn(bs, 1280, generator=g)
+    nz0, nzs = torch.randn(bs, 4, h, w, generator=g), torch.randn(steps, bs, 4, h, w, generator=g)
+    lat0 = enc.encode(img.cuda()).cpu().repeat(bs, 1, 1, 1)          # the MoVQ encoder has its own parity tests (test_movq_gpu.py)
+    want = unet22_ref.img2img_loop(lambda xx, t, e, hh: unet22_ref.unet22_forward(sd, cfg, xx, t, e, hh), lat0, pos, neg, steps, strength, gs, nz0, nzs)
+    pipe = k22.pipeline22.KandinskyV22Img2ImgDecoderHIP(m, dec, enc)
+    got = pipe(pos.cuda(), neg.cuda(), image=img.cuda(), height=8 * h, width=8 * w, num_inference_steps=steps, guidance_scale=gs, strength=strength,
+               noise=nz0.cuda(), noise_seq=nzs.cuda(), output_type="latent").cpu()
+    err = (got - want).abs().max().item()
+    print(f"2.2 img2img decoder fp32: final latent max|d| {err:.3e} (scale {want.abs().max().item():.2f}, oracle unpinned)")
+    assert err <= 1e-3
+    u8 = pipe(pos.cuda(), neg.cuda(), image=img.cuda(), height=8 * h, width=8 * w, num_inference_steps=4, strength=0.5, output_type="uint8")
+    assert u8.shape == (bs, 8 * h, 8 * w, 3)
+    with pytest.raises(ValueError):
+        pipe(pos.cuda(), neg.cuda(), image=img.cuda(), height=8 * h, width=8 * w, num_inference_steps=4, strength=0.1, output_type="latent")
+
+
+def test_inpaint_decoder_vs_oracle_fp32():
+    """KandinskyV22InpaintPipeline path on the 9-channel UNet: [latents | masked image latents | mask] input, per-step re-imposition of
+    the known region at the next noise level (oracle unpinned)."""
+    from oracle import prestep_ref
+    import torch.nn.functional as F
+    cfgu = k22.tiny_unet22_config()
+    arch = k22.make_arch22(cfgu, inpainting=True)
+    sd = k22.init_unet22_state_dict(arch, seed=0)
+    m = k22.UNet2DConditionHIP(arch, backend_dtype=torch.float32)
+    m.load_state_dict(sd)
+    m = m.to("cuda").eval()
+    msd, dec, enc = _movq_pair()
+    bs, h, w, steps, gs = 2, 16, 16, 5, 4.0
+    g = torch.Generator().manual_seed(11)
+    img = (torch.randn(1, 3, 8 * h, 8 * w, generator=g) * 0.5).clamp(-1, 1)
+    mask_px = torch.ones(8 * h, 8 * w)
+    mask_px[24:90, 40:100] = 0.0
+    pos, neg = torch.randn(bs, 1280, generator=g), torch.randn(bs, 1280, generator=g)
+    x_T, nzs = torch.randn(bs, 4, h, w, generator=g), torch.randn(steps, bs, 4, h, w, generator=g)
+    lat0 = enc.encode(img.cuda()).cpu()
+    mlat = prestep_ref.prepare_mask(F.interpolate(mask_px[None, None], (h, w), mode="nearest"))
+    cfg9 = dict(cfgu, in_channels=9)
+    want = unet22_ref.inpaint_loop(lambda xx, t, e, hh: unet22_ref.unet22_forward(sd, cfg9, xx, t, e, hh), lat0, mlat, x_T, pos, neg, steps, gs, nzs)
+    pipe = k22.pipeline22.KandinskyV22InpaintDecoderHIP(m, dec, enc)
+    got = pipe(pos.cuda(), neg.cuda(), image=img.cuda(), mask_image=mask_px.numpy(), height=8 * h, width=8 * w, num_inference_steps=steps,
+               guidance_scale=gs, latents=x_T.cuda(), noise_seq=nzs.cuda(), output_type="latent").cpu()
+    err = (got - want).abs().max().item()
+    keep = mlat[0, 0] == 1
+    print(f"2.2 inpainting decoder fp32: final latent max|d| {err:.3e} (scale {want.abs().max().item():.2f}, oracle unpinned)")
+    assert err <= 1e-3
+    assert (got[:, :, keep] - lat0[:, :, keep]).abs().max().item() <= 1e-5          # the known region ends un-noised
+    inv = pipe(pos.cuda(), neg.cuda(), image=img.cuda(), mask_image=1.0 - mask_px.numpy(), repaint_white=True, height=8 * h, width=8 * w,
+               num_inference_steps=steps, guidance_scale=gs, latents=x_T.cuda(), noise_seq=nzs.cuda(), output_type="latent").cpu()
+    assert torch.equal(inv, got)
+
+
+def test_kandinsky2_2_wrapper_task_types():
+    """Kandinsky2_2HIP: the reference's (task_type -> pipeline, UNet) table and its generate_* / mix_images signatures."""
+    msd, _, _ = _movq_pair()
+    H = 128
+    img = torch.zeros(1, 3, H, H).cuda()
+    for task, inp in (("text2img", False), ("img2img", False), ("inpainting", True)):
+        arch = k22.make_arch22(k22.tiny_unet22_config(), inpainting=inp)
+        mdl = k22.pipeline22.Kandinsky2_2HIP("cuda", task, unet_state_dict=k22.init_unet22_state_dict(arch, seed=0), movq_state_dict=msd,
+                                             unet_config=k22.tiny_unet22_config(), backend_dtype=torch.float32)
+        if task == "text2img":
+            out = mdl.generate_text2img("a cat", batch_size=2, decoder_steps=3, h=H, w=H, output_type="uint8")
+            mix = mdl.mix_images(["a cat", img], [0.3, 0.7], batch_size=1, decoder_steps=2, h=H, w=H, output_type="uint8")
+            assert mix.shape == (1, H, H, 3)
+            with pytest.raises(ValueError):
+                mdl.generate_img2img("a cat", img)
+        elif task == "img2img":
+            out = mdl.generate_img2img("a cat", img, strength=0.5, batch_size=2, decoder_steps=4, h=H, w=H, output_type="uint8")
+        else:
+            mk = torch.ones(H, H).numpy()
+            mk[:, :64] = 0
+            out = mdl.generate_inpainting("a cat", img, mk, batch_size=2, decoder_steps=3, h=H, w=H, output_type="uint8")
+        assert out.shape == (2, H, H, 3) and out.dtype.name == "uint8"
+    with pytest.raises(ValueError):
+        k22.pipeline22.Kandinsky2_2HIP("cuda", "superres", unet_state_dict={}, movq_state_dict={})
