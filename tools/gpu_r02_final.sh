@@ -24,6 +24,13 @@ for cfg in "--head 2.2" "--controlnet --bs 2" "--inpaint --bs 4" "--size 1024 --
 done
 timeout 300 python tools/bench_prior.py 2>&1 | grep -E "prior forward|steady" | head -3
 timeout 300 python tools/bench_movq.py 2>&1 | tail -3
+timeout 300 python tools/bench_encoders.py 2>&1 | tail -1 | tee gpurun_out/bench_encoders_$TAG.json
+EOUT=$PWD/gpurun_out/rocprof_${TAG}_enc; rm -rf $EOUT
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $EOUT -- python $OLDPWD/tools/bench_encoders.py --reps 10 > /dev/null 2>&1 )
+EF=$(find $EOUT -name "*kernel_stats.csv" | head -1)
+[ -n "$EF" ] && python tools/rocprof_summary.py "$EF" "python tools/bench_encoders.py --reps 10" > gpurun_out/rocprof_${TAG}_encoders_summary.txt
+find $EOUT -name "*kernel_trace.csv" -size +20M -delete
+head -12 gpurun_out/rocprof_${TAG}_encoders_summary.txt | cut -c1-150
 bash tools/gpu_profile.sh $TAG 10 > gpurun_out/profile_$TAG.log 2>&1
 head -24 gpurun_out/rocprof_${TAG}_summary.txt | cut -c1-150
 bash tools/gpu_pmc.sh $TAG > gpurun_out/pmc_$TAG.log 2>&1
