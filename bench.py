@@ -66,9 +66,13 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # launched by torch.distributed.run (it exports RANK / WORLD_SIZE): take the RCCL path even for one rank, so that a 1-GPU
+    # box exercises the same init / broadcast / barrier / max-over-ranks code the multi-GPU runs depend on
+    dist_on = world > 1 or ("RANK" in os.environ and "WORLD_SIZE" in os.environ)
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     if a.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
@@ -100,7 +104,7 @@ def main():
     else:
         m = Model(arch, backend_dtype=tdt, use_graph=not a.no_graph, meta_params=True)
         arena = None
-    if world > 1:
+    if dist_on:
         arena = broadcast_arena(arena, m.arena_bytes() if rank else arena.numel(), dev, src=0)
         if rank != 0:
             m.prepare(arena=arena)
@@ -163,7 +167,7 @@ def main():
         x, x_next = step(k, x, x_next)
         k += 1
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -171,11 +175,11 @@ def main():
         x, x_next = step(k, x, x_next)
         k += 1
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = tt.item()
@@ -217,7 +221,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -23,7 +23,7 @@ def shard_range(n_items: int, rank: int, world: int):
 def broadcast_arena(arena: Optional[torch.Tensor], nbytes: int, device, src: int = 0, chunk_bytes: int = 1 << 30) -> torch.Tensor:
     """Rank `src` passes its packed arena; every other rank passes None and receives a copy.
     Sent as a few large chunks (xGMI rings are per-link bound; large messages amortise latency)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         assert arena is not None
         return arena
     if dist.get_rank() != src:
