@@ -321,7 +321,7 @@ int k22_movq_num_ops(const K22MoVQ* m);
  *   T (engine dtype), rows padded to 64: "layers.<l>.qkv.weight" [3*width][width] (rows Q | K | V, heads x 64 inside each),
  *   ".proj.weight", ".fc.weight" [4*width][width], ".out.weight" [width][4*width]; vision "patch.weight" [width][roundup(3*patch^2,
  *   64)] (conv1.weight flattened (c, i, j), zero padded).
- * Tile configurations are the fixed heuristic: no on-device tuning, no dependence on the tile table. */
+ * The Linears' tile configurations come from the tile table like the other engines' (shipped for the production shapes). */
 enum { K22_ENC_CLIP_TEXT = 0, K22_ENC_CLIP_VISION = 1, K22_ENC_XLMR = 2 };
 typedef struct K22EncoderConfig {
   int dtype;       /* K22_BF16 | K22_F32 */

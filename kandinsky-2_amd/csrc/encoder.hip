@@ -15,10 +15,13 @@
 // fp32 residual stream is updated in place by the GEMM epilogue, LayerNorm writes the next GEMM's operand, attention is the UNet's
 // flash kernel with a causal / key-validity mask.  QuickGELU is applied by a separate pass on the fp32 accumulator output of c_fc
 // (one rounding, like a fused epilogue) so that the hot GEMM kernels' epilogue is left exactly as validated.
-// Tile configurations are the fixed heuristic (no on-device tuning): results never depend on a tuner.
+// Tile configurations of the transformer Linears come from the process-wide tile table like the other engines' (tuning.h): the
+// production shapes (2/4/8 sequences, 1/2 images) are in the shipped table, so nothing is timed for them and the bits are the same
+// on every box; other shapes are measured at their first pass (K22_AUTOTUNE=0: the fixed heuristic).
 #include "kernels.h"
 #include "elementwise.h"
 #include "../../include/k22.h"
+#include "tuning.h"
 
 #include <deque>
 #include <functional>
@@ -149,6 +152,9 @@ struct K22Encoder {
   int B = 0;
   std::deque<ESlot> slots;
   std::vector<EOp> ops;
+  std::deque<Tuned> tuned;   // every transformer Linear: its tile configuration (table / measurement at the first pass)
+  bool tuned_done = false;
+  int autotune = 1;
   size_t ws_bytes = 0;
   char* ws = nullptr;
   std::string err;
@@ -159,7 +165,7 @@ struct K22Encoder {
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
   }
   ESlot *s_tok, *s_valid, *s_img, *s_patch, *s_pout, *s_inp, *s_ln, *s_qkv, *s_att, *s_fc, *s_fc32, *s_seq, *s_pool_in, *s_pooled, *s_splitk,
-      *s_kall, *s_vtall;
+      *s_kall, *s_vtall, *s_flush;
 
   ESlot* new_slot(size_t bytes = 0) { slots.emplace_back(); slots.back().bytes = bytes; return &slots.back(); }
   static void need(ESlot* s, size_t bytes) { if (bytes > s->bytes) s->bytes = bytes; }
@@ -173,20 +179,25 @@ struct K22Encoder {
 
   // out = A[M][K] . W[N][K]^T + bias:  mode 0 -> T rows; 1 -> fp32 rows; 2 -> fp32 rows += (in-place residual stream)
   void op_linear(ESlot* a, int M, int N, int K, const std::string& pfx, int act, ESlot* dst, int ldo, int mode) {
-    IgemmParams p = {};
+    tuned.emplace_back();
+    Tuned* t = &tuned.back();
+    IgemmParams& p = t->p;
     p.stages = -1;
     p.M = M; p.N = N; p.Npad = (N + 63) / 64 * 64; p.Kc = K; p.K0 = K; p.taps = 1; p.lda0 = K; p.ldo = ldo; p.ldr = ldo;
     p.out_mode = mode == 0 ? IG_OUT_ROWMAJOR : IG_OUT_ROWMAJOR_F32; p.act = act; p.res_f32 = mode == 2 ? 1 : 0;
     p.Wp = W_(pfx + ".weight"); p.bias = Wf(pfx + ".bias");
-    p.splitk = igemm_choose_splitk(p, dtype);
-    if (p.splitk > 1) need(s_splitk, (size_t)p.splitk * M * N * sizeof(float));
+    tuned_make_candidates(*t, dtype);
+    tuned_default_cfg(*t, dtype);
+    need(s_splitk, tuned_max_splitk_bytes(*t, autotune != 0));
     const int dt = dtype;
-    ops.push_back([=](hipStream_t st) {
-      IgemmParams q = p;
+    t->run = [=](hipStream_t st) {
+      IgemmParams q = t->p;
+      tuned_apply_cfg(q, t->cfg);
       q.A0 = ptr(a); q.out = ptr(dst); q.partial = ptr<float>(s_splitk);
       q.residual = mode == 2 ? ptr(dst) : nullptr;
       return launch_igemm(q, dt, st);
-    });
+    };
+    ops.push_back([=](hipStream_t st) { return t->run(st); });
   }
   // LayerNorm of `rows` fp32 rows of x (stride ldx): fp32 copy into yf (may be x itself) and / or T copy into yt
   void op_ln(ESlot* x, size_t x_off, int64_t ldx, int rows, const std::string& pfx, ESlot* yf, int64_t ldyf, ESlot* yt) {
@@ -207,7 +218,7 @@ struct K22Encoder {
 
   int plan(int nB) {
     B = nB;
-    slots.clear(); ops.clear(); err.clear(); ws = nullptr;
+    slots.clear(); ops.clear(); err.clear(); ws = nullptr; tuned.clear(); tuned_done = false;
     if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
     const int D = cfg.width, n = cfg.n_ctx, M = B * n, heads = cfg.heads, od = cfg.out_dim, kind = cfg.kind;
     if (B < 1 || B > 8) return k22_set_error(K22_EINVAL, "encoder: 1..8 sequences / images per call");
@@ -225,6 +236,7 @@ struct K22Encoder {
     s_att = new_slot((size_t)M * D * esz); s_fc = new_slot((size_t)M * 4 * D * esz); s_fc32 = new_slot(xlmr ? 0 : (size_t)M * 4 * D * 4);
     s_seq = new_slot((size_t)M * D * 4); s_pool_in = new_slot((size_t)B * D * 4); s_pooled = new_slot((size_t)B * od * 4);
     s_splitk = new_slot(256); s_kall = new_slot(); s_vtall = new_slot();
+    s_flush = new_slot(autotune ? ((size_t)320 << 20) : 0);
     const int Bn = B, dt = dtype;
 
     // ---- input sequence ------------------------------------------------------------------------------------------------------
@@ -353,6 +365,10 @@ int k22_encoder_create(const K22EncoderConfig* cfg, const K22Weight* weights, in
   K22Encoder* m = new K22Encoder();
   m->cfg = *cfg; m->dtype = cfg->dtype; m->esz = cfg->dtype == K22_BF16 ? 2 : 4;
   for (int i = 0; i < n_weights; ++i) m->w[weights[i].name] = weights[i].ptr;
+  {
+    const char* e = getenv("K22_AUTOTUNE");
+    m->autotune = e ? (atoi(e) != 0) : 1;
+  }
   *out = m;
   return K22_OK;
 }
@@ -393,6 +409,13 @@ int k22_encoder_forward(K22Encoder* m, const int* tokens, const float* key_valid
   if (vision) { K22_CPY(m->ptr(m->s_img), image, (size_t)m->B * 3 * c.image_size * c.image_size * 4); }
   else { K22_CPY(m->ptr(m->s_tok), tokens, M * 4); }
   if (xlmr) { K22_CPY(m->ptr(m->s_valid), key_valid, M * 4); }
+  if (m->autotune && !m->tuned_done) {
+    // problems the tile table does not know are measured here (the in-place residual GEMMs accumulate garbage into the sequence
+    // buffer meanwhile: the real pass below rebuilds it from the inputs)
+    int rc = tune_igemm_ops(m->tuned, m->dtype, m->s_flush->bytes ? m->ptr(m->s_flush) : nullptr, m->s_flush->bytes, st);
+    if (rc) return rc;
+    m->tuned_done = true;
+  }
   if (!m->graph_exec) {
     // first pass on this plan: run eagerly once (function attributes, code load), then capture the launch list
     for (auto& op : m->ops) { int rc = op(st); if (rc) return rc; }

@@ -39,7 +39,11 @@ def test_multiclip_vs_reference_golden(golden_dir, size, backend, tol_tiny, tol_
     te = k22.TextEncoderHIP(model_name="multiclip", xlmr_config=m["cfg"], in_features=m["in_features"], out_features=m["out_features"],
                             state_dict=k22.init_multiclip_state_dict(m["cfg"], m["in_features"], m["out_features"], seed=m["seed_w"]),
                             backend_dtype=backend).to("cuda")
+    from kandinsky2_amd import _lib
+    measured = _lib.lib().k22_tile_table_measured()
     full_out, pooled_out = te(tokens=fx["input_ids"].cuda(), mask=fx["attention_mask"].cuda())
+    if size == "full":      # production shapes come from the shipped tile table: nothing is timed, the bits do not depend on the box
+        assert _lib.lib().k22_tile_table_measured() == measured
     e1, e2 = _rel(full_out, fx["embs"]), _rel(pooled_out, fx["pooled"])
     print(f"multiclip {size} {backend}: embs {e1:.3e} pooled {e2:.3e} of scale (reference MultilingualCLIP golden)")
     tol = tol_tiny if size == "tiny" else tol_full
@@ -57,8 +61,12 @@ def test_clip_towers_vs_golden(golden_dir, size, backend, tol_tiny, tol_full):
     m = k22.CLIPModelHIP(cfg, backend_dtype=backend)
     m.load_state_dict(k22.init_clip_state_dict(cfg, seed=fx["meta"]["seed_w"]))
     m = m.to("cuda")
+    from kandinsky2_amd import _lib
+    measured = _lib.lib().k22_tile_table_measured()
     feat, seq = m.encode_text_with_sequence(fx["tokens"].cuda())
     img = m.encode_image(fx["image"].cuda())
+    if size == "full":
+        assert _lib.lib().k22_tile_table_measured() == measured
     e = _rel(seq, fx["txt_feat_seq"]), _rel(feat, fx["txt_feat"]), _rel(img, fx["img_feat"])
     print(f"clip {size} {backend}: txt_feat_seq {e[0]:.3e} txt_feat {e[1]:.3e} img_feat {e[2]:.3e} of scale")
     tol = tol_tiny if size == "tiny" else tol_full

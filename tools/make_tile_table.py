@@ -12,7 +12,9 @@ import os
 import sys
 import time
 
-os.environ["K22_TILE_TABLE"] = "0"          # start empty: everything below is measured here
+ENC_ONLY = "--encoders-only" in sys.argv     # keep the shipped table and add only the conditioning-tower shapes to it
+if not ENC_ONLY:
+    os.environ["K22_TILE_TABLE"] = "0"      # start empty: everything below is measured here
 os.environ.setdefault("K22_TUNE_REPS", "7")
 os.environ.pop("K22_TUNE_CACHE", None)
 os.environ["K22_AUTOTUNE"] = "1"
@@ -83,9 +85,44 @@ def prior(hp, batches, dtypes=(torch.bfloat16, torch.float32)):
         torch.cuda.empty_cache()
 
 
+def encoders():
+    """conditioning towers: production sizes at 2 / 4 / 8 sequences (bs 1, 2, 4) and 1 / 2 images, and the parity-test shapes"""
+    cases = [(k22.CLIP_VITL14, dict(k22.XLMR_LARGE, vocab_size=4096), 1024, 768, (2, 4, 8), (1, 2), (torch.bfloat16, torch.float32)),
+             (k22.tiny_clip_config(), k22.tiny_xlmr_config(), 128, 64, (1, 3, 4, 8), (1, 3), (torch.bfloat16, torch.float32))]
+    for ccfg, xcfg, inf, outf, seqs, imgs, dtypes in cases:
+        csd, xsd = k22.init_clip_state_dict(ccfg, seed=0), k22.init_multiclip_state_dict(xcfg, inf, outf, seed=0)
+        for dt in dtypes:
+            clip = k22.CLIPModelHIP(ccfg, backend_dtype=dt)
+            clip.load_state_dict(csd)
+            clip = clip.to("cuda")
+            xl = k22.MultilingualCLIPHIP(xcfg, in_features=inf, out_features=outf, backend_dtype=dt)
+            xl.load_state_dict(xsd)
+            xl = xl.to("cuda")
+            for n in seqs:
+                tok = torch.zeros(n, 77, dtype=torch.long, device="cuda")
+                tok[:, 0], tok[:, 1] = ccfg["vocab_size"] - 2, ccfg["vocab_size"] - 1
+                clip.encode_text(tok)
+                ids = torch.ones(n, 77, dtype=torch.long, device="cuda")
+                ids[:, 0], ids[:, 1] = 0, 2
+                xl(ids, ids.ne(1).long())
+            r = ccfg["image_resolution"]
+            for n in imgs:
+                clip.encode_image(torch.zeros(n, 3, r, r, device="cuda"))
+            torch.cuda.synchronize()
+            print(f"encoders width {ccfg['transformer_width']}/{xcfg['hidden_size']} {dt}: table = {_lib.lib().k22_tile_table_size()} entries", flush=True)
+            del clip, xl
+            torch.cuda.empty_cache()
+
+
 def main():
-    out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/tiles_gfx950.txt"
+    out = next((a for a in sys.argv[1:] if not a.startswith("--")), "gpurun_out/tiles_gfx950.txt")
     quick = "--quick" in sys.argv
+    if ENC_ONLY:
+        n0 = _lib.lib().k22_tile_table_size()
+        encoders()
+        n = _lib.lib().k22_tile_table_save(out.encode())
+        print(f"{n0} shipped + {n - n0} new = {n} entries -> {out}")
+        return
     tiny = k22.tiny_model_config()
     # smoke() / parity-test shapes of the 1/3-width model
     unet(tiny, False, [(2, 16, 16), (4, 8, 24), (4, 16, 16)])
@@ -110,6 +147,7 @@ def main():
         prior(k22.tiny_prior_hparams(), [4])
         prior(k22.PRIOR_HPARAMS_2_1, [2, 4, 8], dtypes=(torch.bfloat16,))
         prior(k22.PRIOR_HPARAMS_2_1, [4], dtypes=(torch.float32,))
+        encoders()
     n = _lib.lib().k22_tile_table_save(out.encode())
     print(f"{n} entries -> {out}")
 
