@@ -120,6 +120,15 @@ class KandinskyV22Img2ImgDecoderHIP(KandinskyV22DecoderHIP):
         super().__init__(unet, movq, scheduler, movq_scale_factor)
         self.movq_encoder = movq_encoder
 
+    def get_timesteps(self, num_inference_steps, strength, device="cuda"):
+        """KandinskyV22Img2ImgPipeline.get_timesteps: the last min(int(steps * strength), steps) timesteps of the schedule"""
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        t_start = max(num_inference_steps - min(int(num_inference_steps * strength), num_inference_steps), 0)
+        ts = self.scheduler.timesteps.tolist()[t_start:]
+        if not ts:
+            raise ValueError("strength too small: no denoising step left")
+        return ts
+
     def _latents_of(self, image, height, width, bs):
         """image: PIL, [n,3,H,W] in [-1,1], or latents [n,4,h,w] (passed through, as the diffusers pipeline does)"""
         if not torch.is_tensor(image):
@@ -137,11 +146,7 @@ class KandinskyV22Img2ImgDecoderHIP(KandinskyV22DecoderHIP):
         dev, bs = image_embeds.device, image_embeds.shape[0]
         emb = torch.cat([image_embeds, negative_image_embeds], 0).float().contiguous()
         lat0 = self._latents_of(image, height, width, bs)
-        self.scheduler.set_timesteps(num_inference_steps, device=dev)
-        t_start = max(num_inference_steps - min(int(num_inference_steps * strength), num_inference_steps), 0)
-        ts = self.scheduler.timesteps.tolist()[t_start:]
-        if not ts:
-            raise ValueError("strength too small: no denoising step left")
+        ts = self.get_timesteps(num_inference_steps, strength, dev)
         nz0 = noise.to(dev).float() if noise is not None else torch.randn(lat0.shape, generator=generator, device=dev)
         x = self.scheduler.add_noise(lat0, nz0, ts[0])
         x = self._denoise(x, emb, ts, guidance_scale, noise_seq, generator)
