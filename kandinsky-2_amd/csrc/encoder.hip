@@ -217,18 +217,22 @@ struct K22Encoder {
   }
 
   int plan(int nB) {
+    const int D = cfg.width, n = cfg.n_ctx, M = nB * n, heads = cfg.heads, od = cfg.out_dim, kind = cfg.kind;
+    if (nB < 1 || nB > 8) return k22_set_error(K22_EINVAL, "encoder: 1..8 sequences / images per call");
+    if (D < 64 || D % 64 || heads * 64 != D || D > 2048) return k22_set_error(K22_EINVAL, "encoder: 64 channels per head, width <= 2048");
+    if (kind < K22_ENC_CLIP_TEXT || kind > K22_ENC_XLMR) return k22_set_error(K22_EINVAL, "encoder: kind");
+    if (n < 1 || cfg.layers < 1 || od < 1) return k22_set_error(K22_EINVAL, "encoder: n_ctx, layers and out_dim must be positive");
+    const bool vision = kind == K22_ENC_CLIP_VISION, xlmr = kind == K22_ENC_XLMR;
+    if (vision && (cfg.patch < 1 || cfg.image_size < cfg.patch)) return k22_set_error(K22_EINVAL, "encoder: patch / image_size");
+    if (xlmr && (cfg.max_pos < 2 || cfg.pad_id < 0 || cfg.pad_id >= cfg.max_pos)) return k22_set_error(K22_EINVAL, "encoder: max_pos / pad_id");
+    const int g = vision ? cfg.image_size / cfg.patch : 0, P = g * g;
+    const int Kraw = 3 * cfg.patch * cfg.patch, Kp = (Kraw + 63) / 64 * 64;
+    if (vision && (cfg.image_size % cfg.patch || P + 1 != n)) return k22_set_error(K22_EINVAL, "encoder: n_ctx must be (image_size/patch)^2 + 1");
+    if (!vision && cfg.vocab < 1) return k22_set_error(K22_EINVAL, "encoder: vocab");
+    // validated: only now drop the previous plan
     B = nB;
     slots.clear(); ops.clear(); err.clear(); ws = nullptr; tuned.clear(); tuned_done = false;
     if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
-    const int D = cfg.width, n = cfg.n_ctx, M = B * n, heads = cfg.heads, od = cfg.out_dim, kind = cfg.kind;
-    if (B < 1 || B > 8) return k22_set_error(K22_EINVAL, "encoder: 1..8 sequences / images per call");
-    if (D % 64 || D / heads != 64 || D > 2048) return k22_set_error(K22_EINVAL, "encoder: 64 channels per head, width <= 2048");
-    if (kind < K22_ENC_CLIP_TEXT || kind > K22_ENC_XLMR) return k22_set_error(K22_EINVAL, "encoder: kind");
-    const bool vision = kind == K22_ENC_CLIP_VISION, xlmr = kind == K22_ENC_XLMR;
-    const int g = vision ? cfg.image_size / cfg.patch : 0, P = g * g;
-    const int Kraw = 3 * cfg.patch * cfg.patch, Kp = (Kraw + 63) / 64 * 64;
-    if (vision && (cfg.patch < 1 || cfg.image_size % cfg.patch || P + 1 != n)) return k22_set_error(K22_EINVAL, "encoder: n_ctx must be (image_size/patch)^2 + 1");
-    if (!vision && cfg.vocab < 1) return k22_set_error(K22_EINVAL, "encoder: vocab");
     s_tok = new_slot((size_t)M * 4); s_valid = new_slot((size_t)M * 4);
     s_img = new_slot(vision ? (size_t)B * 3 * cfg.image_size * cfg.image_size * 4 : 0);
     s_patch = new_slot(vision ? (size_t)B * P * Kp * esz : 0); s_pout = new_slot(vision ? (size_t)B * P * D * 4 : 0);
@@ -377,7 +381,7 @@ void k22_encoder_destroy(K22Encoder* m) { delete m; }
 int k22_encoder_plan(K22Encoder* m, int B, size_t* workspace_bytes) {
   if (!m || !workspace_bytes) return k22_set_error(K22_EINVAL, "encoder_plan: null argument");
   int rc = m->plan(B);
-  if (rc) { m->ops.clear(); return rc; }
+  if (rc) { if (!m->err.empty()) { m->ops.clear(); m->ws = nullptr; } return rc; }   // a missing weight is found after the old plan was dropped
   *workspace_bytes = m->ws_bytes;
   return K22_OK;
 }

@@ -111,3 +111,39 @@ def test_encoders_fail_loudly_without_gpu_and_validate_inputs():
         k22.TextEncoderHIP(model_name="T5EncoderModel")
     with pytest.raises(ValueError):
         k22.MultilingualCLIPHIP(dict(k22.tiny_xlmr_config(), intermediate_size=256), in_features=128, out_features=64)
+
+
+def test_encoder_c_abi_argument_checks():
+    """k22_encoder_create / plan / forward reject bad configurations with an error code and message (host logic, no GPU work)."""
+    import ctypes as C
+    from kandinsky2_amd import _lib
+    L = _lib.lib()
+
+    def plan(B=2, **kw):
+        c = _lib.K22EncoderConfig()
+        vals = dict(dtype=_lib.K22_BF16, kind=encoders.ENC_XLMR, width=128, layers=2, heads=2, n_ctx=77, vocab=1000, out_dim=64, image_size=0,
+                    patch=0, max_pos=514, pad_id=1, ln_eps=1e-5)
+        vals.update(kw)
+        for k, v in vals.items():
+            setattr(c, k, v)
+        h, n = C.c_void_p(), C.c_size_t()
+        assert L.k22_encoder_create(C.byref(c), None, 0, C.byref(h)) == 0
+        try:
+            rc = L.k22_encoder_plan(h, B, C.byref(n))
+            fwd = L.k22_encoder_forward(h, None, None, None, None, None, None)
+            return rc, (L.k22_last_error() or b"").decode(), fwd
+        finally:
+            L.k22_encoder_destroy(h)
+
+    assert plan(B=9)[0] != 0 and plan(B=0)[0] != 0
+    assert plan(heads=3)[0] != 0 and plan(width=96, heads=1)[0] != 0
+    assert plan(kind=encoders.ENC_CLIP_VISION, image_size=56, patch=0, n_ctx=17)[0] != 0          # no division by a zero patch
+    assert plan(kind=encoders.ENC_CLIP_VISION, image_size=56, patch=14, n_ctx=18)[0] != 0         # n_ctx != 16 patches + class token
+    assert plan(kind=7)[0] != 0 and plan(max_pos=1)[0] != 0
+    rc, msg, fwd = plan()                                             # a valid configuration without weights: named, not dereferenced
+    assert rc != 0 and fwd != 0
+    c = _lib.K22EncoderConfig()
+    c.dtype = 5
+    h = C.c_void_p()
+    assert L.k22_encoder_create(C.byref(c), None, 0, C.byref(h)) != 0 and L.k22_encoder_create(None, None, 0, C.byref(h)) != 0
+    assert L.k22_blend_noised(None, None, None, None, 1.0, 0.0, None, 1, 4, 16, 0, None) != 0
