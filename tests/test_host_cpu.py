@@ -400,3 +400,24 @@ def test_unet22_oracle_runs_and_scheduler_tables_agree():
     # respacing identity: betas' = 1 - abar_t / abar_prev over the retained timesteps
     d = k22.create_gaussian_diffusion(**dict(k22.DIFFUSION_CONFIG_2_1, timestep_respacing="50"))
     assert d.num_timesteps == 50
+
+
+def test_shipped_tile_table_loads_and_round_trips(tmp_path):
+    """kandinsky-2_amd/tiles_gfx950.txt (csrc/tuning.h): the table that fixes every tile configuration - and with it every fp32
+    summation order - of the benchmarked shapes.  Host logic only: load, save, reload give the same entries."""
+    L = _lib.lib()
+    shipped = [l for l in open(_lib.TILE_TABLE_PATH).read().splitlines() if l and not l.startswith("#")]
+    assert len(shipped) >= 800 and len(set(tuple(l.split()[:10]) for l in shipped)) == len(shipped), "one line per problem"
+    try:
+        L.k22_tile_table_clear()
+        assert L.k22_tile_table_size() == 0
+        assert L.k22_tile_table_load(_lib.TILE_TABLE_PATH.encode()) == len(shipped) and L.k22_tile_table_size() == len(shipped)
+        out = str(tmp_path / "tiles.txt")
+        assert L.k22_tile_table_save(out.encode()) == len(shipped)
+        again = [l for l in open(out).read().splitlines() if l and not l.startswith("#")]
+        assert sorted(again) == sorted(shipped)
+        assert L.k22_tile_table_load(b"/nonexistent/tiles.txt") < 0
+        assert L.k22_tile_table_measured() == 0          # nothing is ever timed without a GPU forward
+    finally:
+        L.k22_tile_table_clear()
+        L.k22_tile_table_load(_lib.TILE_TABLE_PATH.encode())
