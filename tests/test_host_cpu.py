@@ -204,9 +204,10 @@ def test_movq_arena_layout_is_shape_determined():
 
 
 # ---- diffusion prior ---------------------------------------------------------------
-def test_prior_oracle_matches_reference_golden(golden_dir):
+@pytest.mark.parametrize("name", ["prior_tiny", "prior_full"])        # prior_full: the production 2048 x 20 transformer (1.0 B parameters)
+def test_prior_oracle_matches_reference_golden(golden_dir, name):
     from oracle import prior_ref
-    fx = _load(golden_dir, "prior_tiny")
+    fx = _load(golden_dir, name)
     hp = fx["hp"]
     sd = k22.init_prior_state_dict(hp, seed=fx["seed_w"])
     g = torch.Generator().manual_seed(7)
@@ -421,3 +422,46 @@ def test_shipped_tile_table_loads_and_round_trips(tmp_path):
     finally:
         L.k22_tile_table_clear()
         L.k22_tile_table_load(_lib.TILE_TABLE_PATH.encode())
+
+
+# ---- the oracle at the FULL shapes of the bench (the fixtures the -m gpu parity tests of tests/test_full_size_gpu.py use) ---------
+def test_oracle_c2_first_forward_matches_reference_golden(golden_dir):
+    """C2 (768x768 bs 1 -> CFG batch 2x4x96x96, 1.23 B parameters): the restatement against the reference create_model(...)'s
+    output stored by oracle/make_golden.py --only c2.  One forward (the 50-step trajectory is what the GPU tests walk)."""
+    p = os.path.join(golden_dir, "c2_text2img.pt")
+    if not os.path.exists(p):
+        pytest.skip("c2_text2img.pt not generated")
+    fx = torch.load(p, weights_only=False)
+    arch = k22.make_arch(k22.MODEL_CONFIG_2_1)
+    sd = k22.init_unet_state_dict(arch, seed=fx["seed_w"])
+    full, pooled, image = k22.make_conditioning(arch, fx["B"], seed=2)
+    g = torch.Generator().manual_seed(42)
+    x_T = torch.randn(fx["B"], 4, fx["lat"], fx["lat"], generator=g)
+    bs = fx["bs"]
+    with torch.no_grad():
+        out = unet_ref.unet_forward(sd, arch, torch.cat([x_T[:bs], x_T[:bs]], 0), fx["first_ts"].float(), full, pooled, image)
+    scale = fx["first_out"].abs().max().item()
+    assert scale > 0.1 and (out - fx["first_out"]).abs().max().item() <= 1e-5 * scale
+
+
+def test_movq_oracle_matches_reference_golden_256px(golden_dir):
+    """MOVQ.decode at 32x32 latents (T = 1024 tokens in the attention blocks): compact fp32 samples + the whole uint8 image."""
+    from oracle import movq_ref
+    p = os.path.join(golden_dir, "movq_256px.pt")
+    if not os.path.exists(p):
+        pytest.skip("movq_256px.pt not generated")
+    fx = torch.load(p, weights_only=False)
+    arch = k22.MoVQArch(k22.MOVQ_CONFIG_2_1["ddconfig"])
+    sd = k22.init_movq_state_dict(arch, seed=fx["seed_w"])
+    z = torch.randn(fx["B"], 4, fx["h"], fx["w"], generator=torch.Generator().manual_seed(fx["seed_z"]))
+    with torch.no_grad():
+        out = movq_ref.movq_decode(sd, arch, z)
+    c = fx["out_compact"]
+    st, r0, c0 = c["stride"], c["r0"], c["c0"]
+    tol = 1e-5 * fx["absmax"]
+    assert (out[..., ::st, ::st] - c["sub"]).abs().max().item() <= tol
+    assert (out[..., r0:r0 + c["rows"].shape[-2], :] - c["rows"]).abs().max().item() <= tol
+    assert (out[..., :, c0:c0 + c["cols"].shape[-1]] - c["cols"]).abs().max().item() <= tol
+    u8 = movq_ref.process_images_u8(out)
+    d = (u8.int() - fx["out_u8"].int()).abs()
+    assert d.max().item() <= 1 and (d > 0).float().mean().item() <= 1e-3       # a grey level can flip on an exact .5
