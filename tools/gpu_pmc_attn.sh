@@ -24,12 +24,12 @@ for f in glob.glob(f"{root}/pmc_attn_*/**/*counter_collection.csv", recursive=Tr
         grid = r.get("Grid_Size", "?")
         res[grid][r["Counter_Name"]].append(float(r["Counter_Value"]))
 print("# rocprofv3 --kernel-trace --pmc <set> (two passes) of: python tools/bench_attn.py 5   - attention_kernel<bf16>, per launch (mean)")
-print("# SQ_VALU_MFMA_BUSY_CYCLES: cycles summed over SIMDs; GRBM_GUI_ACTIVE: device cycles of the launch; 256 CUs x 4 SIMDs")
+print("# SQ_VALU_MFMA_BUSY_CYCLES: cycles summed over the 1024 SIMDs (= 32 per 32x32x16 bf16 MFMA); GRBM_GUI_ACTIVE: active cycles summed over the 8 XCDs")
 for grid, d in sorted(res.items(), key=lambda kv: -float(kv[0]) if kv[0].isdigit() else 0):
     m = {k: sum(v) / len(v) for k, v in d.items()}
     line = f"grid {grid:>9}: " + "  ".join(f"{k}={v:.3e}" for k, v in sorted(m.items()))
     if "SQ_VALU_MFMA_BUSY_CYCLES" in m and m.get("GRBM_GUI_ACTIVE"):
-        line += f"  => matrix pipe busy {m['SQ_VALU_MFMA_BUSY_CYCLES'] / (m['GRBM_GUI_ACTIVE'] * 1024):.3f} of SIMD-cycles"
+        line += f"  => matrix pipe busy {m['SQ_VALU_MFMA_BUSY_CYCLES'] / (m['GRBM_GUI_ACTIVE'] / 8 * 1024):.3f} of SIMD-cycles ({m['GRBM_GUI_ACTIVE'] / 8:.0f} cycles per launch)"
     if "SQ_WAVE_CYCLES" in m and "SQ_ACTIVE_INST_VALU" in m:
         line += f"  VALU-issue {m['SQ_ACTIVE_INST_VALU'] / m['SQ_WAVE_CYCLES']:.3f}, waiting-on-issue {m.get('SQ_WAIT_INST_ANY', 0) / m['SQ_WAVE_CYCLES']:.3f}, parked {m.get('SQ_WAIT_ANY', 0) / m['SQ_WAVE_CYCLES']:.3f} of wave-cycles"
     print(line)
