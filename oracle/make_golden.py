@@ -500,6 +500,9 @@ BIG_CASES = {
     # MoVQ at real sizes: 32x32 latents (256x256 px, attention over T = 1024) and C2's 96x96 (768x768 px, T = 9216)
     "movq32": lambda: movq_case("movq_256px", B=1, h=32, w=32, compact=True),
     "movq96": lambda: movq_case("movq_768px", B=1, h=96, w=96, compact=True),
+    # 8f-1 at the C2 shape with the 1.23 B UNet: the reference DDIMSampler / PLMSSampler, 20 steps; ~10 min each on 8 cores
+    "c2ddim": lambda: ddim_case("c2_ddim", k22.MODEL_CONFIG_2_1, B=2, h=96, w=96, steps=20),
+    "c2plms": lambda: plms_case("c2_plms", k22.MODEL_CONFIG_2_1, B=2, h=96, w=96, steps=20),
     "movqenc": lambda: (movq_enc_case("movq_enc_256px", B=1, H=256, W=256), movq_enc_case("movq_enc_768px", B=1, H=768, W=768)),
 }
 

@@ -29,10 +29,10 @@ _SD_CACHE = {}
 
 
 def _state_dict(fx):
-    key = (fx["name"], fx["seed_w"])
+    key = (fx["model_config"]["num_channels"], bool(fx.get("inpainting", False)), fx["seed_w"])
     if key not in _SD_CACHE:
         _SD_CACHE.clear()  # keep at most one (the full model is 4.9 GB of fp32)
-        arch = k22.make_arch(fx["model_config"], inpainting=fx["inpainting"])
+        arch = k22.make_arch(fx["model_config"], inpainting=bool(fx.get("inpainting", False)))
         _SD_CACHE[key] = k22.init_unet_state_dict(arch, seed=fx["seed_w"])
     return _SD_CACHE[key]
 
@@ -135,13 +135,14 @@ def test_forward_matches_oracle_on_fresh_seed():
     assert (o_new - ref2).abs().max().item() <= 2e-4 * ref2.abs().max().item()
 
 
-def test_ddim_sampler_final_latent_vs_reference_golden_fp32(golden_dir):
+@pytest.mark.parametrize("name", ["tiny_ddim", "c2_ddim"])
+def test_ddim_sampler_final_latent_vs_reference_golden_fp32(golden_dir, name):
     """the reference's default sampler (DDIMSampler, eta = 0) with the fused k22_ddim_step; fp32 engine,
-    5 steps, final latent within 1e-3 of the reference's (relative to its scale: the un-clamped DDIM latent of a
-    random-weight UNet grows to ~50)."""
-    fx = _load(golden_dir, "tiny_ddim")
+    final latent within 1e-3 of the reference's (relative to its scale: the un-clamped DDIM latent of a random-weight UNet
+    grows to ~50).  tiny_ddim: 1/3-width UNet, 5 steps; c2_ddim: the 1.23 B UNet at the C2 shape (2x4x96x96), 20 steps."""
+    fx = _load(golden_dir, name)
     arch = k22.make_arch(fx["model_config"])
-    sd = k22.init_unet_state_dict(arch, seed=fx["seed_w"])
+    sd = _state_dict(fx)
     m = k22.Text2ImUNetHIP(arch, backend_dtype=torch.float32, use_graph=True)
     m.load_state_dict(sd)
     m = m.to("cuda").eval()
@@ -159,13 +160,14 @@ def test_ddim_sampler_final_latent_vs_reference_golden_fp32(golden_dir):
     assert err <= 1e-3 * max(1.0, scale)
 
 
-def test_plms_sampler_final_latent_vs_reference_golden_fp32(golden_dir):
+@pytest.mark.parametrize("name", ["tiny_plms", "c2_plms"])
+def test_plms_sampler_final_latent_vs_reference_golden_fp32(golden_dir, name):
     """PLMSSampler (pseudo improved Euler start + Adams-Bashforth on the guided eps) with the fused
-    k22_plms_step; fp32 engine, 8 steps (all four orders are exercised), final latent within 1e-3 of the reference's
-    (relative to its scale)."""
-    fx = _load(golden_dir, "tiny_plms")
+    k22_plms_step; fp32 engine (all four orders are exercised), final latent within 1e-3 of the reference's (relative to its
+    scale).  tiny_plms: 8 steps; c2_plms: the 1.23 B UNet at the C2 shape, 20 steps."""
+    fx = _load(golden_dir, name)
     arch = k22.make_arch(fx["model_config"])
-    sd = k22.init_unet_state_dict(arch, seed=fx["seed_w"])
+    sd = _state_dict(fx)
     m = k22.Text2ImUNetHIP(arch, backend_dtype=torch.float32, use_graph=True)
     m.load_state_dict(sd)
     m = m.to("cuda").eval()
