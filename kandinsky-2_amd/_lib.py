@@ -111,9 +111,7 @@ SIGNATURES = {
     "k22_groupnorm_scratch_bytes": (_Z, [_I, _I]),
     "k22_attention": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "k22_qkv_project": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "k22_qkv_project_stream": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "k22_linear_smallm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "k22_debug_counter": (_L, [C.c_char_p]),
 }
 
 _lib = None

@@ -31,11 +31,6 @@ int k22_set_option(const char* name, int value) {
 }
 const char* k22_last_error(void) { return g_err; }
 
-long k22_debug_counter(const char* name) {
-  if (name && !strcmp(name, "stream_launches")) return stream_launch_count();
-  return -1;
-}
-
 // ---- multi-GPU: the ONE collective of a job -------------------------------------------------------------
 // Broadcast of the packed weight arena from `root` over an RCCL communicator the caller owns (one process per GPU; prompts are
 // sharded by rank and nothing is exchanged in the step loop).  ncclBroadcast is resolved at call time from the RCCL that is
@@ -150,7 +145,7 @@ int k22_gemm_gnstats(const void* A, const void* Wp, const float* bias, const voi
   p.A0 = A; p.Wp = Wp; p.bias = bias; p.residual = residual; p.out = out; p.partial = reinterpret_cast<float*>(partial);
   p.M = B * H * W; p.N = N; p.Npad = Npad; p.Kc = K; p.K0 = K; p.taps = 1; p.H = H; p.W = W; p.lda0 = K;
   p.ldo = N; p.ldr = N; p.out_mode = IG_OUT_ROWMAJOR; p.act = K22_ACT_NONE; p.splitk = splitk > 0 ? splitk : 1;
-  p.force_bm = bm; p.algo = (bm == 160 || bm == 288) ? 20 : 10;
+  p.force_bm = bm; p.algo = 10;
   const int rpi = igemm_stats_rows_per_image(p, dtype);
   if (rows_per_image) *rows_per_image = rpi;
   if (rpi <= 0) return k22_set_error(K22_EINVAL, "gemm_gnstats: this configuration cannot produce GroupNorm partial sums");
@@ -246,19 +241,6 @@ int k22_qkv_project(const void* x, const void* Wp, const float* bias, void* q_ou
   p.M = B * T; p.N = 3 * C; p.Npad = 3 * C; p.Kc = K; p.K0 = K; p.taps = 1; p.lda0 = K; p.lda1 = 0;
   p.ldo = C; p.ldr = 3 * C; p.out_mode = IG_OUT_QKV; p.act = K22_ACT_NONE; p.splitk = 1; p.force_bm = bm; p.force_bn = bn;
   p.att_T = T; p.att_S = S; p.att_Tkp = Tkp; p.H = 1; p.W = T;   /* rows per image */
-  return launch_igemm(p, dtype, reinterpret_cast<hipStream_t>(stream));
-}
-
-int k22_qkv_project_stream(const void* x, const void* Wp, const float* bias, void* q_out, void* kall, void* vtall, void* partial,
-                           int B, int H, int T, int S, int K, int bm, int splitk, int dtype, void* stream) {
-  const int C = H * 64, Tkp = (S + T + 63) / 64 * 64;
-  IgemmParams p = {};
-  p.stages = -1;
-  p.A0 = x; p.Wp = Wp; p.bias = bias; p.out = q_out; p.kall = kall; p.vtall = vtall; p.partial = reinterpret_cast<float*>(partial);
-  p.M = B * T; p.N = 3 * C; p.Npad = 3 * C; p.Kc = K; p.K0 = K; p.taps = 1; p.lda0 = K; p.lda1 = 0;
-  p.ldo = C; p.ldr = 3 * C; p.out_mode = IG_OUT_QKV; p.act = K22_ACT_NONE; p.splitk = splitk > 0 ? splitk : 1; p.force_bm = bm; p.algo = 20;
-  p.att_T = T; p.att_S = S; p.att_Tkp = Tkp; p.H = 1; p.W = T;
-  if (!stream_supported(p, dtype, bm == 288 ? 9 : 5)) return k22_set_error(K22_EINVAL, "qkv_project_stream: unsupported problem");
   return launch_igemm(p, dtype, reinterpret_cast<hipStream_t>(stream));
 }
 
