@@ -14,8 +14,13 @@ Multi-GPU: every rank denoises its own image (weak scaling), weights arrive by O
 packed arena before the timed region; value = images-steps per second over all ranks.
 
 Extra objects on the JSON line: "roofline" (dominant kernel = implicit-GEMM conv3x3, MFMA-bound; measured
-with HIP events around every engine op on the launch stream) and "cpu_baseline" (the CPU oracle, i.e. the
-restated reference algorithm in PyTorch fp32, timed on this box's host cores on a bounded sample).
+with HIP events around every engine op on the launch stream), "cpu_baseline" (the CPU oracle, i.e. the
+restated reference algorithm in PyTorch fp32, timed on this box's host cores on a bounded sample),
+"parity_paths" (N = 1, default workload: steps/s of the fp16 and fp32 engines next to the timed dtype, each with the
+distance of ITS 50-step final latent from the committed reference golden tests/golden/c2_text2img.pt - the number that is
+timed and the number that has parity, side by side) and "e2e" (images/sec of Kandinsky2_1HIP.generate_text2img: prior 25
+steps + 50 denoise steps + MoVQ decode + uint8, with per-phase ms; seeded random weights, stand-in conditioning).
+`--gpus N` without RANK in the environment starts the N ranks itself and fails loudly when fewer devices are visible.
 """
 import argparse
 import json
@@ -37,17 +42,21 @@ PEAK_F32_TFLOPS = 157.3     # fp32-input MFMA
 PEAK_HBM_GBS = 8000.0
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=768, help="image side in pixels (latent = size/8)")
     ap.add_argument("--bs", type=int, default=1, help="images per GPU (CFG batch = 2*bs)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
+                    help="engine storage / MFMA operand type: bf16 (BASELINE's), fp16 (the reference's own use_fp16 mode), fp32 (parity path)")
     ap.add_argument("--sched-steps", type=int, default=50, help="decoder_steps of the schedule being sampled")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity_paths object (fp16 / fp32 engines + final-latent distances)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end images/sec pass (prior + denoise + MoVQ + uint8)")
+    ap.add_argument("--e2e-images", type=int, default=2, help="images timed by the end-to-end pass (after one untimed image)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-op HIP-event pass (roofline object = null)")
     ap.add_argument("--cpu-baseline-size", type=int, default=0, help="image side for the CPU sample (0 = same as --size)")
     ap.add_argument("--tuning-report", default="", help="write the chosen conv/GEMM tile configurations to this file")
@@ -55,10 +64,25 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="1/3-width UNet (debug only; not a valid bench config)")
     ap.add_argument("--head", default="2.1", choices=["2.1", "2.2"],
                     help="conditioning head: 2.1 = Text2ImUNet (10 image + 77 text tokens; parity pinned against the reference's modules); "
-                         "2.2 = diffusers UNet2DConditionModel of the 2.2 decoder (32 image tokens, DDPM step with clip +-2; parity unpinned)")
+                         "2.2 = diffusers UNet2DConditionModel of the 2.2 decoder (32 image tokens, DDPMScheduler step per SCHEDULER_CONFIG_2_2; parity unpinned)")
     ap.add_argument("--controlnet", action="store_true", help="2.2 ControlNet-depth UNet (hint conv stack, in_channels 8): config C5")
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
+    if a.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks here (what torch.distributed.run would do) - never a quiet 1-rank run
+        from kandinsky2_amd.parallel import launch_ranks
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n_dev < a.gpus:
+            raise SystemExit(f"bench.py: --gpus {a.gpus} but only {n_dev} GPU(s) visible")
+        launch_ranks(_rank_main, a.gpus, args=(list(sys.argv[1:] if argv is None else argv),), devices_visible=n_dev)
+        return
+    run(a)
 
+
+def _rank_main(rank, world, argv):
+    main(argv)
+
+
+def run(a):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -85,8 +109,9 @@ def main():
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
-    if a.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if a.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE {world} rank(s)")
+    world_observed = dist.get_world_size() if dist_on else 1      # what RCCL actually built
 
     v22 = a.head == "2.2" or a.controlnet
     if v22:
@@ -98,7 +123,7 @@ def main():
         mcfg = k22.tiny_model_config() if a.tiny else k22.MODEL_CONFIG_2_1
         arch = k22.make_arch(mcfg, inpainting=a.inpaint)
         Model, init_sd = k22.Text2ImUNetHIP, k22.init_unet_state_dict
-    tdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[a.dtype]
     lat = a.size // 8
     B = 2 * a.bs
 
@@ -129,7 +154,7 @@ def main():
             hint = torch.rand(a.bs, 3, a.size, a.size, generator=gc)          # depth map in [0,1]
             ack["hint"] = torch.cat([hint, hint], 0).to(dev)
         kw = dict(encoder_hidden_states=None, added_cond_kwargs=ack, return_dict=False)
-        sch = k22.DDPMSchedulerHIP().set_timesteps(a.sched_steps, device=dev)
+        sch = k22.DDPMSchedulerHIP.from_config(k22.SCHEDULER_CONFIG_2_2).set_timesteps(a.sched_steps, device=dev)
         T = a.sched_steps
         table = sch._table
         ts_rows = sch.timesteps.float().flip(0)[:, None].expand(-1, B).contiguous()   # row i = loop index i (ascending t), like the 2.1 table
@@ -148,7 +173,8 @@ def main():
     x_next = torch.empty_like(x)
     noise = torch.randn(a.steps + a.warmup + 1, B, 4, lat, lat, generator=g).to(dev)  # resident before timing
     scratch = torch.empty(L.k22_sampler_scratch_bytes(B, HW), dtype=torch.uint8, device=dev)
-    lo, gamma = (-1, 0.0) if v22 else k22.percentile_index(4 * HW)    # 2.2: DDPMScheduler clip_sample +-2, no dynamic threshold
+    lo, gamma = (-1, 0.0) if v22 else k22.percentile_index(4 * HW)    # 2.2: DDPMScheduler (clip per its config), no dynamic threshold
+    clamp = min(sch.clip, 3.0e38) if v22 else 2.0
     stream = torch.cuda.current_stream().cuda_stream
     init_img = img_mask = None
     if a.inpaint:
@@ -165,7 +191,7 @@ def main():
         if v22:
             out = out[0]
         _lib.check(L.k22_sampler_step(x.data_ptr(), out.data_ptr(), noise[k].data_ptr(), _lib.ptr(init_img), _lib.ptr(img_mask), table.data_ptr(), i,
-                                      4.0, 1, -2.0, 2.0, lo, gamma, scratch.data_ptr(), x_next.data_ptr(), None, B, HW, stream))
+                                      4.0, 1, -clamp, clamp, lo, gamma, scratch.data_ptr(), x_next.data_ptr(), None, B, HW, stream))
         return x_next, x
 
     # engine initialisation, outside warm-up and timing whatever W is: the first forward of a plan measures its conv / GEMM
@@ -196,6 +222,17 @@ def main():
         el = tt.item()
     finite = bool(torch.isfinite(x).all().item())
 
+    # ---- end-to-end images/sec: every rank generates its own images (weak scaling, no collective inside) --------------------
+    e2e = None
+    default_21 = not v22 and not a.inpaint and not a.tiny
+    if not a.no_e2e and default_21:
+        try:
+            e2e = e2e_pass(a, arch, sd, dev, tdt, dist_on, world)
+        except Exception as e:  # the bench line must come out whatever happens in the side measurements
+            print(f"bench: e2e pass failed on rank {rank}: {e}", file=sys.stderr)
+            if dist_on:
+                raise
+
     if rank == 0:
         if a.tuning_report:
             with open(a.tuning_report, "w") as f:
@@ -212,6 +249,12 @@ def main():
                 cpu = cpu_baseline(arch, sd, a, B)
             except Exception as e:
                 print(f"bench: cpu baseline failed: {e}", file=sys.stderr)
+        parity = None
+        if not a.no_parity and default_21 and world == 1 and a.size == 768 and a.bs == 1 and a.sched_steps == 50:
+            try:
+                parity = parity_paths(m, arch, sd, a, dev)
+            except Exception as e:
+                print(f"bench: parity pass failed: {e}", file=sys.stderr)
         value = world * a.steps / el
         line = {
             "metric": "UNet denoise steps/sec @ 768x768 bs=1, 50 steps" if (a.size == 768 and a.bs == 1) else
@@ -226,10 +269,11 @@ def main():
                                     f"2.1-architecture UNet ({'tiny' if a.tiny else '1.23B'}) p_sampler step; parity pinned against the reference's modules"),
                        "head": "2.2" if v22 else "2.1", "tile_configs_measured_in_this_process": measured_here,
                        "images_per_gpu": a.bs, "parallelism": f"prompt-sharded x{world}, weights by one RCCL broadcast",
+                       "world_size_observed": world_observed,
                        "graph": not a.no_graph},
-            "images_per_sec": round(world * a.bs * a.steps / el / a.sched_steps, 4),
+            "images_per_sec_denoise_only": round(world * a.bs * a.steps / el / a.sched_steps, 4),
             "finite": finite, "load_s": round(t_load, 1),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "parity_paths": parity, "e2e": e2e,
         }
         print(json.dumps(line))
     if dist_on:
@@ -237,11 +281,120 @@ def main():
         dist.destroy_process_group()
 
 
+def _seeded_pipeline(a, arch, sd, dev, tdt):
+    """Kandinsky2_1HIP on seeded random weights (UNet 1.23 B, prior 1.0 B, MoVQ) and the seeded stand-in conditioner: the whole
+    generate_text2img chain of kandinsky2_1_model.py:135-292 on the engines."""
+    import copy
+    if sd is None:
+        sd = k22.init_unet_state_dict(arch, seed=0)          # ranks other than 0 draw the same seeded weights themselves
+    cfg = copy.deepcopy(k22.CONFIG_2_1)
+    hp = cfg["prior"]["params"]["model"]["hparams"]
+    g = torch.Generator().manual_seed(17)
+    cfg["prior"]["clip_mean_std_path"] = (torch.randn(768, generator=g) * 0.1, torch.rand(768, generator=g) + 0.5)
+    marc = k22.MoVQArch(k22.MOVQ_CONFIG_2_1["ddconfig"])
+    cfg["image_enc_params"]["ckpt_path"] = dict(k22.init_movq_state_dict(marc, seed=0))
+    return k22.Kandinsky2_1HIP(cfg, sd, k22.init_prior_state_dict(hp, seed=0), str(dev), task_type="text2img", conditioner="seeded",
+                               backend_dtype=tdt)
+
+
+def e2e_pass(a, arch, sd, dev, tdt, dist_on, world):
+    """images/sec of Kandinsky2_1HIP.generate_text2img (prior 25 steps + decoder_steps denoise steps + MoVQ decode + crop + uint8),
+    max over ranks, plus per-phase ms measured on separate calls of the same pipeline."""
+    import torch.distributed as dist
+    pipe = _seeded_pipeline(a, arch, sd, dev, tdt)
+    prompt = "a red cat, 4k photo"
+
+    def gen():
+        return pipe.generate_text2img(prompt, num_steps=a.sched_steps, batch_size=a.bs, guidance_scale=4, h=a.size, w=a.size,
+                                      sampler="p_sampler", prior_cf_scale=4, prior_steps="25", output_type="tensor")
+    img = gen()                                   # untimed: plans, graph captures
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.e2e_images):
+        img = gen()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist_on:
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = tt.item()
+
+    def timed(fn, n=3):
+        fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n * 1e3
+    prior_ms = timed(lambda: pipe.generate_clip_emb(prompt, batch_size=a.bs, prior_cf_scale=4, prior_steps="25"))
+    lat = pipe.last_latent
+    movq_ms = timed(lambda: pipe.image_encoder.decode(lat, return_uint8=True))
+    per_image_ms = el / a.e2e_images * 1e3
+    return {"images_per_sec": round(world * a.bs * a.e2e_images / el, 4), "ms_per_call": round(per_image_ms, 2),
+            "images_timed_per_gpu": a.e2e_images * a.bs, "ok": bool(tuple(img.shape) == (a.bs, a.size, a.size, 3)),
+            "phases_ms": {"prior_25_steps": round(prior_ms, 2), "movq_decode_uint8": round(movq_ms, 2),
+                          "denoise_and_host": round(per_image_ms - prior_ms - movq_ms, 2)},
+            "what": f"Kandinsky2_1HIP.generate_text2img, {a.size}x{a.size}, bs {a.bs}/GPU, prior_steps 25, num_steps {a.sched_steps}, p_sampler, "
+                    f"{a.dtype} engines, seeded random weights + stand-in conditioning embeddings (tokenizers / text encoders are not in the timed chain)"}
+
+
+def parity_paths(m_timed, arch, sd, a, dev):
+    """The number that is timed and the number that has parity, side by side: for the timed engine and for the fp16 / fp32 engines,
+    steps/s of the 50-step p_sample_loop and the distance of its final latent from the committed REFERENCE golden
+    (tests/golden/c2_text2img.pt = reference create_model + SpacedDiffusion.p_sample_loop, fp32, same seeds and injected noise)."""
+    gpath = os.path.join(ROOT, "tests", "golden", "c2_text2img.pt")
+    if not os.path.exists(gpath):
+        return None
+    fx = torch.load(gpath, weights_only=False)
+    B, lat, steps = fx["B"], fx["lat"], fx["steps"]
+    full, pooled, image = k22.make_conditioning(arch, B, seed=2)
+    g = torch.Generator().manual_seed(42)
+    x_T = torch.randn(B, 4, lat, lat, generator=g).to(dev)
+    noise_seq = torch.randn(steps, B, 4, lat, lat, generator=g).to(dev)
+    kw = dict(full_emb=full.to(dev), pooled_emb=pooled.to(dev), image_emb=image.to(dev))
+    d = k22.create_gaussian_diffusion(**dict(k22.DIFFUSION_CONFIG_2_1, timestep_respacing=str(steps)))
+
+    def one(model):
+        model.del_cache()
+        out = None
+        for it in range(2):       # the first loop plans / captures; the second is timed
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = d.p_sample_loop(model, (B, 4, lat, lat), model_kwargs=kw, guidance_scale=fx["guidance"], noise=x_T, noise_seq=noise_seq)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+        model.del_cache()
+        dd = (out.cpu() - fx["final"]).float()
+        return {"steps_per_s": round(steps / el, 2), "final_latent_max_abs": float(f"{dd.abs().max().item():.3e}"),
+                "final_latent_rms": float(f"{dd.pow(2).mean().sqrt().item():.3e}")}
+    res = {"reference": "tests/golden/c2_text2img.pt: the reference's create_model + SpacedDiffusion.p_sample_loop (fp32), C2 shape, 50 steps, "
+                        "fixed seed, injected noise; gate of the north star: 1e-3 max-abs on the final latent",
+           a.dtype: one(m_timed)}
+    for name, dt in (("fp16", torch.float16), ("fp32", torch.float32)):
+        if name == a.dtype:
+            continue
+        mm = k22.Text2ImUNetHIP(arch, backend_dtype=dt, use_graph=not a.no_graph)
+        mm.load_state_dict(sd)
+        mm = mm.to(dev)
+        mm.prepare(free_params=True)
+        res[name] = one(mm)
+        del mm
+        torch.cuda.empty_cache()
+    return res
+
+
 def measure_roofline(m, a):
     """roofline object of the 3x3-conv class."""
     prof = m.profile(reps=3)
     conv = prof["conv3x3"]
-    peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+    peak = PEAK_F32_TFLOPS if a.dtype == "fp32" else PEAK_BF16_TFLOPS      # fp16 and bf16 MFMA run at the same dense rate
     conv_tf = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
     tot_ms = sum(v["ms"] for v in prof.values())
     tot_fl = sum(v["flops"] for v in prof.values())
@@ -299,7 +452,7 @@ def cpu_baseline(arch, sd, a, B):
             half = x[: B // 2]
             out = unet22_ref.unet22_forward(sd, cfg22, torch.cat([half, half], 0), t_first, emb, hint)
             eps = out[B // 2:, :4] + 4.0 * (out[: B // 2, :4] - out[B // 2:, :4])
-            xh = sch.step(torch.cat([eps, out[: B // 2, 4:]], 1), t_first, half, nz[: B // 2])
+            xh = sch.step(torch.cat([eps, out[: B // 2, 4:]], 1) if sch.learned else eps, t_first, half, nz[: B // 2])
             return torch.cat([xh, xh], 0)
     else:
         full, pooled, image = k22.make_conditioning(arch, B, seed=2)

@@ -29,6 +29,8 @@ extern "C" {
 
 #define K22_BF16 0 /* product path: bf16 storage, v_mfma_f32_32x32x16_bf16, fp32 accumulate */
 #define K22_F32 1  /* parity path : fp32 storage, v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain) */
+#define K22_F16 2  /* the reference's own reduced-precision mode (use_fp16 / convert_to_fp16, kandinsky2/model/unet.py:409, 566-572):
+                      fp16 storage, v_mfma_f32_32x32x16_f16, fp32 accumulate - bf16's speed and bytes, 3 more mantissa bits */
 
 int k22_version(void);
 const char* k22_last_error(void);
@@ -46,7 +48,7 @@ int k22_set_option(const char* name, int value);
  * (kandinsky2/model/model_creation.py:9-83) / CONFIG_2_1["model_config"] (kandinsky2/configs.py:125-149).
  */
 typedef struct K22UNetConfig {
-  int dtype;               /* K22_BF16 | K22_F32 */
+  int dtype;               /* K22_BF16 | K22_F32 | K22_F16 */
   int in_channels;         /* 4; 9 for the inpainting UNet (x, image*mask, mask); 8 for the 2.2 ControlNet-depth UNet (x, hint latent) */
   int model_channels;      /* 384 */
   int out_channels;        /* 8 = eps + learned variance */
@@ -177,7 +179,7 @@ int k22_sampler_step(const float* x, const float* model_out, const float* noise,
                      float* x_out, float* x0_out, int N, int HW, void* stream);
 
 /* ---- individual kernels (unit-parity surface; the engine calls the same launchers) -------------
- * dtype-typed buffers are bf16 or fp32 according to `dtype`.  Layouts: see the headers in kandinsky-2_amd/csrc. */
+ * dtype-typed buffers are bf16, fp16 or fp32 according to `dtype`.  Layouts: see the headers in kandinsky-2_amd/csrc. */
 int k22_gemm(const void* A0, const void* A1, const void* Wp, const float* bias, const void* residual, void* out,
              void* partial, int M, int N, int Npad, int K0, int K1, long lda0, long lda1, int ldo, int ldr,
              int out_f32, int act, int splitk, int bm, int bn, int dtype, void* stream);
@@ -239,7 +241,7 @@ int k22_linear_smallm(const float* x, const void* W, const float* bias, const fl
  * transformer.resblocks.<l>.attn.c_qkv.weight ...); transformer Linear weights packed T [roundup(N,64)][K] with
  * c_qkv rows re-ordered to Q | K | V planes x [head][64]; everything else fp32; plus "time_freqs" [xf_width/2]. */
 typedef struct K22PriorConfig {
-  int dtype;          /* K22_BF16 | K22_F32 */
+  int dtype;          /* K22_BF16 | K22_F32 | K22_F16 */
   int text_ctx;       /* 77 */
   int xf_width;       /* 2048 */
   int xf_layers;      /* 20 */
@@ -275,7 +277,7 @@ int k22_prior_sampler_step(const float* x, const float* model_out, const float* 
  * "decoder.mid.block_1.norm1.norm_layer.weight", ".conv_y.weight" ...); 3x3 weights packed [Npad][ky][kx][Cin]
  * (conv_in zero-extended to Cin = 64), 1x1 weights [Npad][Cin], everything else fp32 as the reference. */
 typedef struct K22MoVQConfig {
-  int dtype;           /* K22_BF16 | K22_F32 */
+  int dtype;           /* K22_BF16 | K22_F32 | K22_F16 */
   int ch;              /* 128 */
   int n_levels;        /* len(ch_mult) */
   int ch_mult[8];      /* (1, 2, 2, 4) */
@@ -324,7 +326,7 @@ int k22_movq_num_ops(const K22MoVQ* m);
  * The Linears' tile configurations come from the tile table like the other engines' (shipped for the production shapes). */
 enum { K22_ENC_CLIP_TEXT = 0, K22_ENC_CLIP_VISION = 1, K22_ENC_XLMR = 2 };
 typedef struct K22EncoderConfig {
-  int dtype;       /* K22_BF16 | K22_F32 */
+  int dtype;       /* K22_BF16 | K22_F32 | K22_F16 */
   int kind;        /* K22_ENC_* */
   int width;       /* 768 / 1024 / 1024 (64 channels per head) */
   int layers;      /* 12 / 24 / 24 */

@@ -12,7 +12,8 @@ from .prior import (PRIOR_HPARAMS_2_1, PRIOR_DIFFUSION_2_1, PriorDiffusionModelH
                     init_prior_state_dict, tiny_prior_hparams)
 from . import prestep
 from . import pipeline22
-from .unet22 import (UNET_CONFIG_2_2, DDPMSchedulerHIP, UNet2DConditionHIP, init_unet22_state_dict, make_arch22, param_shapes22,
+from .unet22 import (DDPM_SCHEDULER_DEFAULTS, SCHEDULER_CONFIG_2_2, SCHEDULER_CONFIG_2_2_LEARNED_RANGE, UNET2D_DEFAULTS, UNET_CONFIG_2_2,
+                     DDPMSchedulerHIP, UNet2DConditionHIP, init_unet22_state_dict, make_arch22, param_shapes22, resolve_unet22_config,
                      tiny_unet22_config)
 from .pipeline import (CONFIG_2_1, Kandinsky2_1HIP, ReferenceConditioner, SeededConditioner, get_kandinsky2, prepare_image,
                        process_images)
@@ -29,7 +30,8 @@ __all__ = [
     "init_prior_state_dict", "tiny_prior_hparams",
     "MOVQ_CONFIG_2_1", "MoVQArch", "MoVQDecoderHIP", "MoVQEncoderHIP", "movq_param_shapes", "init_movq_state_dict",
     "movq_encoder_param_shapes", "init_movq_encoder_state_dict", "prestep",
-    "UNET_CONFIG_2_2", "DDPMSchedulerHIP", "UNet2DConditionHIP", "init_unet22_state_dict", "make_arch22", "param_shapes22", "tiny_unet22_config",
+    "UNET_CONFIG_2_2", "UNET2D_DEFAULTS", "DDPM_SCHEDULER_DEFAULTS", "SCHEDULER_CONFIG_2_2", "SCHEDULER_CONFIG_2_2_LEARNED_RANGE",
+    "resolve_unet22_config", "DDPMSchedulerHIP", "UNet2DConditionHIP", "init_unet22_state_dict", "make_arch22", "param_shapes22", "tiny_unet22_config",
     "CLIP_VITL14", "XLMR_LARGE", "CLIPModelHIP", "HIPConditioner", "MultilingualCLIPHIP", "TextEncoderHIP", "clip_param_shapes",
     "init_clip_state_dict", "init_multiclip_state_dict", "multiclip_param_shapes", "tiny_clip_config", "tiny_xlmr_config",
     "CONFIG_2_1", "Kandinsky2_1HIP", "ReferenceConditioner", "SeededConditioner", "get_kandinsky2", "prepare_image", "process_images",

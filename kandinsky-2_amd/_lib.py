@@ -15,7 +15,17 @@ LIB_PATH = os.path.join(_HERE, "libk22hip.so")
 # K22_TILE_TABLE=<file> substitutes another table, K22_TILE_TABLE=0 starts with an empty one.
 TILE_TABLE_PATH = os.path.join(_HERE, "tiles_gfx950.txt")
 
-K22_BF16, K22_F32 = 0, 1
+K22_BF16, K22_F32, K22_F16 = 0, 1, 2
+
+
+def dtype_code(backend_dtype) -> int:
+    """torch dtype of an engine's storage / MFMA operand type -> K22DType: bfloat16 (product path), float16 (the reference's own
+    use_fp16 mode: same speed, 3 more mantissa bits), float32 (parity path, exact-fp32 MFMA)."""
+    import torch
+    try:
+        return {torch.bfloat16: K22_BF16, torch.float32: K22_F32, torch.float16: K22_F16}[backend_dtype]
+    except KeyError:
+        raise ValueError("backend_dtype must be torch.bfloat16, torch.float16 or torch.float32") from None
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 OUT_ROWMAJOR, OUT_ROWMAJOR_F32, OUT_NCHW_F32 = 0, 1, 2
 

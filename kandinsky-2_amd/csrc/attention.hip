@@ -22,6 +22,12 @@ __device__ __forceinline__ void ld_frag_split(Frag<bf16_t>& f, const char* tile,
   const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(tile + lds_chunk_off(r, 2 * a + 1) + 8 * h);
   f.v = u32x4_t{lo.x, lo.y, hi.x, hi.y};
 }
+__device__ __forceinline__ void ld_frag_split(Frag<f16_t>& f, const char* tile, int r, int a, int h) {
+  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+  const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(tile + lds_chunk_off(r, 2 * a) + 8 * h);
+  const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(tile + lds_chunk_off(r, 2 * a + 1) + 8 * h);
+  f.v = u32x4_t{lo.x, lo.y, hi.x, hi.y};
+}
 __device__ __forceinline__ void ld_frag_split(Frag<float>& f, const char* tile, int r, int a, int h) {
   const char* sub = tile + (a >> 1) * 8192;
   const int al = a & 1;
@@ -36,11 +42,15 @@ __device__ __forceinline__ void make_pfrag(Frag<bf16_t>& f, const float* p) {
                 pack2_bf16(p[4], p[5]),
                 pack2_bf16(p[6], p[7])};
 }
+__device__ __forceinline__ void make_pfrag(Frag<f16_t>& f, const float* p) {
+  f.v = u32x4_t{pack2_f16(p[0], p[1]), pack2_f16(p[2], p[3]), pack2_f16(p[4], p[5]), pack2_f16(p[6], p[7])};
+}
 __device__ __forceinline__ void make_pfrag(Frag<float>& f, const float* p) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) f.v[j] = p[j];
 }
 __device__ __forceinline__ void ld_qfrag(Frag<bf16_t>& f, const bf16_t* p) { f.v = *reinterpret_cast<const u32x4_t*>(p); }
+__device__ __forceinline__ void ld_qfrag(Frag<f16_t>& f, const f16_t* p) { f.v = *reinterpret_cast<const u32x4_t*>(p); }
 __device__ __forceinline__ void ld_qfrag(Frag<float>& f, const float* p) {
   const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
   f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
@@ -50,6 +60,7 @@ __device__ __forceinline__ void ld_qfrag(Frag<float>& f, const float* p) {
 // far below bf16 resolution of the probabilities), the fp32 parity path the accurate exp2f.
 template <typename T> __device__ __forceinline__ float exp2_t(float x);
 template <> __device__ __forceinline__ float exp2_t<bf16_t>(float x) { return __builtin_amdgcn_exp2f(x); }
+template <> __device__ __forceinline__ float exp2_t<f16_t>(float x) { return __builtin_amdgcn_exp2f(x); }
 template <> __device__ __forceinline__ float exp2_t<float>(float x) { return exp2f(x); }
 
 // The online softmax is the issue-bound part of this kernel (measured at T = 2304: waves ISSUING 49 % of their cycles,
@@ -213,8 +224,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttentionParams p) {
         const int d = db * 32 + 8 * g + 4 * h;
         if constexpr (sizeof(T) == 2) {
           uint2 w;
-          w.x = pack2_bf16(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
-          w.y = pack2_bf16(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+          w.x = pack2<T>(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
+          w.y = pack2<T>(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
           *reinterpret_cast<uint2*>(orow + d) = w;
         } else {
           *reinterpret_cast<float4*>(orow + d) =
@@ -228,6 +239,7 @@ int launch_attention(const AttentionParams& p, int dtype, hipStream_t s) {
   if (p.Tkp % 64 || p.Tkp < p.Tk) return k22_set_error(K22_EINVAL, "attention: Tkp must be roundup(Tk,64)");
   dim3 grid((p.T + 127) / 128, p.H, p.B);
   if (dtype == K22_BF16) hipLaunchKernelGGL(attention_kernel<bf16_t>, grid, dim3(256), 0, s, p);
+  else if (dtype == K22_F16) hipLaunchKernelGGL(attention_kernel<f16_t>, grid, dim3(256), 0, s, p);
   else if (dtype == K22_F32) hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(256), 0, s, p);
   else return k22_set_error(K22_EINVAL, "attention: bad dtype");
   K22_CHECK_LAUNCH();

@@ -1,8 +1,9 @@
 // k22 — MI355X (gfx950 / CDNA4) native Kandinsky-2 sampling engine: shared device helpers.
 //
-// Element types: the torso of the UNet runs either in bf16 (product path; MFMA
-// v_mfma_f32_32x32x16_bf16) or in fp32 (parity path; v_mfma_f32_32x32x2_f32, exact
-// fp32 FMA chain).  Both paths share one kernel structure: every LDS tile row is 128
+// Element types: the torso of the UNet runs in bf16 (product path; MFMA v_mfma_f32_32x32x16_bf16), in fp16 (the reference's own
+// reduced-precision mode, use_fp16 / convert_to_fp16 - kandinsky2/model/unet.py:409,566-572; v_mfma_f32_32x32x16_f16: the same
+// rate and the same bytes as bf16 with 3 more mantissa bits) or in fp32 (parity path; v_mfma_f32_32x32x2_f32, exact
+// fp32 FMA chain).  All paths share one kernel structure: every LDS tile row is 128
 // bytes = 8 chunks of 16 B, and an "atom" is a 32x32x16 matrix product whose A/B
 // fragments are 8 consecutive K elements per lane.
 #pragma once
@@ -10,12 +11,19 @@
 #include <stdint.h>
 
 typedef unsigned short bf16_t;  // bf16 storage type
+typedef _Float16 f16_t;         // fp16 storage type (IEEE binary16)
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
-enum K22DType { K22_BF16 = 0, K22_F32 = 1 };
+enum K22DType { K22_BF16 = 0, K22_F32 = 1, K22_F16 = 2 };
+// bytes per element / elements per 128-byte LDS row of a storage type code
+inline int k22_esz(int dtype) { return dtype == K22_F32 ? 4 : 2; }
+inline int k22_bk(int dtype) { return dtype == K22_F32 ? 32 : 64; }
+inline bool k22_dtype_ok(int dtype) { return dtype == K22_BF16 || dtype == K22_F32 || dtype == K22_F16; }
 enum K22Act { K22_ACT_NONE = 0, K22_ACT_SILU = 1, K22_ACT_GELU = 2 };
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
@@ -28,10 +36,31 @@ __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack2_bf16(f, 0.f) & 0xffffu); }
+// fp32 pair -> packed fp16 pair, round-to-nearest-even (v_cvt_f16_f32 x2 + pack; NOT v_cvt_pkrtz, which truncates)
+__device__ __forceinline__ uint32_t pack2_f16(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+__device__ __forceinline__ void unpack2_f16(uint32_t w, float& lo, float& hi) {
+  const f16x2_t v = __builtin_bit_cast(f16x2_t, w);
+  lo = (float)v[0]; hi = (float)v[1];
+}
+__device__ __forceinline__ void unpack2_bf16(uint32_t w, float& lo, float& hi) {
+  lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u);
+}
+// packed pair of a 16-bit storage type <-> two floats
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float lo, float hi) { return pack2_bf16(lo, hi); }
+template <> __device__ __forceinline__ uint32_t pack2<f16_t>(float lo, float hi) { return pack2_f16(lo, hi); }
+template <typename T> __device__ __forceinline__ void unpack2(uint32_t w, float& lo, float& hi);
+template <> __device__ __forceinline__ void unpack2<bf16_t>(uint32_t w, float& lo, float& hi) { unpack2_bf16(w, lo, hi); }
+template <> __device__ __forceinline__ void unpack2<f16_t>(uint32_t w, float& lo, float& hi) { unpack2_f16(w, lo, hi); }
 __device__ __forceinline__ float to_f32(bf16_t v) { return bf16_to_f32(v); }
+__device__ __forceinline__ float to_f32(f16_t v) { return (float)v; }
 __device__ __forceinline__ float to_f32(float v) { return v; }
 template <typename T> __device__ __forceinline__ T from_f32(float f);
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float f) { return f32_to_bf16(f); }
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float f) { return (f16_t)f; }
 template <> __device__ __forceinline__ float from_f32<float>(float f) { return f; }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
@@ -49,6 +78,7 @@ template <> struct TT<bf16_t> {
   static constexpr int EPC = 8;      // elements per 16-byte chunk
   static constexpr int KSTEPS = 4;   // 32x32x16 atoms per LDS row
 };
+template <> struct TT<f16_t> : TT<bf16_t> {};
 template <> struct TT<float> {
   static constexpr int BK = 32;
   static constexpr int EPC = 4;
@@ -58,6 +88,7 @@ template <> struct TT<float> {
 // A/B fragment of one 32x32x16 atom: 8 consecutive K elements of one row.
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { u32x4_t v; };
+template <> struct Frag<f16_t> { u32x4_t v; };
 template <> struct Frag<float> { float v[8]; };
 
 // Swizzled LDS tile: row r (128 B), logical chunk c (16 B) lives at physical chunk c ^ ((r >> 1) & 7).
@@ -69,6 +100,9 @@ __device__ __forceinline__ int lds_chunk_off(int r, int c) { return r * 128 + ((
 
 // lane-half h (= lane>>5) reads K elements [16*ks + 8*h, +8) of row r.
 __device__ __forceinline__ void ld_frag(Frag<bf16_t>& f, const char* tile, int r, int ks, int h) {
+  f.v = *reinterpret_cast<const u32x4_t*>(tile + lds_chunk_off(r, 2 * ks + h));
+}
+__device__ __forceinline__ void ld_frag(Frag<f16_t>& f, const char* tile, int r, int ks, int h) {
   f.v = *reinterpret_cast<const u32x4_t*>(tile + lds_chunk_off(r, 2 * ks + h));
 }
 __device__ __forceinline__ void ld_frag(Frag<float>& f, const char* tile, int r, int ks, int h) {
@@ -83,6 +117,9 @@ __device__ __forceinline__ void ld_frag(Frag<float>& f, const char* tile, int r,
 __device__ __forceinline__ void mma_atom(f32x16_t& acc, const Frag<bf16_t>& a, const Frag<bf16_t>& b) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a.v), __builtin_bit_cast(bf16x8_t, b.v),
                                                 acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_atom(f32x16_t& acc, const Frag<f16_t>& a, const Frag<f16_t>& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a.v), __builtin_bit_cast(f16x8_t, b.v), acc, 0, 0, 0);
 }
 __device__ __forceinline__ void mma_atom(f32x16_t& acc, const Frag<float>& a, const Frag<float>& b) {
   // 8 exact-fp32 MFMAs (K=2 each): call j pairs element j of lane-half 0 with element j of lane-half 1.
@@ -147,6 +184,15 @@ template <> struct Vec16<bf16_t> {
   __device__ __forceinline__ void set2(int pair, float lo, float hi) {
     (&raw.x)[pair] = pack2_bf16(lo, hi);
   }
+};
+template <> struct Vec16<f16_t> {
+  static constexpr int N = 8;
+  uint4 raw;
+  __device__ __forceinline__ float get(int i) const {
+    const f16x2_t v = __builtin_bit_cast(f16x2_t, (&raw.x)[i >> 1]);
+    return (float)v[i & 1];
+  }
+  __device__ __forceinline__ void set2(int pair, float lo, float hi) { (&raw.x)[pair] = pack2_f16(lo, hi); }
 };
 template <> struct Vec16<float> {
   static constexpr int N = 4;

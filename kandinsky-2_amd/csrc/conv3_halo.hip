@@ -39,6 +39,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 __device__ __forceinline__ void ld_frag_at(Frag<bf16_t>& f, const char* rowp, int sw, int ks, int h) {
   f.v = *reinterpret_cast<const u32x4_t*>(rowp + (((2 * ks + h) ^ sw) << 4));
 }
+__device__ __forceinline__ void ld_frag_at(Frag<f16_t>& f, const char* rowp, int sw, int ks, int h) {
+  f.v = *reinterpret_cast<const u32x4_t*>(rowp + (((2 * ks + h) ^ sw) << 4));
+}
 __device__ __forceinline__ void ld_frag_at(Frag<float>& f, const char* rowp, int sw, int ks, int h) {
   const float4 a = *reinterpret_cast<const float4*>(rowp + (((4 * ks + 2 * h) ^ sw) << 4));
   const float4 b = *reinterpret_cast<const float4*>(rowp + (((4 * ks + 2 * h + 1) ^ sw) << 4));
@@ -55,6 +58,14 @@ template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* dst, const fl
   w.w = pack2_bf16(v[6], v[7]);
   *reinterpret_cast<uint4*>(dst) = w;
 }
+template <> __device__ __forceinline__ void store8<f16_t>(f16_t* dst, const float* v) {
+  uint4 w;
+  w.x = pack2_f16(v[0], v[1]);
+  w.y = pack2_f16(v[2], v[3]);
+  w.z = pack2_f16(v[4], v[5]);
+  w.w = pack2_f16(v[6], v[7]);
+  *reinterpret_cast<uint4*>(dst) = w;
+}
 template <> __device__ __forceinline__ void store8<float>(float* dst, const float* v) {
   *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
   *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -67,6 +78,10 @@ template <> __device__ __forceinline__ void load8f<bf16_t>(const bf16_t* src, fl
   v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
   v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
 }
+template <> __device__ __forceinline__ void load8f<f16_t>(const f16_t* src, float* v) {
+  const uint4 r = *reinterpret_cast<const uint4*>(src);
+  unpack2_f16(r.x, v[0], v[1]); unpack2_f16(r.y, v[2], v[3]); unpack2_f16(r.z, v[4], v[5]); unpack2_f16(r.w, v[6], v[7]);
+}
 template <> __device__ __forceinline__ void load8f<float>(const float* src, float* v) {
   const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
@@ -74,6 +89,7 @@ template <> __device__ __forceinline__ void load8f<float>(const float* src, floa
 // value as it will be read back from memory (the GroupNorm statistics are those of the stored tensor)
 template <typename T> __device__ __forceinline__ float stored(float v);
 template <> __device__ __forceinline__ float stored<bf16_t>(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+template <> __device__ __forceinline__ float stored<f16_t>(float v) { return (float)(f16_t)v; }
 template <> __device__ __forceinline__ float stored<float>(float v) { return v; }
 
 __device__ __forceinline__ int xcd_remap_h(int bid, int nblocks) {
@@ -588,6 +604,8 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const IgemmParams p) {
             _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], b[ni], a[mi]);         \
           }                                                                                                \
         }                                                                                                  \
+        /* no fragment read of this tap's weight slot in flight when the slot is refilled after the next barrier */ \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
         }                                                                                                  \
         if constexpr (TRACE) {                                                                             \
           /* stamp after the last MFMA has been ISSUED (issue blocks while the pipe is busy) */            \
@@ -836,10 +854,11 @@ __global__ __launch_bounds__(512) void conv3_halo_spec_kernel(const IgemmParams 
               _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], b[ni], a[mi]);       \
           }                                                                                                \
           }                                                                                                \
-          /* Fragment reads may not stay in flight across the next barrier when the producers refill what they read right    \
-             after it: with a 2-deep ring that is THIS tap's weight slot, and after tap 8 the halo buffer of the slab before. \
-             (The MFMAs that use them can sink below the barrier - registers only - in both forms.) */                      \
-          if constexpr (NBST == 2 || (TAP) == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        \
+          /* Fragment reads may not stay in flight across the next barrier: right after barrier TAP+1 the producers refill    \
+             slot (TAP + NBST) % NBST = the weight slot THIS tap read, whatever the ring depth (and after tap 8 the halo buffer \
+             of the slab before).  Only the DMA's latency kept the NBST >= 3 forms correct in round 2; now nothing is left to   \
+             timing.  (The MFMAs that use the fragments can still sink below the barrier - registers only - in both forms.) */  \
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
           cur = (cur + 1 == NBST) ? 0 : cur + 1;                                                           \
         }
         K22_SP_CTAP(0) K22_SP_CTAP(1) K22_SP_CTAP(2) K22_SP_CTAP(3) K22_SP_CTAP(4) K22_SP_CTAP(5) K22_SP_CTAP(6) K22_SP_CTAP(7) K22_SP_CTAP(8)
@@ -992,6 +1011,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const IgemmParams p) {
 // ================================================================================================================
 namespace {
 __device__ __forceinline__ void ld_frag64(Frag<bf16_t>& f, const char* rowp, int sw, int ks, int h) {
+  f.v = *reinterpret_cast<const u32x4_t*>(rowp + (((2 * ks + h) ^ sw) << 4));
+}
+__device__ __forceinline__ void ld_frag64(Frag<f16_t>& f, const char* rowp, int sw, int ks, int h) {
   f.v = *reinterpret_cast<const u32x4_t*>(rowp + (((2 * ks + h) ^ sw) << 4));
 }
 __device__ __forceinline__ void ld_frag64(Frag<float>& f, const char* rowp, int sw, int /*ks == 0*/, int h) {
@@ -1438,7 +1460,7 @@ static size_t gemm8_smem_bytes(int bm, int nst) {
 int gemm8_tiles_per_image(const IgemmParams& p, int bm) { return ((p.H > 0 ? p.H * p.W : p.M) + bm - 1) / bm; }
 
 bool gemm8_supported(const IgemmParams& p, int dtype, int bm) {
-  const int BK = (dtype == K22_BF16) ? 64 : 32;
+  const int BK = (dtype == K22_F32) ? 32 : 64;
   if (p.taps != 1 || (bm != 256 && bm != 128) || p.N < 128) return false;
   if (p.K0 != p.Kc || p.S0 != nullptr || p.res_f32) return false;          // one A operand, no fused skip, T residual
   if (p.out_mode != IG_OUT_ROWMAJOR && p.out_mode != IG_OUT_ROWMAJOR_F32 && p.out_mode != IG_OUT_QKV) return false;
@@ -1472,12 +1494,16 @@ int launch_gemm8(const IgemmParams& p, int dtype, int bm, int splitk, hipStream_
     if (bm == 256) return launch_gemm8_cfg<bf16_t, 256, 3>(p, splitk, stream);
     return nst == 2 ? launch_gemm8_cfg<bf16_t, 128, 2>(p, splitk, stream) : launch_gemm8_cfg<bf16_t, 128, 4>(p, splitk, stream);
   }
+  if (dtype == K22_F16) {
+    if (bm == 256) return launch_gemm8_cfg<f16_t, 256, 3>(p, splitk, stream);
+    return nst == 2 ? launch_gemm8_cfg<f16_t, 128, 2>(p, splitk, stream) : launch_gemm8_cfg<f16_t, 128, 4>(p, splitk, stream);
+  }
   if (bm == 256) return launch_gemm8_cfg<float, 256, 3>(p, splitk, stream);
   return nst == 2 ? launch_gemm8_cfg<float, 128, 2>(p, splitk, stream) : launch_gemm8_cfg<float, 128, 4>(p, splitk, stream);
 }
 
 bool conv3_halo_supported(const IgemmParams& p, int dtype, int bm) {
-  const int BK = (dtype == K22_BF16) ? 64 : 32;
+  const int BK = (dtype == K22_F32) ? 32 : 64;
   if (p.taps != 9 || (bm != 256 && bm != 128)) return false;
   if (p.out_mode != IG_OUT_ROWMAJOR && p.out_mode != IG_OUT_ROWMAJOR_F32) return false;
   if (p.N % 8 || p.ldo % 8 || (p.residual && p.ldr % 8) || p.Kc % BK) return false;
@@ -1602,7 +1628,7 @@ int launch_conv3_halo_trace(const IgemmParams& p, int dtype, hipStream_t stream)
 // 5 the 128-byte-row kernel with loader-wave specialisation, anything else the symmetric 128-byte-row one.
 int launch_conv3_halo(const IgemmParams& p, int dtype, int bm, int splitk, hipStream_t stream) {
   if (!conv3_halo_supported(p, dtype, bm)) return k22_set_error(K22_EINVAL, "conv3_halo: unsupported problem");
-  if (p.algo == 4) {
+  if (p.algo == 4 && dtype != K22_F16) {   // (fp16: not instantiated - never a tuner candidate; the default kernel below)
     int nbst = halo4_pick_nbst(p, bm);
     if (p.stages >= 2 && p.stages < nbst) nbst = p.stages;
     if (dtype == K22_BF16) return bm == 256 ? launch_halo4_nbst<bf16_t, 256>(p, nbst, splitk, stream) : launch_halo4_nbst<bf16_t, 128>(p, nbst, splitk, stream);
@@ -1612,41 +1638,53 @@ int launch_conv3_halo(const IgemmParams& p, int dtype, int bm, int splitk, hipSt
     int rb = halo3_pick_rb(p, bm);
     if (p.stages >= 2 && p.stages < rb) rb = p.stages;
     if (dtype == K22_BF16) return bm == 256 ? launch_halo3_rb<bf16_t, 256>(p, rb, splitk, stream) : launch_halo3_rb<bf16_t, 128>(p, rb, splitk, stream);
+    else if (dtype == K22_F16) return bm == 256 ? launch_halo3_rb<f16_t, 256>(p, rb, splitk, stream) : launch_halo3_rb<f16_t, 128>(p, rb, splitk, stream);
     return bm == 256 ? launch_halo3_rb<float, 256>(p, rb, splitk, stream) : launch_halo3_rb<float, 128>(p, rb, splitk, stream);
   }
   int nbst = halo_pick_nbst(p, bm);
   if (p.stages >= 2 && p.stages < nbst) nbst = p.stages == 5 ? 4 : p.stages;  // tuning knob: shallower ring on request
   if (p.algo == 11) {  // producer / consumer wave specialisation (conv3_halo_spec_kernel), compiler-scheduled consumers
     if (dtype == K22_BF16) return bm == 256 ? launch_halo_spec_nbst<bf16_t, 256, false>(p, nbst, splitk, stream) : launch_halo_spec_nbst<bf16_t, 128, false>(p, nbst, splitk, stream);
+    else if (dtype == K22_F16) return bm == 256 ? launch_halo_spec_nbst<f16_t, 256, false>(p, nbst, splitk, stream) : launch_halo_spec_nbst<f16_t, 128, false>(p, nbst, splitk, stream);
     return bm == 256 ? launch_halo_spec_nbst<float, 256, false>(p, nbst, splitk, stream) : launch_halo_spec_nbst<float, 128, false>(p, nbst, splitk, stream);
   }
   if (p.algo == 12) {  // the same with the explicit, interleaved fragment pipeline in the consumers
     if (dtype == K22_BF16) return bm == 256 ? launch_halo_spec_nbst<bf16_t, 256, true>(p, nbst, splitk, stream) : launch_halo_spec_nbst<bf16_t, 128, true>(p, nbst, splitk, stream);
+    else if (dtype == K22_F16) return bm == 256 ? launch_halo_spec_nbst<f16_t, 256, true>(p, nbst, splitk, stream) : launch_halo_spec_nbst<f16_t, 128, true>(p, nbst, splitk, stream);
     // fp32, BM = 256: two fragment sets of 8 registers per fragment do not fit beside 128 accumulators (the pipelined form spills):
     // the compiler-scheduled consumer is used there
     return bm == 256 ? launch_halo_spec_nbst<float, 256, false>(p, nbst, splitk, stream) : launch_halo_spec_nbst<float, 128, true>(p, nbst, splitk, stream);
   }
+#ifdef K22_DEBUG_VARIANTS   // measurement-only kernels (wrong results) are compiled only into a developer build: make CXXFLAGS+=-DK22_DEBUG_VARIANTS
   if (p.algo == 13 || p.algo == 14) {  // measurement-only forms of algo 12 (wrong results): 13 = no LDS-DMA inside the tap loop, 14 = LDS-DMA issued but never waited for
     if (dtype != K22_BF16 || bm != 256) return k22_set_error(K22_EINVAL, "conv3_halo: the debug variants are bf16, BM = 256 only");
     if (p.algo == 13) return nbst == 2 ? launch_halo_spec_cfg<bf16_t, 256, 2, true, 1>(p, splitk, stream) : launch_halo_spec_cfg<bf16_t, 256, 4, true, 1>(p, splitk, stream);
     return nbst == 2 ? launch_halo_spec_cfg<bf16_t, 256, 2, true, 2>(p, splitk, stream) : launch_halo_spec_cfg<bf16_t, 256, 4, true, 2>(p, splitk, stream);
   }
-  if (p.algo == 5) {  // loader-wave specialisation (waves 0-3 issue all LDS-DMA)
+#else
+  if (p.algo == 13 || p.algo == 14 || p.algo == 8 || p.algo == 9) return k22_set_error(K22_EINVAL, "conv3_halo: measurement-only variants need a -DK22_DEBUG_VARIANTS build");
+#endif
+  if (p.algo == 5 && dtype != K22_F16) {  // loader-wave specialisation (waves 0-3 issue all LDS-DMA)
     if (dtype == K22_BF16) return bm == 256 ? launch_halo_nbst<bf16_t, 256, 4, 0>(p, nbst, splitk, stream) : launch_halo_nbst<bf16_t, 128, 4, 0>(p, nbst, splitk, stream);
     return bm == 256 ? launch_halo_nbst<float, 256, 4, 0>(p, nbst, splitk, stream) : launch_halo_nbst<float, 128, 4, 0>(p, nbst, splitk, stream);
   }
   if (p.algo == 6) {  // explicit fragment pipeline across the barrier + asm LDS-DMA
     if (dtype == K22_BF16) return bm == 256 ? launch_halo_nbst<bf16_t, 256, 8, 1>(p, nbst, splitk, stream) : launch_halo_nbst<bf16_t, 128, 8, 1>(p, nbst, splitk, stream);
+    else if (dtype == K22_F16) return bm == 256 ? launch_halo_nbst<f16_t, 256, 8, 1>(p, nbst, splitk, stream) : launch_halo_nbst<f16_t, 128, 8, 1>(p, nbst, splitk, stream);
     return bm == 256 ? launch_halo_nbst<float, 256, 8, 1>(p, nbst, splitk, stream) : launch_halo_nbst<float, 128, 8, 1>(p, nbst, splitk, stream);
   }
+#ifdef K22_DEBUG_VARIANTS
   if (p.algo == 8 || p.algo == 9) {  // measurement-only variants (wrong results): 8 = no LDS-DMA in the loop, 9 = no MFMA
     if (dtype != K22_BF16 || bm != 256) return k22_set_error(K22_EINVAL, "conv3_halo: debug variants are bf16, BM = 256 only");
     return p.algo == 8 ? launch_halo_nbst<bf16_t, 256, 8, 3>(p, nbst, splitk, stream) : launch_halo_nbst<bf16_t, 256, 8, 4>(p, nbst, splitk, stream);
   }
+#endif
   if (p.algo == 7) {  // compiler schedule + asm LDS-DMA
     if (dtype == K22_BF16) return bm == 256 ? launch_halo_nbst<bf16_t, 256, 8, 2>(p, nbst, splitk, stream) : launch_halo_nbst<bf16_t, 128, 8, 2>(p, nbst, splitk, stream);
+    else if (dtype == K22_F16) return bm == 256 ? launch_halo_nbst<f16_t, 256, 8, 2>(p, nbst, splitk, stream) : launch_halo_nbst<f16_t, 128, 8, 2>(p, nbst, splitk, stream);
     return bm == 256 ? launch_halo_nbst<float, 256, 8, 2>(p, nbst, splitk, stream) : launch_halo_nbst<float, 128, 8, 2>(p, nbst, splitk, stream);
   }
   if (dtype == K22_BF16) return bm == 256 ? launch_halo_nbst<bf16_t, 256, 8, 0>(p, nbst, splitk, stream) : launch_halo_nbst<bf16_t, 128, 8, 0>(p, nbst, splitk, stream);
+  else if (dtype == K22_F16) return bm == 256 ? launch_halo_nbst<f16_t, 256, 8, 0>(p, nbst, splitk, stream) : launch_halo_nbst<f16_t, 128, 8, 0>(p, nbst, splitk, stream);
   return bm == 256 ? launch_halo_nbst<float, 256, 8, 0>(p, nbst, splitk, stream) : launch_halo_nbst<float, 128, 8, 0>(p, nbst, splitk, stream);
 }

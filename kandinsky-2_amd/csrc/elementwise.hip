@@ -19,6 +19,10 @@ __device__ __forceinline__ void load4(const bf16_t* p, float* f) {
   f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
   f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
 }
+__device__ __forceinline__ void load4(const f16_t* p, float* f) {
+  const uint2 r = *reinterpret_cast<const uint2*>(p);
+  unpack2_f16(r.x, f[0], f[1]); unpack2_f16(r.y, f[2], f[3]);
+}
 __device__ __forceinline__ void load4(const float* p, float* f) {
   const float4 r = *reinterpret_cast<const float4*>(p);
   f[0] = r.x; f[1] = r.y; f[2] = r.z; f[3] = r.w;
@@ -628,6 +632,7 @@ int launch_gn_stats(const GnStatsParams& p, int dtype, hipStream_t s) {
   if (C / 4 < 256 && (256 / (C / 4)) * C > 2048) return k22_set_error(K22_EINVAL, "gn_stats: internal LDS bound");
   dim3 grid(p.nsplit, p.B);
   if (dtype == K22_BF16) hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), 0, s, p);
+  else if (dtype == K22_F16) hipLaunchKernelGGL(gn_stats_kernel<f16_t>, grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, s, p);
   K22_CHECK_LAUNCH();
   return K22_OK;
@@ -640,7 +645,7 @@ int launch_gn_coeff(const GnCoeffParams& p, int B, hipStream_t s) {
 }
 int launch_gn_apply(const GnApplyParams& p, int dtype, hipStream_t s) {
   const int C = p.C0 + p.C1;
-  const int epv = dtype == K22_BF16 ? 8 : 4;
+  const int epv = dtype == K22_F32 ? 4 : 8;
   if (C % epv || p.C0 % epv) return k22_set_error(K22_EINVAL, "gn_apply: channel alignment");
   const int Ho = p.mode == 1 ? p.H / 2 : (p.mode == 2 ? p.H * 2 : p.H);
   const int Wo = p.mode == 1 ? p.W / 2 : (p.mode == 2 ? p.W * 2 : p.W);
@@ -648,18 +653,19 @@ int launch_gn_apply(const GnApplyParams& p, int dtype, hipStream_t s) {
   if (Hp > 65535 || p.B > 65535) return k22_set_error(K22_EINVAL, "gn_apply: tensor too large");
   dim3 grid((Wp * (C / epv) + 255) / 256, Hp, p.B);
   if (dtype == K22_BF16) hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, p);
+  else if (dtype == K22_F16) hipLaunchKernelGGL(gn_apply_kernel<f16_t>, grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, p);
   K22_CHECK_LAUNCH();
   return K22_OK;
 }
 bool gn_apply3_supported(int C, int dtype) {
-  const int epv = dtype == K22_BF16 ? 8 : 4;
+  const int epv = dtype == K22_F32 ? 4 : 8;
   return C % 32 == 0 && C / 32 >= epv && (C / 32) % 1 == 0 && C % epv == 0;
 }
 int launch_gn_apply3(const GnApply3Params& q, int dtype, hipStream_t s) {
   const GnApplyParams& p = q.a;
   const int C = p.C0;
-  const int epv = dtype == K22_BF16 ? 8 : 4;
+  const int epv = dtype == K22_F32 ? 4 : 8;
   if (p.C1 != 0 || p.x1 != nullptr || !gn_apply3_supported(C, dtype) || q.gsum == nullptr)
     return k22_set_error(K22_EINVAL, "gn_apply3: one source tensor with C/32 >= 8 (bf16) / 4 (fp32) channels per group");
   const int Ho = p.mode == 1 ? p.H / 2 : (p.mode == 2 ? p.H * 2 : p.H);
@@ -671,6 +677,9 @@ int launch_gn_apply3(const GnApply3Params& q, int dtype, hipStream_t s) {
   if (dtype == K22_BF16) {
     if (pool) hipLaunchKernelGGL((gn_apply3_kernel<bf16_t, true>), grid, dim3(256), 0, s, q);
     else hipLaunchKernelGGL((gn_apply3_kernel<bf16_t, false>), grid, dim3(256), 0, s, q);
+  } else if (dtype == K22_F16) {
+    if (pool) hipLaunchKernelGGL((gn_apply3_kernel<f16_t, true>), grid, dim3(256), 0, s, q);
+    else hipLaunchKernelGGL((gn_apply3_kernel<f16_t, false>), grid, dim3(256), 0, s, q);
   } else {
     if (pool) hipLaunchKernelGGL((gn_apply3_kernel<float, true>), grid, dim3(256), 0, s, q);
     else hipLaunchKernelGGL((gn_apply3_kernel<float, false>), grid, dim3(256), 0, s, q);
@@ -679,10 +688,11 @@ int launch_gn_apply3(const GnApply3Params& q, int dtype, hipStream_t s) {
   return K22_OK;
 }
 int launch_resample(const void* x, void* y, int B, int H, int W, int C, int mode, int dtype, hipStream_t s) {
-  const int epv = dtype == K22_BF16 ? 8 : 4;
+  const int epv = dtype == K22_F32 ? 4 : 8;
   const int Ho = mode == 1 ? H / 2 : H * 2, Wo = mode == 1 ? W / 2 : W * 2;
   const int nb = grid_for((int64_t)B * Ho * Wo * (C / epv), 256, 8192);
   if (dtype == K22_BF16) hipLaunchKernelGGL(resample_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, x, y, B, H, W, C, mode);
+  else if (dtype == K22_F16) hipLaunchKernelGGL(resample_kernel<f16_t>, dim3(nb), dim3(256), 0, s, x, y, B, H, W, C, mode);
   else hipLaunchKernelGGL(resample_kernel<float>, dim3(nb), dim3(256), 0, s, x, y, B, H, W, C, mode);
   K22_CHECK_LAUNCH();
   return K22_OK;
@@ -691,12 +701,15 @@ int launch_conv_in(const ConvInParams& p, int dtype, hipStream_t s) {
   dim3 grid((p.W + CONV_IN_PT - 1) / CONV_IN_PT, p.H, p.B);
   if (p.Cin == 4) {
     if (dtype == K22_BF16) hipLaunchKernelGGL((conv_in_kernel<bf16_t, 4>), grid, dim3(128), 0, s, p);
+    else if (dtype == K22_F16) hipLaunchKernelGGL((conv_in_kernel<f16_t, 4>), grid, dim3(128), 0, s, p);
     else hipLaunchKernelGGL((conv_in_kernel<float, 4>), grid, dim3(128), 0, s, p);
   } else if (p.Cin == 9) {
     if (dtype == K22_BF16) hipLaunchKernelGGL((conv_in_kernel<bf16_t, 9>), grid, dim3(128), 0, s, p);
+    else if (dtype == K22_F16) hipLaunchKernelGGL((conv_in_kernel<f16_t, 9>), grid, dim3(128), 0, s, p);
     else hipLaunchKernelGGL((conv_in_kernel<float, 9>), grid, dim3(128), 0, s, p);
   } else if (p.Cin == 8) {
     if (dtype == K22_BF16) hipLaunchKernelGGL((conv_in_kernel<bf16_t, 8>), grid, dim3(128), 0, s, p);
+    else if (dtype == K22_F16) hipLaunchKernelGGL((conv_in_kernel<f16_t, 8>), grid, dim3(128), 0, s, p);
     else hipLaunchKernelGGL((conv_in_kernel<float, 8>), grid, dim3(128), 0, s, p);
   } else {
     return k22_set_error(K22_EINVAL, "conv_in: in_channels must be 4, 8 or 9");
@@ -729,7 +742,7 @@ static void launch_linear_m(const LinearSmallParams& p, int Mt, dim3 grid, size_
 }
 int launch_linear_smallm(const LinearSmallParams& p0, int wdtype, hipStream_t s) {
   if (p0.M > 8 || p0.M < 1) return k22_set_error(K22_EINVAL, "linear_smallm: M must be in 1..8");
-  const int epc = wdtype == K22_BF16 ? 8 : 4;
+  const int epc = wdtype == K22_F32 ? 4 : 8;
   if (p0.K % epc) return k22_set_error(K22_EINVAL, "linear_smallm: K alignment");
   const int Mt = p0.M <= 2 ? p0.M : (p0.M <= 4 ? 4 : 8);  // rows the kernel is instantiated for
   const size_t smem = (size_t)Mt * p0.K * 4;
@@ -741,6 +754,7 @@ int launch_linear_smallm(const LinearSmallParams& p0, int wdtype, hipStream_t s)
   p.rows_per_wave = rpw;
   dim3 grid((p.N + 4 * rpw - 1) / (4 * rpw));
   if (wdtype == K22_BF16) launch_linear_m<bf16_t>(p, Mt, grid, smem, s);
+  else if (wdtype == K22_F16) launch_linear_m<f16_t>(p, Mt, grid, smem, s);
   else launch_linear_m<float>(p, Mt, grid, smem, s);
   K22_CHECK_LAUNCH();
   return K22_OK;
@@ -753,6 +767,7 @@ int launch_layernorm_f32(const float* x, const float* g, const float* b, float* 
 int launch_cast_rows(const float* x, void* y, int rows, int cols, int64_t ldx, int64_t ldy, int dtype, hipStream_t s) {
   const int nb = grid_for((int64_t)rows * cols, 256, 4096);
   if (dtype == K22_BF16) hipLaunchKernelGGL(cast_rows_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, x, y, rows, cols, ldx, ldy);
+  else if (dtype == K22_F16) hipLaunchKernelGGL(cast_rows_kernel<f16_t>, dim3(nb), dim3(256), 0, s, x, y, rows, cols, ldx, ldy);
   else hipLaunchKernelGGL(cast_rows_kernel<float>, dim3(nb), dim3(256), 0, s, x, y, rows, cols, ldx, ldy);
   K22_CHECK_LAUNCH();
   return K22_OK;
@@ -761,6 +776,7 @@ int launch_kv_pack(const KvPackParams& p, int dtype, hipStream_t s) {
   if (p.Tkp % 64) return k22_set_error(K22_EINVAL, "kv_pack: Tkp % 64");
   dim3 grid(p.Tkp / 64, p.H, p.B);
   if (dtype == K22_BF16) hipLaunchKernelGGL(kv_pack_kernel<bf16_t>, grid, dim3(256), 0, s, p);
+  else if (dtype == K22_F16) hipLaunchKernelGGL(kv_pack_kernel<f16_t>, grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(kv_pack_kernel<float>, grid, dim3(256), 0, s, p);
   K22_CHECK_LAUNCH();
   return K22_OK;

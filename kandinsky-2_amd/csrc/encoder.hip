@@ -209,6 +209,8 @@ struct K22Encoder {
       float* f = yf ? ptr<float>(yf) : nullptr;
       if (yt != nullptr && dt == K22_BF16)
         hipLaunchKernelGGL(enc_layernorm_kernel<bf16_t>, dim3(rows), dim3(256), 0, st, xp, ldx, g, b, f, ldyf, ptr<bf16_t>(yt), (int64_t)D, D, eps);
+      else if (yt != nullptr && dt == K22_F16)
+        hipLaunchKernelGGL(enc_layernorm_kernel<f16_t>, dim3(rows), dim3(256), 0, st, xp, ldx, g, b, f, ldyf, ptr<f16_t>(yt), (int64_t)D, D, eps);
       else
         hipLaunchKernelGGL(enc_layernorm_kernel<float>, dim3(rows), dim3(256), 0, st, xp, ldx, g, b, f, ldyf, yt ? ptr<float>(yt) : nullptr, (int64_t)D, D, eps);
       K22_CHECK_LAUNCH();
@@ -251,6 +253,7 @@ struct K22Encoder {
       const int S = cfg.image_size, patch = cfg.patch;
       ops.push_back([=](hipStream_t st) {
         if (dt == K22_BF16) hipLaunchKernelGGL(enc_patchify_kernel<bf16_t>, dim3(Bn * P), dim3(256), 0, st, ptr<float>(s_img), ptr<bf16_t>(s_patch), S, patch, Kp);
+        else if (dt == K22_F16) hipLaunchKernelGGL(enc_patchify_kernel<f16_t>, dim3(Bn * P), dim3(256), 0, st, ptr<float>(s_img), ptr<f16_t>(s_patch), S, patch, Kp);
         else hipLaunchKernelGGL(enc_patchify_kernel<float>, dim3(Bn * P), dim3(256), 0, st, ptr<float>(s_img), ptr<float>(s_patch), S, patch, Kp);
         K22_CHECK_LAUNCH();
         return K22_OK;
@@ -319,6 +322,7 @@ struct K22Encoder {
         ops.push_back([=](hipStream_t st) {
           const int nb = (int)((nel + 255) / 256 < 4096 ? (nel + 255) / 256 : 4096);
           if (dt == K22_BF16) hipLaunchKernelGGL(enc_quickgelu_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, ptr<float>(s_fc32), ptr<bf16_t>(s_fc), nel);
+          else if (dt == K22_F16) hipLaunchKernelGGL(enc_quickgelu_kernel<f16_t>, dim3(nb), dim3(256), 0, st, ptr<float>(s_fc32), ptr<f16_t>(s_fc), nel);
           else hipLaunchKernelGGL(enc_quickgelu_kernel<float>, dim3(nb), dim3(256), 0, st, ptr<float>(s_fc32), ptr<float>(s_fc), nel);
           K22_CHECK_LAUNCH();
           return K22_OK;
@@ -365,9 +369,9 @@ extern "C" {
 
 int k22_encoder_create(const K22EncoderConfig* cfg, const K22Weight* weights, int n_weights, K22Encoder** out) {
   if (!cfg || !out || (!weights && n_weights > 0)) return k22_set_error(K22_EINVAL, "encoder_create: null argument");
-  if (cfg->dtype != K22_BF16 && cfg->dtype != K22_F32) return k22_set_error(K22_EINVAL, "encoder_create: dtype");
+  if (!k22_dtype_ok(cfg->dtype)) return k22_set_error(K22_EINVAL, "encoder_create: dtype");
   K22Encoder* m = new K22Encoder();
-  m->cfg = *cfg; m->dtype = cfg->dtype; m->esz = cfg->dtype == K22_BF16 ? 2 : 4;
+  m->cfg = *cfg; m->dtype = cfg->dtype; m->esz = cfg->dtype == K22_F32 ? 4 : 2;
   for (int i = 0; i < n_weights; ++i) m->w[weights[i].name] = weights[i].ptr;
   {
     const char* e = getenv("K22_AUTOTUNE");

@@ -683,7 +683,7 @@ extern "C" {
 
 int k22_unet_create(const K22UNetConfig* cfg, const K22Weight* weights, int n_weights, K22UNet** out) {
   if (!cfg || !out) return k22_set_error(K22_EINVAL, "unet_create: null argument");
-  if (cfg->dtype != K22_BF16 && cfg->dtype != K22_F32) return k22_set_error(K22_EINVAL, "unet_create: dtype");
+  if (!k22_dtype_ok(cfg->dtype)) return k22_set_error(K22_EINVAL, "unet_create: dtype");
   if (cfg->num_head_channels != 64) return k22_set_error(K22_EINVAL, "unet_create: only num_head_channels == 64");
   if (cfg->model_channels % 128) return k22_set_error(K22_EINVAL, "unet_create: model_channels % 128");
   if (cfg->n_levels < 1 || cfg->n_levels > 8) return k22_set_error(K22_EINVAL, "unet_create: n_levels");
@@ -693,7 +693,7 @@ int k22_unet_create(const K22UNetConfig* cfg, const K22Weight* weights, int n_we
     return k22_set_error(K22_EINVAL, "unet_create: hint_channels = 3 goes with in_channels = 8 (latent + hint latent), else 0");
   if (cfg->head_type == 1 && cfg->n_image_embs != cfg->ctx_len) return k22_set_error(K22_EINVAL, "unet_create: the 2.2 head has image tokens only (n_image_embs == ctx_len)");
   K22UNet* u = new K22UNet();
-  u->cfg = *cfg; u->dtype = cfg->dtype; u->esz = cfg->dtype == K22_BF16 ? 2 : 4;
+  u->cfg = *cfg; u->dtype = cfg->dtype; u->esz = cfg->dtype == K22_F32 ? 4 : 2;
   {
     const char* e = getenv("K22_AUTOTUNE");  // 0 = heuristics only (no measurement at the first forward)
     u->autotune = e ? (atoi(e) != 0) : 1;

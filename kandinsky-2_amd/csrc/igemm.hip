@@ -39,6 +39,12 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* dst, const fl
   w.y = pack2_bf16(v[2], v[3]);
   *reinterpret_cast<uint2*>(dst) = w;
 }
+template <> __device__ __forceinline__ void store4<f16_t>(f16_t* dst, const float* v) {
+  uint2 w;
+  w.x = pack2_f16(v[0], v[1]);
+  w.y = pack2_f16(v[2], v[3]);
+  *reinterpret_cast<uint2*>(dst) = w;
+}
 template <> __device__ __forceinline__ void store4<float>(float* dst, const float* v) {
   *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
 }
@@ -47,6 +53,10 @@ template <> __device__ __forceinline__ void load4f<bf16_t>(const bf16_t* src, fl
   const uint2 r = *reinterpret_cast<const uint2*>(src);
   v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
   v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void load4f<f16_t>(const f16_t* src, float* v) {
+  const uint2 r = *reinterpret_cast<const uint2*>(src);
+  unpack2_f16(r.x, v[0], v[1]); unpack2_f16(r.y, v[2], v[3]);
 }
 template <> __device__ __forceinline__ void load4f<float>(const float* src, float* v) {
   const float4 r = *reinterpret_cast<const float4*>(src);
@@ -427,7 +437,11 @@ static int g_xcd_remap = 1;
 static int g_conv_algo = 0;
 void igemm_set_default_stages(int v) { g_stages_override = (v >= 2 && v <= 4) ? v : -1; }
 void igemm_set_xcd_remap(int v) { g_xcd_remap = v ? 1 : 0; }
+#ifdef K22_DEBUG_VARIANTS
 void igemm_set_conv_algo(int v) { g_conv_algo = ((v >= 0 && v <= 9) || (v >= 11 && v <= 14)) ? v : 0; }
+#else   // 8, 9, 13, 14 are measurement-only kernels (wrong results): not reachable in a release build
+void igemm_set_conv_algo(int v) { g_conv_algo = ((v >= 0 && v <= 7) || v == 11 || v == 12) ? v : 0; }
+#endif
 static int g_gemm_algo = 0;   // 0 = generic igemm_kernel, 10 = gemm8_kernel where it applies (unit tests / kernel benches)
 void igemm_set_gemm_algo(int v) { g_gemm_algo = (v == 10) ? 10 : 0; }
 
@@ -443,7 +457,7 @@ static int g_default_stages() {
 }
 
 static IgemmPlan igemm_plan(const IgemmParams& p, int dtype) {
-  const int BK = (dtype == K22_BF16) ? 64 : 32;
+  const int BK = (dtype == K22_F32) ? 32 : 64;
   const int nkt = p.taps * (p.Kc / BK);
   IgemmPlan pl;
   pl.halo = 0;
@@ -597,7 +611,7 @@ static int launch_typed(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s
 }
 
 int launch_igemm(const IgemmParams& p, int dtype, hipStream_t stream) {
-  const int BK = (dtype == K22_BF16) ? 64 : 32;
+  const int BK = (dtype == K22_F32) ? 32 : 64;
   if (p.M <= 0 || p.N <= 0) return K22_OK;
   if (p.taps != 1 && p.taps != 9) return k22_set_error(K22_EINVAL, "igemm: taps must be 1 or 9");
   if (p.Kc % BK != 0 || p.K0 % BK != 0) return k22_set_error(K22_EINVAL, "igemm: K per tap must be a multiple of 64 (bf16) / 32 (fp32)");
@@ -621,7 +635,7 @@ int launch_igemm(const IgemmParams& p, int dtype, hipStream_t stream) {
     if (q.stages < 2 && g_stages_override >= 0) q.stages = g_stages_override;   // "igemm_stages" option (benches / tests)
     int rc = launch_gemm8(q, dtype, pl.bm, pl.splitk, stream);
     if (rc || pl.splitk == 1) return rc;
-    return dtype == K22_BF16 ? launch_reduce<bf16_t>(q, stream) : launch_reduce<float>(q, stream);
+    return dtype == K22_BF16 ? launch_reduce<bf16_t>(q, stream) : (dtype == K22_F16 ? launch_reduce<f16_t>(q, stream) : launch_reduce<float>(q, stream));
   }
   if (pl.halo) {
     IgemmParams q = p;
@@ -631,9 +645,10 @@ int launch_igemm(const IgemmParams& p, int dtype, hipStream_t stream) {
     if (q.stages < 2 && g_stages_override >= 0) q.stages = g_stages_override;   // "igemm_stages" option (benches / tests)
     int rc = launch_conv3_halo(q, dtype, pl.bm, pl.splitk, stream);
     if (rc || pl.splitk == 1) return rc;
-    return dtype == K22_BF16 ? launch_reduce<bf16_t>(q, stream) : launch_reduce<float>(q, stream);
+    return dtype == K22_BF16 ? launch_reduce<bf16_t>(q, stream) : (dtype == K22_F16 ? launch_reduce<f16_t>(q, stream) : launch_reduce<float>(q, stream));
   }
   if (dtype == K22_BF16) return launch_typed<bf16_t>(p, pl, stream);
+  else if (dtype == K22_F16) return launch_typed<f16_t>(p, pl, stream);
   if (dtype == K22_F32) return launch_typed<float>(p, pl, stream);
   return k22_set_error(K22_EINVAL, "igemm: bad dtype");
 }

@@ -343,10 +343,10 @@ extern "C" {
 
 int k22_movq_create(const K22MoVQConfig* cfg, const K22Weight* weights, int n_weights, K22MoVQ** out) {
   if (!cfg || !out) return k22_set_error(K22_EINVAL, "movq_create: null argument");
-  if (cfg->dtype != K22_BF16 && cfg->dtype != K22_F32) return k22_set_error(K22_EINVAL, "movq_create: dtype");
+  if (!k22_dtype_ok(cfg->dtype)) return k22_set_error(K22_EINVAL, "movq_create: dtype");
   if (cfg->n_levels < 1 || cfg->n_levels > 8 || cfg->z_channels != 4 || cfg->ch % 128) return k22_set_error(K22_EINVAL, "movq_create: unsupported configuration (z_channels == 4, ch % 128 == 0)");
   K22MoVQ* m = new K22MoVQ();
-  m->cfg = *cfg; m->dtype = cfg->dtype; m->esz = cfg->dtype == K22_BF16 ? 2 : 4;
+  m->cfg = *cfg; m->dtype = cfg->dtype; m->esz = cfg->dtype == K22_F32 ? 4 : 2;
   for (int i = 0; i < n_weights; ++i) m->w[weights[i].name] = weights[i].ptr;
   *out = m;
   return K22_OK;

@@ -211,24 +211,27 @@ int launch_movq_enc_prepare(const float* img, void* xin, int B, int H, int W, in
   const int64_t total = (int64_t)B * (H + 2) * (W + 2);
   const unsigned nb = (unsigned)((total + 255) / 256);
   if (dtype == K22_BF16) hipLaunchKernelGGL(movq_enc_prepare_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, img, xin, B, H, W, Cpad);
+  else if (dtype == K22_F16) hipLaunchKernelGGL(movq_enc_prepare_kernel<f16_t>, dim3(nb), dim3(256), 0, s, img, xin, B, H, W, Cpad);
   else hipLaunchKernelGGL(movq_enc_prepare_kernel<float>, dim3(nb), dim3(256), 0, s, img, xin, B, H, W, Cpad);
   K22_CHECK_LAUNCH();
   return K22_OK;
 }
 int launch_pad_copy(const void* x, void* y, int B, int H, int W, int C, int dtype, hipStream_t s) {
-  const int epv = dtype == K22_BF16 ? 8 : 4;
+  const int epv = dtype == K22_F32 ? 4 : 8;
   if (C % epv || H + 2 > 65535) return k22_set_error(K22_EINVAL, "pad_copy: bad shape");
   dim3 grid(((W + 2) * (C / epv) + 255) / 256, H + 2, B);
   if (dtype == K22_BF16) hipLaunchKernelGGL(pad_copy_kernel<bf16_t>, grid, dim3(256), 0, s, x, y, B, H, W, C);
+  else if (dtype == K22_F16) hipLaunchKernelGGL(pad_copy_kernel<f16_t>, grid, dim3(256), 0, s, x, y, B, H, W, C);
   else hipLaunchKernelGGL(pad_copy_kernel<float>, grid, dim3(256), 0, s, x, y, B, H, W, C);
   K22_CHECK_LAUNCH();
   return K22_OK;
 }
 int launch_subsample_odd(const void* x, void* y, int B, int H, int W, int C, int dtype, hipStream_t s) {
-  const int epv = dtype == K22_BF16 ? 8 : 4;
+  const int epv = dtype == K22_F32 ? 4 : 8;
   if (C % epv || (H & 1) || (W & 1) || H / 2 > 65535) return k22_set_error(K22_EINVAL, "subsample_odd: bad shape");
   dim3 grid(((W / 2) * (C / epv) + 255) / 256, H / 2, B);
   if (dtype == K22_BF16) hipLaunchKernelGGL(subsample_odd_kernel<bf16_t>, grid, dim3(256), 0, s, x, y, B, H, W, C);
+  else if (dtype == K22_F16) hipLaunchKernelGGL(subsample_odd_kernel<f16_t>, grid, dim3(256), 0, s, x, y, B, H, W, C);
   else hipLaunchKernelGGL(subsample_odd_kernel<float>, grid, dim3(256), 0, s, x, y, B, H, W, C);
   K22_CHECK_LAUNCH();
   return K22_OK;
@@ -241,31 +244,34 @@ int launch_movq_quant_conv(const float* h, const float* wq, const float* bq, flo
 }
 
 int launch_spatialnorm_apply(const SpatialNormParams& p, int dtype, hipStream_t s) {
-  const int epv = dtype == K22_BF16 ? 8 : 4;
+  const int epv = dtype == K22_F32 ? 4 : 8;
   if (p.C % epv) return k22_set_error(K22_EINVAL, "spatialnorm: channel alignment");
   const int Hp = p.H + 2 * p.pad, Wp = p.W + 2 * p.pad;
   if (Hp > 65535 || p.B > 65535) return k22_set_error(K22_EINVAL, "spatialnorm: tensor too large");
   dim3 grid((Wp * (p.C / epv) + 255) / 256, Hp, p.B);
   if (dtype == K22_BF16) hipLaunchKernelGGL(spatialnorm_apply_kernel<bf16_t>, grid, dim3(256), 0, s, p);
+  else if (dtype == K22_F16) hipLaunchKernelGGL(spatialnorm_apply_kernel<f16_t>, grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(spatialnorm_apply_kernel<float>, grid, dim3(256), 0, s, p);
   K22_CHECK_LAUNCH();
   return K22_OK;
 }
 int launch_upsample2_pad(const void* x, void* y, int B, int H, int W, int C, int dtype, hipStream_t s) {
-  const int epv = dtype == K22_BF16 ? 8 : 4;
+  const int epv = dtype == K22_F32 ? 4 : 8;
   if (C % epv) return k22_set_error(K22_EINVAL, "upsample2_pad: channel alignment");
   const int Hp = 2 * H + 2, Wp = 2 * W + 2;
   if (Hp > 65535) return k22_set_error(K22_EINVAL, "upsample2_pad: tensor too large");
   dim3 grid((Wp * (C / epv) + 255) / 256, Hp, B);
   if (dtype == K22_BF16) hipLaunchKernelGGL(upsample2_pad_kernel<bf16_t>, grid, dim3(256), 0, s, x, y, B, H, W, C);
+  else if (dtype == K22_F16) hipLaunchKernelGGL(upsample2_pad_kernel<f16_t>, grid, dim3(256), 0, s, x, y, B, H, W, C);
   else hipLaunchKernelGGL(upsample2_pad_kernel<float>, grid, dim3(256), 0, s, x, y, B, H, W, C);
   K22_CHECK_LAUNCH();
   return K22_OK;
 }
 int launch_softmax_rows(void* x, int64_t rows, int L, float scale, int dtype, hipStream_t s) {
-  const int epv = dtype == K22_BF16 ? 8 : 4;
+  const int epv = dtype == K22_F32 ? 4 : 8;
   if (L % epv || rows <= 0 || rows > 0x7fffffff) return k22_set_error(K22_EINVAL, "softmax_rows: bad shape");
   if (dtype == K22_BF16) hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, dim3((unsigned)rows), dim3(256), 0, s, x, L, scale);
+  else if (dtype == K22_F16) hipLaunchKernelGGL(softmax_rows_kernel<f16_t>, dim3((unsigned)rows), dim3(256), 0, s, x, L, scale);
   else hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3((unsigned)rows), dim3(256), 0, s, x, L, scale);
   K22_CHECK_LAUNCH();
   return K22_OK;
@@ -274,6 +280,7 @@ int launch_movq_prepare(const float* z, const float* wpq, const float* bpq, floa
                         int Cpad, int dtype, hipStream_t s) {
   const int total = B * (h + 2) * (w + 2);
   if (dtype == K22_BF16) hipLaunchKernelGGL(movq_prepare_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, s, z, wpq, bpq, zq, xin, B, h, w, Cpad);
+  else if (dtype == K22_F16) hipLaunchKernelGGL(movq_prepare_kernel<f16_t>, dim3((total + 255) / 256), dim3(256), 0, s, z, wpq, bpq, zq, xin, B, h, w, Cpad);
   else hipLaunchKernelGGL(movq_prepare_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, s, z, wpq, bpq, zq, xin, B, h, w, Cpad);
   K22_CHECK_LAUNCH();
   return K22_OK;

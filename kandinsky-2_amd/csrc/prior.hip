@@ -135,6 +135,7 @@ struct K22Prior {
       const float* xp = reinterpret_cast<const float*>(ptr(x) + x_off);
       if (to_f32) hipLaunchKernelGGL(prior_layernorm_kernel<float>, dim3(rows), dim3(256), 0, st, xp, ldx, g, b, ptr<float>(y), (int64_t)D, D, 1e-5f);
       else if (dt == K22_BF16) hipLaunchKernelGGL(prior_layernorm_kernel<bf16_t>, dim3(rows), dim3(256), 0, st, xp, ldx, g, b, ptr<bf16_t>(y), (int64_t)D, D, 1e-5f);
+      else if (dt == K22_F16) hipLaunchKernelGGL(prior_layernorm_kernel<f16_t>, dim3(rows), dim3(256), 0, st, xp, ldx, g, b, ptr<f16_t>(y), (int64_t)D, D, 1e-5f);
       else hipLaunchKernelGGL(prior_layernorm_kernel<float>, dim3(rows), dim3(256), 0, st, xp, ldx, g, b, ptr<float>(y), (int64_t)D, D, 1e-5f);
       K22_CHECK_LAUNCH();
       return K22_OK;
@@ -265,9 +266,9 @@ extern "C" {
 
 int k22_prior_create(const K22PriorConfig* cfg, const K22Weight* weights, int n_weights, K22Prior** out) {
   if (!cfg || !out) return k22_set_error(K22_EINVAL, "prior_create: null argument");
-  if (cfg->dtype != K22_BF16 && cfg->dtype != K22_F32) return k22_set_error(K22_EINVAL, "prior_create: dtype");
+  if (!k22_dtype_ok(cfg->dtype)) return k22_set_error(K22_EINVAL, "prior_create: dtype");
   K22Prior* m = new K22Prior();
-  m->cfg = *cfg; m->dtype = cfg->dtype; m->esz = cfg->dtype == K22_BF16 ? 2 : 4;
+  m->cfg = *cfg; m->dtype = cfg->dtype; m->esz = cfg->dtype == K22_F32 ? 4 : 2;
   for (int i = 0; i < n_weights; ++i) m->w[weights[i].name] = weights[i].ptr;
   {
     const char* e = getenv("K22_AUTOTUNE");

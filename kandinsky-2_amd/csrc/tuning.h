@@ -103,7 +103,7 @@ inline void tuned_apply_cfg(IgemmParams& q, const Cfg& c) {
 
 inline void tuned_make_candidates(Tuned& t, int dtype) {
   const IgemmParams& p = t.p;
-  const int BK = dtype == K22_BF16 ? 64 : 32;
+  const int BK = dtype == K22_F32 ? 32 : 64;
   const int nkt = p.taps * (p.Kc / BK);
   std::vector<Cfg> all;
   if (p.taps == 9) {
@@ -179,6 +179,8 @@ inline void tuned_make_candidates(Tuned& t, int dtype) {
 
 inline TileKey tuned_key(const Tuned& t, int dtype) {
   const IgemmParams& p = t.p;
+  // fp16 runs the same kernels on the same bytes at the same MFMA rate as bf16: one table line serves both 16-bit types
+  if (dtype == K22_F16) dtype = K22_BF16;
   return TileKey(dtype, p.taps, p.M, p.N, p.Kc, p.K0 + (p.S0 ? 100000 * (p.SK0 + p.SK1) : 0), p.H, p.W,
                  p.out_mode + 16 * p.res_f32 + 32 * p.act, t.want_stats);
 }

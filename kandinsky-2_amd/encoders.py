@@ -233,7 +233,7 @@ class _Engine:
     def __init__(self, ecfg: dict, arena: torch.Tensor, table, backend_dtype):
         self.cfg, self.arena = ecfg, arena
         c = _lib.K22EncoderConfig()
-        c.dtype = _lib.K22_BF16 if backend_dtype == torch.bfloat16 else _lib.K22_F32
+        c.dtype = _lib.dtype_code(backend_dtype)
         for k, v in ecfg.items():
             setattr(c, k, v)
         base = arena.data_ptr()

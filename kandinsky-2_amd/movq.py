@@ -209,7 +209,7 @@ class MoVQDecoderHIP(nn.Module):
         self._arena, table = pack_movq_arena(self.arch, self.state_dict(), self.backend_dtype, dev)
         a = self.arch
         cfg = _lib.K22MoVQConfig()
-        cfg.dtype = _lib.K22_BF16 if self.backend_dtype == torch.bfloat16 else _lib.K22_F32
+        cfg.dtype = _lib.dtype_code(self.backend_dtype)
         cfg.ch = a.ch
         cfg.n_levels = len(a.ch_mult)
         for i, v in enumerate(a.ch_mult):
@@ -419,7 +419,7 @@ class MoVQEncoderHIP(nn.Module):
         self._arena, table = pack_movq_encoder_arena(self.arch, self.state_dict(), self.backend_dtype, dev)
         a = self.arch
         cfg = _lib.K22MoVQConfig()
-        cfg.dtype = _lib.K22_BF16 if self.backend_dtype == torch.bfloat16 else _lib.K22_F32
+        cfg.dtype = _lib.dtype_code(self.backend_dtype)
         cfg.ch = a.ch
         cfg.n_levels = len(a.ch_mult)
         for i, v in enumerate(a.ch_mult):

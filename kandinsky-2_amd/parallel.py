@@ -7,7 +7,9 @@ torch.distributed is used as plumbing (backend "nccl" == RCCL on ROCm; "gloo" in
 """
 from __future__ import annotations
 
-from typing import List, Optional
+import os
+import socket
+from typing import Callable, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -49,3 +51,45 @@ def gather_outputs(local: torch.Tensor, dst: int = 0) -> Optional[List[torch.Ten
     if dist.get_rank() != dst:
         return None
     return [b[: int(s.item())] for b, s in zip(bufs, sizes)]
+
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _rank_entry(rank: int, world: int, port: int, fn: Callable, args: Sequence):
+    # exactly what `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` exports
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    fn(rank, world, *args)
+
+
+def launch_ranks(fn: Callable, world: int, args: Sequence = (), devices_visible: Optional[int] = None, timeout_s: float = 3600.0) -> None:
+    """Self-launcher for `--gpus N` without torch.distributed.run: starts `world` processes (one per GPU) that run
+    fn(rank, world, *args) with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT exported.  Fails LOUDLY - never quietly
+    runs fewer ranks - when fewer devices are visible than ranks, or when a rank exits non-zero."""
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    if devices_visible is not None and devices_visible < world:
+        raise RuntimeError(f"{world} ranks requested but only {devices_visible} device(s) visible: refusing to run a smaller job under the same name")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_entry, args=(r, world, port, fn, tuple(args))) for r in range(world)]
+    for p in procs:
+        p.start()
+    bad = []
+    for r, p in enumerate(procs):
+        p.join(timeout_s)
+        if p.is_alive():
+            p.terminate()
+            bad.append((r, "timeout"))
+        elif p.exitcode != 0:
+            bad.append((r, p.exitcode))
+    if bad:
+        raise RuntimeError(f"launch_ranks: ranks failed: {bad}")

@@ -186,8 +186,18 @@ class Kandinsky2_1HIP:
         self.config["model_config"]["inpainting"] = task_type == "inpainting"
         mcfg = self.config["model_config"]
         hp = self.config["prior"]["params"]["model"]["hparams"]
-        self.conditioner = conditioner if conditioner is not None else SeededConditioner(
-            mcfg.get("text_encoder_in_dim1", 1024), mcfg.get("text_encoder_in_dim2", 768), hp["clip_dim"], hp["clip_xf_width"], hp["text_ctx"])
+        # The reference builds its XLM-R and CLIP encoders here (kandinsky2_1_model.py:57-66).  A drop-in that silently
+        # conditioned real checkpoints on hash-seeded noise would ignore the prompt, so the stand-in is an explicit opt-in:
+        # conditioner="seeded" (benchmarks / parity tests), else a HIPConditioner / ReferenceConditioner object is required.
+        if conditioner is None:
+            raise ValueError("Kandinsky2_1HIP: pass conditioner=HIPConditioner(...) / ReferenceConditioner(...) (the XLM-R and CLIP "
+                             "encoders of Kandinsky2_1.__init__), or conditioner='seeded' for the offline benchmark stand-in")
+        if isinstance(conditioner, str):
+            if conditioner != "seeded":
+                raise ValueError("conditioner must be an object or the string 'seeded'")
+            conditioner = SeededConditioner(mcfg.get("text_encoder_in_dim1", 1024), mcfg.get("text_encoder_in_dim2", 768), hp["clip_dim"],
+                                            hp["clip_xf_width"], hp["text_ctx"])
+        self.conditioner = conditioner
 
         ms = self.config["prior"]["clip_mean_std_path"]
         clip_mean, clip_std = _load(ms) if isinstance(ms, (str, os.PathLike)) else ms
@@ -394,6 +404,32 @@ class _MoVQ:
         return self
 
 
+def _conditioner_from_cache_dir(cache_dir, device, backend_dtype):
+    """The encoders Kandinsky2_1.__init__ builds (kandinsky2_1_model.py:57-66; files as kandinsky2/__init__.py:124-160 stores them):
+    cache_dir/text_encoder (XLM-R tokenizer + pytorch_model.bin of MultilingualCLIP) and cache_dir/ViT-L-14.pt, on the HIP encoder
+    engine.  Raises - never substitutes seeded noise - when a file or a tokenizer dependency is missing."""
+    from .encoders import CLIPModelHIP, HIPConditioner, TextEncoderHIP
+    te_dir, clip_pt = os.path.join(cache_dir, "text_encoder"), os.path.join(cache_dir, "ViT-L-14.pt")
+    missing = [p for p in (os.path.join(te_dir, "pytorch_model.bin"), clip_pt) if not os.path.exists(p)]
+    if missing:
+        raise FileNotFoundError(f"Kandinsky 2.1 conditioning encoders not found: {missing}; pass conditioner=... explicitly "
+                                "(conditioner='seeded' is the offline benchmark stand-in)")
+    from transformers import AutoTokenizer
+    tokenizer1 = AutoTokenizer.from_pretrained(te_dir)
+    try:
+        from kandinsky2.model.prior import CustomizedTokenizer   # the reference's own BPE wrapper (needs the `clip` package)
+        tokenizer2 = CustomizedTokenizer()
+    except Exception as e:  # noqa: BLE001
+        raise RuntimeError("the CLIP BPE tokenizer (kandinsky2.model.prior.CustomizedTokenizer, which needs OpenAI `clip`) is not "
+                           "importable; pass conditioner=HIPConditioner(..., tokenizer2=...) explicitly") from e
+    clip_sd = torch.jit.load(clip_pt, map_location="cpu").state_dict()   # the OpenAI checkpoint is a TorchScript archive (clip.load)
+    clip_model = CLIPModelHIP(backend_dtype=backend_dtype)
+    clip_model.load_state_dict({k: v.float() for k, v in clip_sd.items() if k in clip_model.state_dict()}, strict=True)
+    text_encoder = TextEncoderHIP(te_dir, "multiclip", state_dict=torch.load(os.path.join(te_dir, "pytorch_model.bin"), map_location="cpu"),
+                                  backend_dtype=backend_dtype)
+    return HIPConditioner(text_encoder.to(device), tokenizer1, tokenizer2, clip_model.to(device).eval())
+
+
 def get_kandinsky2(device, task_type="text2img", cache_dir="/tmp/kandinsky2", use_auth_token=None, model_version="2.1",
                    use_flash_attention=False, *, conditioner=None, backend_dtype: torch.dtype = torch.bfloat16, use_graph: bool = True):
     """`get_kandinsky2` (kandinsky2/__init__.py:164-192) for the HIP engines.  The reference downloads the checkpoints into
@@ -411,6 +447,8 @@ def get_kandinsky2(device, task_type="text2img", cache_dir="/tmp/kandinsky2", us
             raise FileNotFoundError(f"Kandinsky 2.1 checkpoints not found (no download path in this build): {missing}")
         config["prior"]["clip_mean_std_path"] = need["ViT-L-14_stats.th"]
         config["image_enc_params"]["ckpt_path"] = need["movq_final.ckpt"]
+        if conditioner is None:
+            conditioner = _conditioner_from_cache_dir(cache_dir, device, backend_dtype)
         return Kandinsky2_1HIP(config, need[model_name], need["prior_fp16.ckpt"], device, task_type=task_type, conditioner=conditioner,
                                backend_dtype=backend_dtype, use_graph=use_graph)
     if model_version == "2.2":

@@ -11,6 +11,7 @@ reached through the conditioner:  conditioner.prior22(prompt, negative_prompt | 
 from __future__ import annotations
 
 import hashlib
+import os
 from typing import Optional
 
 import torch
@@ -18,7 +19,7 @@ import torch
 from . import _lib, prestep
 from .movq import MoVQDecoderHIP, MoVQEncoderHIP
 from .pipeline import prepare_image, process_images
-from .unet22 import DDPMSchedulerHIP, UNet2DConditionHIP, make_arch22
+from .unet22 import SCHEDULER_CONFIG_2_2, DDPMSchedulerHIP, UNet2DConditionHIP, make_arch22
 
 
 class SeededPrior22:
@@ -57,7 +58,7 @@ class KandinskyV22DecoderHIP:
     so the order is an internal convention: diffusers uses [uncond | cond])."""
 
     def __init__(self, unet: UNet2DConditionHIP, movq: MoVQDecoderHIP, scheduler: Optional[DDPMSchedulerHIP] = None, movq_scale_factor: int = 8):
-        self.unet, self.movq, self.scheduler = unet, movq, scheduler or DDPMSchedulerHIP()
+        self.unet, self.movq, self.scheduler = unet, movq, scheduler or DDPMSchedulerHIP.from_config(SCHEDULER_CONFIG_2_2)
         self.movq_scale_factor = movq_scale_factor
 
     def _check(self, image_embeds):
@@ -200,22 +201,73 @@ class KandinskyV22InpaintDecoderHIP(KandinskyV22Img2ImgDecoderHIP):
         return self._images(x, height, width, output_type)
 
 
+def _load_weights(folder):
+    """diffusion_pytorch_model.safetensors / .bin of one diffusers sub-folder"""
+    import json
+    st, bn = os.path.join(folder, "diffusion_pytorch_model.safetensors"), os.path.join(folder, "diffusion_pytorch_model.bin")
+    if os.path.exists(st):
+        from safetensors.torch import load_file
+        sd = load_file(st)
+    elif os.path.exists(bn):
+        sd = torch.load(bn, map_location="cpu")
+    else:
+        raise FileNotFoundError(f"no diffusion_pytorch_model.safetensors / .bin under {folder}")
+    cfg = os.path.join(folder, "config.json")
+    return sd, (json.load(open(cfg)) if os.path.exists(cfg) else None)
+
+
+def load_decoder22_from_cache_dir(cache_dir, task_type="text2img", controlnet=False):
+    """What `from_pretrained('kandinsky-community/kandinsky-2-2-<repo>', subfolder='unet' | 'movq' | 'scheduler')` reads
+    (kandinsky2_2_model.py:26-41), from a local copy `cache_dir/<repo>/{unet,movq,scheduler}/`: the UNet and MoVQ state dicts plus
+    unet/config.json and scheduler/scheduler_config.json, which DRIVE the architecture and the scheduler (make_arch22,
+    DDPMSchedulerHIP.from_config) - nothing about the checkpoint is assumed.  Raises when a folder is missing (no download path)."""
+    import json
+    repo = "kandinsky-2-2-controlnet-depth" if controlnet else ("kandinsky-2-2-decoder-inpaint" if task_type == "inpainting" else "kandinsky-2-2-decoder")
+    root = os.path.join(cache_dir, repo)
+    if not os.path.isdir(root):
+        raise FileNotFoundError(f"{root} not found (expected the decoder repository's unet/, movq/, scheduler/ folders)")
+    unet_sd, unet_cfg = _load_weights(os.path.join(root, "unet"))
+    movq_sd, _ = _load_weights(os.path.join(root, "movq"))
+    sc = os.path.join(root, "scheduler", "scheduler_config.json")
+    return {"unet": unet_sd, "unet_config": unet_cfg, "movq": movq_sd, "scheduler_config": json.load(open(sc)) if os.path.exists(sc) else None}
+
+
 class Kandinsky2_2HIP:
     """`Kandinsky2_2` (kandinsky2_2_model.py:15-173): get_new_h_w, generate_text2img, generate_img2img, mix_images,
     generate_inpainting with the reference's argument names and its (task_type -> pipeline, UNet) table."""
 
     def __init__(self, device="cuda", task_type="text2img", *, unet_state_dict=None, movq_state_dict=None, conditioner=None,
-                 cache_dir=None, backend_dtype: torch.dtype = torch.bfloat16, use_graph: bool = True, unet_config=None, controlnet=False):
+                 cache_dir=None, backend_dtype: torch.dtype = torch.bfloat16, use_graph: bool = True, unet_config=None, controlnet=None,
+                 scheduler_config=None):
         if task_type not in ("text2img", "img2img", "inpainting"):
             raise ValueError("Only text2img, img2img, inpainting is available")
+        if (unet_state_dict is None or movq_state_dict is None) and cache_dir is not None:
+            # the files from_pretrained('kandinsky-community/kandinsky-2-2-decoder[-inpaint]', subfolder=...) caches (kandinsky2_2_model.py:26-41)
+            loaded = load_decoder22_from_cache_dir(cache_dir, task_type, bool(controlnet))
+            unet_state_dict = unet_state_dict if unet_state_dict is not None else loaded["unet"]
+            movq_state_dict = movq_state_dict if movq_state_dict is not None else loaded["movq"]
+            unet_config = unet_config if unet_config is not None else loaded["unet_config"]
+            scheduler_config = scheduler_config if scheduler_config is not None else loaded["scheduler_config"]
         if unet_state_dict is None or movq_state_dict is None:
-            raise FileNotFoundError("Kandinsky 2.2 weights: pass unet_state_dict= (diffusers UNet2DConditionModel keys) and movq_state_dict= "
-                                    "(there is no download path in this build)")
+            raise FileNotFoundError("Kandinsky 2.2 weights: pass unet_state_dict= (diffusers UNet2DConditionModel keys) and movq_state_dict=, or "
+                                    "cache_dir= holding the decoder repository's unet/, movq/, scheduler/ folders (no download path in this build)")
         if controlnet and task_type != "text2img":
             raise ValueError("the ControlNet-depth UNet is a text2img decoder")
+        # The reference builds the CLIP-bigG image encoder and the prior pipeline here (kandinsky2_2_model.py:24-31).  Seeded stand-in
+        # embeddings would ignore the prompt, so they are an explicit opt-in (conditioner="seeded"), never a silent default.
+        if conditioner is None:
+            raise ValueError("Kandinsky2_2HIP: pass conditioner= (an object with prior22 / encode_image22: the 2.2 prior pipeline and its "
+                             "CLIP-bigG image encoder), or conditioner='seeded' for the offline benchmark stand-in")
+        if isinstance(conditioner, str):
+            if conditioner != "seeded":
+                raise ValueError("conditioner must be an object or the string 'seeded'")
+            conditioner = SeededPrior22()
         self.device, self.task_type = device, task_type
-        self.conditioner = conditioner or SeededPrior22()
-        arch = make_arch22(unet_config, controlnet=controlnet, inpainting=task_type == "inpainting")
+        self.conditioner = conditioner
+        arch = make_arch22(unet_config, controlnet=controlnet if controlnet else None, inpainting=True if task_type == "inpainting" else None)
+        if arch.inpainting != (task_type == "inpainting"):
+            raise ValueError(f"task_type {task_type!r} does not match the UNet config (in_channels {arch.in_channels})")
+        scheduler = lambda: DDPMSchedulerHIP.from_config(scheduler_config if scheduler_config is not None else SCHEDULER_CONFIG_2_2)  # noqa: E731
         self.unet = UNet2DConditionHIP(arch, backend_dtype=backend_dtype, use_graph=use_graph)
         self.unet.load_state_dict(unet_state_dict)
         self.unet = self.unet.to(device).eval()
@@ -223,12 +275,12 @@ class Kandinsky2_2HIP:
         movq.load_state_dict(movq_state_dict, strict=True)          # decoder keys; a full MOVQ checkpoint's other keys are skipped
         movq = movq.to(device)
         if task_type == "text2img":
-            self.decoder = KandinskyV22DecoderHIP(self.unet, movq)
+            self.decoder = KandinskyV22DecoderHIP(self.unet, movq, scheduler())
         else:
             enc = MoVQEncoderHIP(backend_dtype=backend_dtype)
             enc.load_state_dict(movq_state_dict, strict=True)
             cls = KandinskyV22Img2ImgDecoderHIP if task_type == "img2img" else KandinskyV22InpaintDecoderHIP
-            self.decoder = cls(self.unet, movq, enc.to(device))
+            self.decoder = cls(self.unet, movq, enc.to(device), scheduler())
 
     def get_new_h_w(self, h, w):
         return (h // 64 + (1 if h % 64 else 0)) * 64, (w // 64 + (1 if w % 64 else 0)) * 64

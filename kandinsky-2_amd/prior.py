@@ -214,7 +214,7 @@ class PriorDiffusionModelHIP(nn.Module):
         sd = {k[len("model."):]: v for k, v in self.state_dict().items() if k.startswith("model.")}
         self._arena, table = pack_prior_arena(self.hp, sd, self.backend_dtype, dev)
         cfg = _lib.K22PriorConfig()
-        cfg.dtype = _lib.K22_BF16 if self.backend_dtype == torch.bfloat16 else _lib.K22_F32
+        cfg.dtype = _lib.dtype_code(self.backend_dtype)
         for k in ("text_ctx", "xf_width", "xf_layers", "xf_heads", "clip_dim", "clip_xf_width"):
             setattr(cfg, k, int(self.hp[k]))
         cfg.xf_final_ln = 1 if self.hp["xf_final_ln"] else 0

@@ -33,15 +33,16 @@ def _register(root: nn.Module, dotted: str, param: nn.Parameter) -> None:
 class Text2ImUNetHIP(nn.Module):
     """MI355X-native Text2ImUNet (kandinsky2/model/text2im_model2_1.py:13-103).
 
-    backend_dtype: torch.bfloat16 (product path, bf16 MFMA) or torch.float32 (parity path, fp32 MFMA).
+    backend_dtype: torch.bfloat16 (BASELINE's dtype, bf16 MFMA), torch.float16 (the reference's own use_fp16 mode: same MFMA rate,
+    3 more mantissa bits - the mode that holds <= 3e-3 on the 50-step final latent) or torch.float32 (parity path, exact-fp32 MFMA).
     use_graph: replay each forward as one captured hipGraph.
     """
 
     def __init__(self, arch: UNetArch, backend_dtype: torch.dtype = torch.bfloat16, use_graph: bool = True,
                  cache_text_emb: bool = True, meta_params: bool = False):
         super().__init__()
-        if backend_dtype not in (torch.bfloat16, torch.float32):
-            raise ValueError("backend_dtype must be torch.bfloat16 or torch.float32")
+        if backend_dtype not in (torch.bfloat16, torch.float16, torch.float32):
+            raise ValueError("backend_dtype must be torch.bfloat16, torch.float16 or torch.float32")
         self.arch = arch
         self.backend_dtype = backend_dtype
         self.use_graph = use_graph
@@ -61,11 +62,25 @@ class Text2ImUNetHIP(nn.Module):
 
     # ---- reference-compatible no-ops -------------------------------------------------------------
     def convert_to_fp16(self):
-        """The reference casts conv weights to fp16 here (unet.py:566-572); precision of the HIP engine is
-        chosen by backend_dtype instead."""
+        """The reference casts its conv / attention / head weights to fp16 here and computes the torso in fp16
+        (unet.py:566-572, text2im_model2_1.py:49-55).  Same meaning here: the engine's storage and MFMA operand type becomes fp16
+        (fp32 accumulation, GroupNorm statistics, softmax and sampler state stay fp32, as in the reference's fp16 mode).  An engine
+        built with backend_dtype=torch.float32 is the parity path and stays fp32 until convert_to_fp16() is asked for explicitly."""
+        if self.backend_dtype != torch.float16:
+            if getattr(self, "_adopted", False) and not any(p.numel() for p in self.parameters()):
+                raise RuntimeError("convert_to_fp16: the fp32 parameters were released (prepare(free_params=True)); construct with "
+                                   "backend_dtype=torch.float16 instead")
+            self.backend_dtype = torch.float16
+            self._release()   # re-pack lazily in fp16
         return self
 
     def convert_to_fp32(self):
+        """unet.py:574-580: back to the fp32 parity path"""
+        if self.backend_dtype != torch.float32:
+            if getattr(self, "_adopted", False) and not any(p.numel() for p in self.parameters()):
+                raise RuntimeError("convert_to_fp32: the fp32 parameters were released (prepare(free_params=True))")
+            self.backend_dtype = torch.float32
+            self._release()
         return self
 
     def del_cache(self):
@@ -124,7 +139,7 @@ class Text2ImUNetHIP(nn.Module):
         self._arena = arena
         a = self.arch
         cfg = _lib.K22UNetConfig()
-        cfg.dtype = _lib.K22_BF16 if self.backend_dtype == torch.bfloat16 else _lib.K22_F32
+        cfg.dtype = _lib.dtype_code(self.backend_dtype)
         cfg.in_channels = a.in_channels
         cfg.model_channels = a.model_channels
         cfg.out_channels = a.out_channels

@@ -54,20 +54,74 @@ def tiny_unet22_config() -> dict:
     return dict(UNET_CONFIG_2_2, block_out_channels=(128, 256, 384, 512))
 
 
-def make_arch22(config: Optional[dict] = None, controlnet: bool = False, inpainting: bool = False) -> UNetArch:
-    c = dict(config or UNET_CONFIG_2_2)
+# diffusers `UNet2DConditionModel.__init__` defaults (models/unet_2d_condition.py, recalled): what a key absent from unet/config.json
+# resolves to.  notebooks/lora_decoder.ipynb:3668-3670 shows the decoder's unet/config.json lacking `addition_time_embed_dim`,
+# `transformer_layers_per_block`, `num_attention_heads`: all three default to values the SimpleCrossAttn / ResnetDownsample blocks never
+# read (None / 1 / None -> heads = channels // attention_head_dim), so that log does not contradict the architecture built here.
+UNET2D_DEFAULTS = {
+    "in_channels": 4, "out_channels": 4, "center_input_sample": False, "flip_sin_to_cos": True, "freq_shift": 0,
+    "down_block_types": ("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+    "mid_block_type": "UNetMidBlock2DCrossAttn", "up_block_types": ("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
+    "only_cross_attention": False, "block_out_channels": (320, 640, 1280, 1280), "layers_per_block": 2, "downsample_padding": 1,
+    "mid_block_scale_factor": 1, "act_fn": "silu", "norm_num_groups": 32, "norm_eps": 1e-5, "cross_attention_dim": 1280,
+    "transformer_layers_per_block": 1, "encoder_hid_dim": None, "encoder_hid_dim_type": None, "attention_head_dim": 8, "num_attention_heads": None,
+    "dual_cross_attention": False, "use_linear_projection": False, "class_embed_type": None, "addition_embed_type": None,
+    "addition_time_embed_dim": None, "num_class_embeds": None, "upcast_attention": False, "resnet_time_scale_shift": "default",
+    "resnet_skip_time_act": False, "resnet_out_scale_factor": 1.0, "time_embedding_type": "positional", "time_embedding_dim": None,
+    "time_embedding_act_fn": None, "timestep_post_act": None, "time_cond_proj_dim": None, "conv_in_kernel": 3, "conv_out_kernel": 3,
+    "projection_class_embeddings_input_dim": None, "class_embeddings_concat": False, "mid_block_only_cross_attention": None,
+    "cross_attention_norm": None, "addition_embed_type_num_heads": 64, "num_image_text_embeds": 32,
+}
+_ENGINE_REQUIRES = {   # values of a resolved unet/config.json the HIP engine is built for (anything else raises, nothing is guessed)
+    "act_fn": ("silu", "swish"), "norm_num_groups": (32,), "resnet_time_scale_shift": ("scale_shift",), "encoder_hid_dim_type": ("image_proj",),
+    "addition_embed_type": ("image", "image_hint"), "mid_block_type": ("UNetMidBlock2DSimpleCrossAttn",), "only_cross_attention": (False,),
+    "class_embed_type": (None,), "time_embedding_type": ("positional",), "flip_sin_to_cos": (True,), "freq_shift": (0,), "conv_in_kernel": (3,),
+    "conv_out_kernel": (3,), "attention_head_dim": (64,), "mid_block_scale_factor": (1, 1.0), "resnet_out_scale_factor": (1, 1.0),
+    "resnet_skip_time_act": (False,), "dual_cross_attention": (False,), "center_input_sample": (False,), "time_cond_proj_dim": (None,),
+    "timestep_post_act": (None,), "time_embedding_act_fn": (None,), "time_embedding_dim": (None,), "cross_attention_norm": (None,),
+    "mid_block_only_cross_attention": (None, False),
+}
+
+
+def resolve_unet22_config(config: Optional[dict] = None) -> dict:
+    """unet/config.json (or None = the recalled UNET_CONFIG_2_2) -> the full key set with diffusers' defaults for absent keys."""
+    given = {k: v for k, v in dict(config or UNET_CONFIG_2_2).items() if not k.startswith("_")}
+    c = dict(UNET2D_DEFAULTS)
+    c.update(given)
+    c["_missing_keys"] = tuple(sorted(k for k in UNET2D_DEFAULTS if k not in given))
+    return c
+
+
+def make_arch22(config: Optional[dict] = None, controlnet: Optional[bool] = None, inpainting: Optional[bool] = None) -> UNetArch:
+    """Architecture of the injected UNet2DConditionModel (kandinsky2_2_model.py:26-41) from its unet/config.json content: absent keys
+    take diffusers' defaults, every value the engine was not built for raises.  controlnet / inpainting default to what the config
+    says (addition_embed_type == "image_hint" / in_channels == 9); passing them overrides the config's in_channels as round 2 did."""
+    c = resolve_unet22_config(config)
+    for key, ok in _ENGINE_REQUIRES.items():
+        v = c[key]
+        if (tuple(v) if isinstance(v, list) else v) not in ok:
+            raise NotImplementedError(f"unet config {key}={v!r}: the HIP engine is built for {ok} (the Kandinsky 2.2 decoder UNets)")
+    if abs(float(c["norm_eps"]) - 1e-5) > 1e-12:
+        raise NotImplementedError("unet config norm_eps: the engine's GroupNorm uses 1e-5")
     boc = tuple(c["block_out_channels"])
     mc = boc[0]
     if any(v % mc for v in boc):
         raise NotImplementedError("block_out_channels must be multiples of the first")
-    if c.get("resnet_time_scale_shift", "scale_shift") != "scale_shift" or c.get("encoder_hid_dim_type", "image_proj") != "image_proj":
-        raise NotImplementedError("only the Kandinsky 2.2 decoder configuration (scale_shift resnets, image_proj context)")
+    types, ups = tuple(c["down_block_types"]), tuple(c["up_block_types"])
+    mirror = {"ResnetDownsampleBlock2D": "ResnetUpsampleBlock2D", "SimpleCrossAttnDownBlock2D": "SimpleCrossAttnUpBlock2D"}
+    if any(t not in mirror for t in types) or len(types) != len(boc) or ups != tuple(mirror[t] for t in reversed(types)):
+        raise NotImplementedError("down / up block types: ResnetDownsampleBlock2D / SimpleCrossAttnDownBlock2D and their mirrored up blocks")
+    if controlnet is None:
+        controlnet = c["addition_embed_type"] == "image_hint"
+    if inpainting is None:
+        inpainting = (not controlnet) and c["in_channels"] == 9
     if controlnet and inpainting:
         raise NotImplementedError("controlnet + inpainting")
-    types = tuple(c["down_block_types"])
+    if config is not None and "in_channels" in config and (controlnet, inpainting) == (False, False) and c["in_channels"] != 4:
+        raise NotImplementedError(f"in_channels={c['in_channels']}: 4 (text2img), 8 (ControlNet-depth: latent + hint) or 9 (inpainting)")
     att = tuple(2 ** i for i, t in enumerate(types) if "CrossAttn" in t)
     a = UNetArch(
-        in_channels=8 if controlnet else (9 if inpainting else c["in_channels"]), model_channels=mc, out_channels=c["out_channels"],
+        in_channels=8 if controlnet else (9 if inpainting else 4), model_channels=mc, out_channels=c["out_channels"],
         num_res_blocks=c["layers_per_block"], channel_mult=tuple(v // mc for v in boc), attention_ds=att,
         num_head_channels=c["attention_head_dim"], model_dim=c["cross_attention_dim"], text_dim1=1, text_dim2=1,
         image_dim=c["encoder_hid_dim"], num_image_embs=c.get("num_image_text_embeds", 32), text_ctx=0, inpainting=inpainting,
@@ -276,11 +330,14 @@ class UNet2DConditionHIP(Text2ImUNetHIP):
         self._ensure_plan(B, H, W)
         ack = added_cond_kwargs or {}
         emb, hint = ack.get("image_embeds"), ack.get("hint")
-        if self._cond_key is None or (emb is not None and emb is not self._cond_src) or (hint is not None and hint is not self._hint_src):
+        # the conditioning head is re-run whenever the tensors CHANGE, not only when they are other objects: diffusers-style callers
+        # update buffers in place (key = storage pointer, version counter, shape)
+        ident = lambda t: None if t is None else (t.data_ptr(), t._version, tuple(t.shape))  # noqa: E731
+        if self._cond_key is None or (emb is not None and ident(emb) != self._cond_src) or (hint is not None and ident(hint) != self._hint_src):
             if emb is None:
                 raise ValueError("added_cond_kwargs['image_embeds'] is required")
             self.set_condition(emb, hint)
-            self._cond_key, self._cond_src, self._hint_src = True, emb, hint
+            self._cond_key, self._cond_src, self._hint_src = True, ident(emb), ident(hint)
             self.cache = {"cached": True}
         t = torch.as_tensor(timestep, device=sample.device).float().reshape(-1)
         if t.numel() == 1:
@@ -298,35 +355,115 @@ class UNet2DConditionHIP(Text2ImUNetHIP):
         return SimpleNamespace(sample=out) if return_dict else (out,)
 
 
-class DDPMSchedulerHIP:
-    """diffusers `DDPMScheduler` as the Kandinsky 2.2 decoder configures it [scheduler_config.json, recalled]: linear betas
-    0.00085 .. 0.012 over 1000 steps, prediction_type epsilon, variance_type learned_range, clip_sample +-2, no dynamic
-    thresholding, "leading" timestep spacing.  step() runs k22_sampler_step (posterior mean / learned-range variance in one
-    launch).  For spaced timesteps the scheduler's per-step quantities (alpha_prod_t / alpha_prod_t_prev, current_beta_t) are
-    exactly improved-DDPM respacing (respace.py:83-97) over the retained timesteps, so the same step table serves both."""
+# diffusers `DDPMScheduler.__init__` defaults (schedulers/scheduling_ddpm.py of the commit the reference's notebook installs, recalled):
+# what a key ABSENT from scheduler_config.json resolves to.
+DDPM_SCHEDULER_DEFAULTS = {
+    "num_train_timesteps": 1000, "beta_start": 0.0001, "beta_end": 0.02, "beta_schedule": "linear", "trained_betas": None,
+    "variance_type": "fixed_small", "clip_sample": True, "prediction_type": "epsilon", "thresholding": False,
+    "dynamic_thresholding_ratio": 0.995, "clip_sample_range": 1.0, "sample_max_value": 1.0, "timestep_spacing": "leading", "steps_offset": 0,
+}
+# scheduler/scheduler_config.json of kandinsky-community/kandinsky-2-2-decoder, the keys this build assumes it holds [RECALLED, UNVERIFIED;
+# no checkpoint is reachable offline].  The one piece of in-tree evidence is notebooks/lora_decoder.ipynb:3661-3662: the 317-byte file
+# loaded into DDPMScheduler reports `variance_type`, `clip_sample_range`, `timestep_spacing`, `trained_betas`, `sample_max_value`,
+# `dynamic_thresholding_ratio` "not found in config ... initialized to default values" - so the decoder steps with FIXED_SMALL variance
+# (the pipeline then drops the UNet's four variance channels), "leading" spacing, and a clip range of 1.0 if it clips at all.  Round 2
+# hard-coded learned_range + clip +-2 (the 2.1 sampler's behaviour), which contradicts that log; it stays selectable
+# (SCHEDULER_CONFIG_2_2_LEARNED_RANGE) because nothing here can be pinned.  `clip_sample` IS in the file but its value is not
+# shown; False is what diffusers' own Kandinsky 2.2 test fixtures use.
+SCHEDULER_CONFIG_2_2 = {"_class_name": "DDPMScheduler", "num_train_timesteps": 1000, "beta_schedule": "linear", "beta_start": 0.00085,
+                        "beta_end": 0.012, "clip_sample": False, "prediction_type": "epsilon", "thresholding": False}
+SCHEDULER_CONFIG_2_2_LEARNED_RANGE = dict(SCHEDULER_CONFIG_2_2, variance_type="learned_range", clip_sample=True, clip_sample_range=2.0)
 
-    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, clip_sample_range=2.0):
+
+class DDPMSchedulerHIP:
+    """diffusers `DDPMScheduler` (schedulers/scheduling_ddpm.py, recalled; PARITY UNPINNED) driven by its config: constructor
+    keywords and defaults are diffusers' own (DDPM_SCHEDULER_DEFAULTS), `from_config(dict)` takes the content of a
+    scheduler_config.json and lists the keys it did not find - nothing about the checkpoint is hard-coded.  Built: linear /
+    scaled_linear / squaredcos_cap_v2 betas, epsilon prediction, variance_type fixed_small / fixed_small_log / fixed_large /
+    fixed_large_log / learned_range, clip_sample with clip_sample_range, leading / linspace / trailing spacing, steps_offset.
+    Not built (raises): thresholding=True, v / sample prediction, variance_type "learned".
+    step() runs k22_sampler_step (guidance, x0, clip, posterior mean, variance, ancestral noise in one launch); for the fixed
+    variance types both log-variance bounds of the step table are set to the fixed value, so the UNet's variance channels cancel out
+    of frac * max_log + (1 - frac) * min_log exactly as the pipeline's "drop the variance channels" rule prescribes.  For spaced
+    timesteps the per-step quantities (alpha_prod_t / alpha_prod_t_prev, current_beta_t) are exactly improved-DDPM respacing
+    (respace.py:83-97) over the retained timesteps, so the same step table serves both samplers."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", trained_betas=None,
+                 variance_type="fixed_small", clip_sample=True, prediction_type="epsilon", thresholding=False,
+                 dynamic_thresholding_ratio=0.995, clip_sample_range=1.0, sample_max_value=1.0, timestep_spacing="leading", steps_offset=0):
+        if prediction_type != "epsilon":
+            raise NotImplementedError("DDPMSchedulerHIP: prediction_type 'epsilon' only (the Kandinsky decoders)")
+        if thresholding:
+            raise NotImplementedError("DDPMSchedulerHIP: thresholding=True (per-sample dynamic thresholding) is not built")
+        if variance_type not in ("fixed_small", "fixed_small_log", "fixed_large", "fixed_large_log", "learned_range"):
+            raise NotImplementedError(f"DDPMSchedulerHIP: variance_type {variance_type!r}")
+        if timestep_spacing not in ("leading", "linspace", "trailing"):
+            raise ValueError(f"timestep_spacing {timestep_spacing!r}")
+        self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
+                                      beta_schedule=beta_schedule, trained_betas=trained_betas, variance_type=variance_type,
+                                      clip_sample=bool(clip_sample), prediction_type=prediction_type, thresholding=False,
+                                      dynamic_thresholding_ratio=dynamic_thresholding_ratio, clip_sample_range=float(clip_sample_range),
+                                      sample_max_value=sample_max_value, timestep_spacing=timestep_spacing, steps_offset=int(steps_offset))
         self.num_train_timesteps = num_train_timesteps
-        self.betas = np.linspace(beta_start, beta_end, num_train_timesteps, dtype=np.float64)
+        if trained_betas is not None:
+            self.betas = np.asarray(trained_betas, dtype=np.float64)
+        elif beta_schedule == "linear":
+            self.betas = np.linspace(beta_start, beta_end, num_train_timesteps, dtype=np.float64)
+        elif beta_schedule == "scaled_linear":
+            self.betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=np.float64) ** 2
+        elif beta_schedule == "squaredcos_cap_v2":
+            f = lambda t: math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2  # noqa: E731
+            self.betas = np.array([min(1 - f((i + 1) / num_train_timesteps) / f(i / num_train_timesteps), 0.999) for i in range(num_train_timesteps)])
+        else:
+            raise NotImplementedError(f"beta_schedule {beta_schedule!r}")
         self.alphas_cumprod = np.cumprod(1.0 - self.betas)
-        self.clip = float(clip_sample_range)
+        self.clip = float(clip_sample_range) if clip_sample else float("inf")
         self.init_noise_sigma = 1.0
         self.timesteps = None
+        self.missing_keys: tuple = ()
+
+    @classmethod
+    def from_config(cls, config: dict):
+        """`DDPMScheduler.from_config(scheduler_config.json)`: keys of the file override diffusers' defaults; like diffusers, the
+        keys the file does not hold are reported (self.missing_keys) - they are what "initialized to default values" names."""
+        known = {k: v for k, v in dict(config).items() if k in DDPM_SCHEDULER_DEFAULTS}
+        unknown = [k for k in config if k not in DDPM_SCHEDULER_DEFAULTS and not k.startswith("_")]
+        if unknown:
+            raise ValueError(f"DDPMSchedulerHIP.from_config: keys this scheduler does not know: {unknown}")
+        cname = dict(config).get("_class_name", "DDPMScheduler")
+        if cname != "DDPMScheduler":
+            raise NotImplementedError(f"scheduler class {cname!r}: only DDPMScheduler (what kandinsky2_2_model.py:29-41 loads) is built")
+        sch = cls(**known)
+        sch.missing_keys = tuple(sorted(k for k in DDPM_SCHEDULER_DEFAULTS if k not in known))
+        return sch
 
     def set_timesteps(self, num_inference_steps: int, device="cuda"):
-        ratio = self.num_train_timesteps // num_inference_steps
-        ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].astype(np.int64)     # "leading" spacing
+        T, c = self.num_train_timesteps, self.config
+        if num_inference_steps > T:
+            raise ValueError("num_inference_steps exceeds num_train_timesteps")
+        ratio = T // num_inference_steps
+        if c.timestep_spacing == "leading":
+            ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].astype(np.int64) + c.steps_offset
+        elif c.timestep_spacing == "linspace":
+            ts = np.linspace(0, T - 1, num_inference_steps).round()[::-1].astype(np.int64)
+        else:
+            ts = np.round(np.arange(T, 0, -T / num_inference_steps)).astype(np.int64) - 1
         self.num_inference_steps = num_inference_steps
         ac = self.alphas_cumprod
         tab = np.zeros((num_inference_steps, 8), dtype=np.float32)
         for row, t in enumerate(ts):
-            prev = t - ratio
+            prev = t - ratio                                          # DDPMScheduler.previous_timestep
             a_t, a_prev = ac[t], (ac[prev] if prev >= 0 else 1.0)
             cur_alpha = a_t / a_prev
             cur_beta = 1.0 - cur_alpha
-            var = max((1.0 - a_prev) / (1.0 - a_t) * cur_beta, 1e-20)
+            var = max((1.0 - a_prev) / (1.0 - a_t) * cur_beta, 1e-20)  # _get_variance
+            lo, hi = math.log(var), math.log(cur_beta)                 # learned_range: min_log, max_log
+            if c.variance_type in ("fixed_small", "fixed_small_log"):
+                hi = lo                                                # std = sqrt(var) (= exp(0.5 log var)) whatever the UNet predicts
+            elif c.variance_type in ("fixed_large", "fixed_large_log"):
+                lo = hi
             tab[row] = [math.sqrt(1.0 / a_t), math.sqrt(1.0 / a_t - 1.0), math.sqrt(a_prev) * cur_beta / (1.0 - a_t),
-                        math.sqrt(cur_alpha) * (1.0 - a_prev) / (1.0 - a_t), math.log(var), math.log(cur_beta), 1.0 if t > 0 else 0.0, float(t)]
+                        math.sqrt(cur_alpha) * (1.0 - a_prev) / (1.0 - a_t), lo, hi, 1.0 if t > 0 else 0.0, float(t)]
         self._table_host = tab
         self._table = torch.from_numpy(tab).to(device)
         self._row = {int(t): i for i, t in enumerate(ts)}
@@ -354,7 +491,8 @@ class DDPMSchedulerHIP:
     @torch.no_grad()
     def step(self, model_output, timestep, sample, generator=None, noise: Optional[torch.Tensor] = None, return_dict: bool = True,
              guidance_scale: Optional[float] = None):
-        """model_output [N,8,h,w] = (eps | learned variance) already guided, sample [N,4,h,w] -> prev_sample.  With
+        """model_output [N,8,h,w] = (eps | variance channels: used by learned_range, ignored by the fixed variance types) already
+        guided, sample [N,4,h,w] -> prev_sample.  With
         guidance_scale=..., model_output is the RAW UNet output of the CFG batch ordered [cond | uncond] and sample holds the
         duplicated halves (the fused call the 2.2 pipeline below makes)."""
         L = _lib.lib()
@@ -366,11 +504,15 @@ class DDPMSchedulerHIP:
         need = L.k22_sampler_scratch_bytes(N, HW)
         if self._scratch is None or self._scratch.numel() < need:
             self._scratch = torch.empty(need, dtype=torch.uint8, device=sample.device)
-        nz = noise if noise is not None else torch.randn(sample.shape, generator=generator, device=sample.device)
+        if noise is not None:
+            nz = noise
+        else:   # diffusers' randn_tensor: a CPU generator draws on the CPU and the noise is moved to the sample's device
+            gdev = generator.device if generator is not None else sample.device
+            nz = torch.randn(sample.shape, generator=generator, device=gdev).to(sample.device)
         x, mo = sample.detach().float().contiguous(), model_output.detach().float().contiguous()
         out = torch.empty_like(x)
         fused = guidance_scale is not None
         _lib.check(L.k22_sampler_step(x.data_ptr(), mo.data_ptr(), nz.float().contiguous().data_ptr(), None, None, self._table.data_ptr(), row,
-                                      float(guidance_scale) if fused else 1.0, 1 if fused else 0, -self.clip, self.clip, -1, 0.0,
+                                      float(guidance_scale) if fused else 1.0, 1 if fused else 0, -min(self.clip, 3.0e38), min(self.clip, 3.0e38), -1, 0.0,
                                       self._scratch.data_ptr(), out.data_ptr(), None, N, HW, _lib.current_stream()))
         return SimpleNamespace(prev_sample=out) if return_dict else (out,)

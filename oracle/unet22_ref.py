@@ -3,7 +3,8 @@
 
     UNet2DConditionModel.forward        (kandinsky-2-2-decoder / -controlnet-depth / -decoder-inpaint `unet`)
     KandinskyV22[Controlnet]Pipeline    denoising loop with classifier-free guidance
-    DDPMScheduler.step                  variance_type = "learned_range", prediction_type = "epsilon", clip_sample +-2
+    DDPMScheduler.step                  driven by a scheduler_config.json dict + diffusers' defaults (SCHED_2_2 below: fixed_small
+                                        variance, no clipping - see the reconciliation note there; learned_range + clip +-2 also covered)
 
 PARITY UNPINNED.  `diffusers` is a third-party dependency of the reference that is neither vendored under /root/reference, nor
 pinned (setup.py:27 lists it without a version; the notebooks install huggingface/diffusers at commit
@@ -140,49 +141,104 @@ def unet22_forward(sd, cfg, sample, timestep, image_embeds, hint=None):
     return _conv(sd, "conv_out", h)
 
 
-class RefDDPMScheduler:
-    """DDPMScheduler(beta_schedule="linear", beta_start=0.00085, beta_end=0.012, variance_type="learned_range",
-    prediction_type="epsilon", clip_sample=True, clip_sample_range=2.0, thresholding=False, timestep_spacing="leading")."""
+# diffusers DDPMScheduler.__init__ defaults (schedulers/scheduling_ddpm.py, recalled): the value of every key a scheduler_config.json omits
+DDPM_DEFAULTS = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", variance_type="fixed_small",
+                     clip_sample=True, prediction_type="epsilon", thresholding=False, clip_sample_range=1.0, timestep_spacing="leading",
+                     steps_offset=0)
+# What this oracle assumes kandinsky-2-2-decoder/scheduler/scheduler_config.json holds (RECALLED, UNVERIFIED).  Reconciled with the only
+# in-tree evidence, /root/reference/notebooks/lora_decoder.ipynb:3661-3662: loading that 317-byte file into DDPMScheduler logs
+#   {'trained_betas', 'sample_max_value', 'dynamic_thresholding_ratio', 'clip_sample_range', 'variance_type', 'timestep_spacing'} was not
+#   found in config. Values will be initialized to default values.
+# i.e. variance_type = "fixed_small" (the pipeline then drops the UNet's variance channels), timestep_spacing = "leading",
+# clip_sample_range = 1.0.  (:3668-3670 logs the same for unet/config.json's addition_time_embed_dim, transformer_layers_per_block,
+# num_attention_heads - defaults no SimpleCrossAttn block reads.)  Round 2's learned_range + clip +-2 contradicted that log; it is kept
+# as SCHED_2_2_LEARNED_RANGE and tested too, since neither can be pinned here.  clip_sample is in the file, value unknown: False as in
+# diffusers' own Kandinsky 2.2 test fixtures.
+SCHED_2_2 = dict(num_train_timesteps=1000, beta_schedule="linear", beta_start=0.00085, beta_end=0.012, clip_sample=False,
+                 prediction_type="epsilon", thresholding=False)
+SCHED_2_2_LEARNED_RANGE = dict(SCHED_2_2, variance_type="learned_range", clip_sample=True, clip_sample_range=2.0)
 
-    def __init__(self, num_inference_steps, num_train=1000, beta_start=0.00085, beta_end=0.012, clip=2.0):
-        self.betas = torch.linspace(beta_start, beta_end, num_train, dtype=torch.float32)
+
+class RefDDPMScheduler:
+    """diffusers DDPMScheduler.set_timesteps / step / _get_variance for a scheduler_config.json dict (absent keys = DDPM_DEFAULTS)."""
+
+    def __init__(self, num_inference_steps, config=None):
+        c = dict(DDPM_DEFAULTS)
+        c.update({k: v for k, v in dict(SCHED_2_2 if config is None else config).items() if not k.startswith("_")})
+        assert c["prediction_type"] == "epsilon" and not c["thresholding"]
+        self.c = c
+        T = c["num_train_timesteps"]
+        if c["beta_schedule"] == "linear":
+            self.betas = torch.linspace(c["beta_start"], c["beta_end"], T, dtype=torch.float32)
+        elif c["beta_schedule"] == "scaled_linear":
+            self.betas = torch.linspace(c["beta_start"] ** 0.5, c["beta_end"] ** 0.5, T, dtype=torch.float32) ** 2
+        else:
+            raise NotImplementedError(c["beta_schedule"])
         self.alphas_cumprod = torch.cumprod(1.0 - self.betas, dim=0)
-        self.ratio = num_train // num_inference_steps
-        self.timesteps = (torch.arange(0, num_inference_steps) * self.ratio).flip(0)
-        self.clip = clip
+        self.ratio = T // num_inference_steps
+        if c["timestep_spacing"] == "leading":
+            self.timesteps = (torch.arange(0, num_inference_steps) * self.ratio).flip(0) + c["steps_offset"]
+        elif c["timestep_spacing"] == "linspace":
+            self.timesteps = torch.linspace(0, T - 1, num_inference_steps, dtype=torch.float64).round().flip(0).long()
+        else:   # trailing
+            self.timesteps = torch.arange(T, 0, -T / num_inference_steps, dtype=torch.float64).round().long() - 1
+        self.learned = c["variance_type"] in ("learned", "learned_range")
 
     def step(self, model_output, t, sample, noise):
         t = int(t)
         prev_t = t - self.ratio
-        eps, pv = model_output[:, :4], model_output[:, 4:]
+        pv = None
+        if model_output.shape[1] == 2 * sample.shape[1] and self.learned:
+            model_output, pv = model_output[:, :4], model_output[:, 4:]
+        eps = model_output
         a_t = self.alphas_cumprod[t]
         a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else torch.tensor(1.0)
         b_t, b_prev = 1 - a_t, 1 - a_prev
         cur_alpha = a_t / a_prev
         cur_beta = 1 - cur_alpha
-        x0 = ((sample - b_t ** 0.5 * eps) / a_t ** 0.5).clamp(-self.clip, self.clip)
+        x0 = (sample - b_t ** 0.5 * eps) / a_t ** 0.5
+        if self.c["clip_sample"]:
+            x0 = x0.clamp(-self.c["clip_sample_range"], self.c["clip_sample_range"])
         mean = (a_prev ** 0.5 * cur_beta) / b_t * x0 + cur_alpha ** 0.5 * b_prev / b_t * sample
         if t > 0:
             var = torch.clamp(b_prev / b_t * cur_beta, min=1e-20)
-            frac = (pv + 1) / 2
-            logvar = frac * torch.log(cur_beta) + (1 - frac) * torch.log(var)
-            mean = mean + torch.exp(0.5 * logvar) * noise
+            vt = self.c["variance_type"]
+            if vt == "fixed_small":
+                std = var ** 0.5
+            elif vt == "fixed_small_log":
+                std = torch.exp(0.5 * torch.log(var))
+            elif vt == "fixed_large":
+                std = cur_beta ** 0.5
+            elif vt == "fixed_large_log":
+                std = torch.exp(0.5 * torch.log(cur_beta))
+            elif vt == "learned_range":
+                frac = (pv + 1) / 2
+                std = torch.exp(0.5 * (frac * torch.log(cur_beta) + (1 - frac) * torch.log(var)))
+            else:
+                raise NotImplementedError(vt)
+            mean = mean + std * noise
         return mean
 
 
+def _guided(sch, out, n_lat, guidance_scale):
+    """the CFG + variance handling of KandinskyV22Pipeline.__call__ (pipelines/kandinsky2_2/pipeline_kandinsky2_2.py, recalled):
+    guide eps, keep the CONDITIONAL half's variance channels, and drop them unless the scheduler's variance_type is learned*."""
+    eps, var = out.split(n_lat, dim=1)
+    eps_u, eps_c = eps.chunk(2)
+    _, var_c = var.chunk(2)
+    eps = eps_u + guidance_scale * (eps_c - eps_u)
+    return torch.cat([eps, var_c], dim=1) if sch.learned else eps
+
+
 @torch.no_grad()
-def decoder_loop(unet_fn, latents, image_embeds, negative_image_embeds, num_steps, guidance_scale, noise_seq, hint=None):
+def decoder_loop(unet_fn, latents, image_embeds, negative_image_embeds, num_steps, guidance_scale, noise_seq, hint=None, sched_cfg=None):
     """KandinskyV22Pipeline.__call__ denoising loop: batch [uncond | cond], variance of the conditional half."""
-    sch = RefDDPMScheduler(num_steps)
+    sch = RefDDPMScheduler(num_steps, sched_cfg)
     emb = torch.cat([negative_image_embeds, image_embeds], 0)
     hint2 = None if hint is None else torch.cat([hint, hint], 0)
     for k, t in enumerate(sch.timesteps):
         out = unet_fn(torch.cat([latents] * 2), t, emb, hint2)
-        eps, var = out.split(latents.shape[1], dim=1)
-        eps_u, eps_c = eps.chunk(2)
-        _, var_c = var.chunk(2)
-        eps = eps_u + guidance_scale * (eps_c - eps_u)
-        latents = sch.step(torch.cat([eps, var_c], dim=1), t, latents, noise_seq[k])
+        latents = sch.step(_guided(sch, out, latents.shape[1], guidance_scale), t, latents, noise_seq[k])
     return latents
 
 
@@ -197,18 +253,14 @@ def _cfg_step(sch, unet_fn, latents, emb, t, guidance_scale, nz, extra=None):
     if extra is not None:
         inp = torch.cat([inp, extra], dim=1)
     out = unet_fn(inp, t, emb, None)
-    eps, var = out.split(latents.shape[1], dim=1)
-    eps_u, eps_c = eps.chunk(2)
-    _, var_c = var.chunk(2)
-    eps = eps_u + guidance_scale * (eps_c - eps_u)
-    return sch.step(torch.cat([eps, var_c], dim=1), t, latents, nz)
+    return sch.step(_guided(sch, out, latents.shape[1], guidance_scale), t, latents, nz)
 
 
 @torch.no_grad()
-def img2img_loop(unet_fn, image_latents, image_embeds, negative_image_embeds, num_steps, strength, guidance_scale, noise, noise_seq):
+def img2img_loop(unet_fn, image_latents, image_embeds, negative_image_embeds, num_steps, strength, guidance_scale, noise, noise_seq, sched_cfg=None):
     """KandinskyV22Img2ImgPipeline.__call__ (PARITY UNPINNED, recalled): get_timesteps(strength), add_noise(movq latents, noise,
     timesteps[0]), then the text2img loop over the retained timesteps."""
-    sch = RefDDPMScheduler(num_steps)
+    sch = RefDDPMScheduler(num_steps, sched_cfg)
     t_start = max(num_steps - min(int(num_steps * strength), num_steps), 0)
     ts = sch.timesteps[t_start:]
     emb = torch.cat([negative_image_embeds, image_embeds], 0)
@@ -219,11 +271,11 @@ def img2img_loop(unet_fn, image_latents, image_embeds, negative_image_embeds, nu
 
 
 @torch.no_grad()
-def inpaint_loop(unet_fn, image_latents, mask, latents, image_embeds, negative_image_embeds, num_steps, guidance_scale, noise_seq):
+def inpaint_loop(unet_fn, image_latents, mask, latents, image_embeds, negative_image_embeds, num_steps, guidance_scale, noise_seq, sched_cfg=None):
     """KandinskyV22InpaintPipeline.__call__ denoising loop (PARITY UNPINNED, recalled).  image_latents [1,4,h,w] = movq.encode(image);
     mask [1,1,h,w] after nearest resize + prepare_mask (1 = keep); latents [bs,4,h,w] = the initial noise, also the noise the known
     region is re-noised with."""
-    sch = RefDDPMScheduler(num_steps)
+    sch = RefDDPMScheduler(num_steps, sched_cfg)
     bs = latents.shape[0]
     emb = torch.cat([negative_image_embeds, image_embeds], 0)
     masked = image_latents * mask

@@ -7,7 +7,7 @@ from kandinsky2_amd import _lib
 
 
 def tdt(dtype_code):
-    return torch.bfloat16 if dtype_code == _lib.K22_BF16 else torch.float32
+    return {_lib.K22_BF16: torch.bfloat16, _lib.K22_F16: torch.float16, _lib.K22_F32: torch.float32}[dtype_code]
 
 
 def pad_rows(w, mult=64):

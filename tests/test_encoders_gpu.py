@@ -17,7 +17,7 @@ import kandinsky2_amd as k22
 pytestmark = pytest.mark.gpu
 
 # measured on MI355X (profiles/r02_parity_lines.txt): fp32 <= 1.9e-6; bf16 tiny 3.4e-3..7.0e-3, production towers 5.5e-3..1.27e-2
-BACKENDS = [(torch.float32, 2e-5, 2e-5), (torch.bfloat16, 1.5e-2, 2.5e-2)]
+BACKENDS = [(torch.float32, 2e-5, 2e-5), (torch.bfloat16, 1.5e-2, 2.5e-2), (torch.float16, 2e-3, 3.2e-3)]
 
 
 def _fx(golden_dir, name):

@@ -35,6 +35,14 @@ BF16_BOUNDS = {
     "c3_forward": {"first_forward_rel": 1.5e-2},                                 # measured 7.4e-3
 }
 
+# fp16 engine (the reference's own use_fp16 mode; same kernels and speed as bf16, 3 more mantissa bits): bounds = 2x the distance the
+# storage-rounding emulation of oracle/drift_ablation.py predicts at C2 (tests/golden/drift_ablation.json "all:fp16": first forward
+# 8.8e-4 of scale, final latent 2.8e-3 max-abs / 5.1e-4 rms); the measured values are printed and recorded
+FP16_BOUNDS = {
+    "c2_text2img": {"first_forward_rel": 1.8e-3, "traj": (8e-3, 1.1e-3), "final": (5.6e-3, 1.1e-3)},
+    "c4_inpaint": {"first_forward_rel": 2.0e-3, "traj": (5e-3, 4e-4), "final": (5e-3, 4e-4)},
+}
+
 _SD = {}
 _REPORT = {}
 
@@ -193,6 +201,33 @@ def test_full_size_p_sampler_bf16_measured_bound(golden_dir, name):
     assert torch.isfinite(traj["final"]).all()
     assert e_first <= bound["first_forward_rel"] * scale
     assert worst[0] <= bound["traj"][0] and worst[1] <= bound["traj"][1]
+
+
+@pytest.mark.parametrize("name", ["c2_text2img", "c4_inpaint"])
+def test_full_size_p_sampler_fp16_measured_bound(golden_dir, name):
+    """backend_dtype=torch.float16 - the reference's own reduced-precision mode (use_fp16=True + convert_to_fp16(),
+    kandinsky2_1_model.py:92-97) and the cheapest engine mode whose 50-step final latent stays within ~3e-3 of the fp32 reference
+    (oracle/drift_ablation.py: bf16 WEIGHT rounding alone costs 1.4e-2, so no bf16 mode can): same kernels, bytes and MFMA rate as bf16."""
+    fx = _load(golden_dir, name)
+    first, traj = _loop_case(fx, torch.float16)
+    scale = fx["first_out"].abs().max().item()
+    e_first = (first - fx["first_out"]).abs().max().item()
+    print(f"{name} fp16: first forward max|d| {e_first:.3e} = {e_first / scale:.3e} of scale {scale:.2f}")
+    _record(name, "fp16_first_forward", max_abs=e_first, scale=scale, rel=e_first / scale)
+    bound = FP16_BOUNDS[name]
+    worst = (0.0, 0.0)
+    for n in sorted(fx["traj"].keys()):
+        ma, rms = _dist(traj[n], fx["traj"][n])
+        worst = (max(worst[0], ma), max(worst[1], rms))
+        print(f"{name} fp16: latent after step {n:2d}: max|d| {ma:.3e} rms {rms:.3e}")
+        _record(name, f"fp16_step{n}", max_abs=ma, rms=rms)
+    ma, rms = _dist(traj["final"], fx["final"])
+    print(f"{name} fp16: FINAL latent ({fx['steps']} steps): max|d| {ma:.3e} rms {rms:.3e}  (latent range [-1, 1])")
+    _record(name, "fp16_final", max_abs=ma, rms=rms)
+    assert torch.isfinite(traj["final"]).all()
+    assert e_first <= bound["first_forward_rel"] * scale
+    assert worst[0] <= bound["traj"][0] and worst[1] <= bound["traj"][1]
+    assert ma <= bound["final"][0] and rms <= bound["final"][1]
 
 
 def _compact_err(out, c):

@@ -388,16 +388,21 @@ def test_unet22_oracle_runs_and_scheduler_tables_agree():
     x, emb, hint = torch.randn(2, 4, 8, 8, generator=g), torch.randn(2, 1280, generator=g), torch.rand(2, 3, 64, 64, generator=g)
     out = unet22_ref.unet22_forward(sd, cfg, x, torch.tensor([980, 0]), emb, hint)
     assert out.shape == (2, 8, 8, 8) and torch.isfinite(out).all() and out.abs().max() > 1e-3
-    sch = k22.DDPMSchedulerHIP().set_timesteps(50, device="cpu")
-    ref = unet22_ref.RefDDPMScheduler(50)
-    assert sch.timesteps.tolist() == ref.timesteps.tolist()
-    tab = sch._table_host
-    ac = ref.alphas_cumprod.double().numpy()
-    for row, t in enumerate(sch.timesteps.tolist()):
-        prev = t - 20
-        a_prev = ac[prev] if prev >= 0 else 1.0
-        assert abs(tab[row, 0] - (1 / ac[t]) ** 0.5) < 1e-5 * tab[row, 0]
-        assert abs(tab[row, 5] - np.log(1 - ac[t] / a_prev)) < 1e-4
+    for cfg_hip, cfg_ref in ((k22.SCHEDULER_CONFIG_2_2_LEARNED_RANGE, unet22_ref.SCHED_2_2_LEARNED_RANGE), (k22.SCHEDULER_CONFIG_2_2, unet22_ref.SCHED_2_2)):
+        sch = k22.DDPMSchedulerHIP.from_config(cfg_hip).set_timesteps(50, device="cpu")
+        ref = unet22_ref.RefDDPMScheduler(50, cfg_ref)
+        assert sch.timesteps.tolist() == ref.timesteps.tolist()
+        tab = sch._table_host
+        ac = ref.alphas_cumprod.double().numpy()
+        for row, t in enumerate(sch.timesteps.tolist()):
+            prev = t - 20
+            a_prev = ac[prev] if prev >= 0 else 1.0
+            assert abs(tab[row, 0] - (1 / ac[t]) ** 0.5) < 1e-5 * tab[row, 0]
+            log_var = np.log(max((1 - a_prev) / (1 - ac[t]) * (1 - ac[t] / a_prev), 1e-20))
+            assert abs(tab[row, 4] - log_var) < 1e-4 * max(1.0, abs(log_var))
+            # learned_range interpolates between log(posterior variance) and log(beta_t); fixed_small pins both bounds to the former
+            want_hi = np.log(1 - ac[t] / a_prev) if ref.learned else log_var
+            assert abs(tab[row, 5] - want_hi) < 1e-4 * max(1.0, abs(want_hi))
     # respacing identity: betas' = 1 - abar_t / abar_prev over the retained timesteps
     d = k22.create_gaussian_diffusion(**dict(k22.DIFFUSION_CONFIG_2_1, timestep_respacing="50"))
     assert d.num_timesteps == 50

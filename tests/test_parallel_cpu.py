@@ -6,7 +6,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from kandinsky2_amd.parallel import broadcast_arena, gather_outputs, shard_range
+from kandinsky2_amd.parallel import broadcast_arena, gather_outputs, launch_ranks, shard_range
 
 
 def _free_port():
@@ -60,3 +60,36 @@ def test_arena_broadcast_and_gather_gloo_world2():
         p.join(60)
     assert all(ok for _, ok, _ in res), res
     assert sorted(span for _, _, span in res) == [(0, 4), (4, 7)]
+
+
+def _launched_rank(rank, world, outdir):
+    """what a bench rank does with the environment the self-launcher exports: init from env, one collective, observed world size"""
+    assert int(os.environ["RANK"]) == rank and int(os.environ["WORLD_SIZE"]) == world and os.environ["MASTER_ADDR"] == "127.0.0.1"
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    try:
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        with open(os.path.join(outdir, f"rank{rank}.txt"), "w") as f:
+            f.write(f"{dist.get_world_size()} {t.item()}")
+    finally:
+        dist.destroy_process_group()
+
+
+def _failing_rank(rank, world):
+    if rank == 1:
+        raise SystemExit(3)
+
+
+def test_self_launcher_exports_the_torchrun_environment_gloo_world2(tmp_path):
+    """`bench.py --gpus N` without torch.distributed.run spawns its ranks itself (kandinsky2_amd.parallel.launch_ranks)."""
+    launch_ranks(_launched_rank, 2, args=(str(tmp_path),))
+    got = sorted(open(tmp_path / f"rank{r}.txt").read() for r in range(2))
+    assert got == ["2 2.0", "2 2.0"]            # both ranks saw world size 2 and the max over ranks
+
+
+def test_self_launcher_fails_loudly():
+    import pytest
+    with pytest.raises(RuntimeError, match="only 1 device"):
+        launch_ranks(_launched_rank, 4, args=("/tmp",), devices_visible=1)       # never a quiet single-rank run
+    with pytest.raises(RuntimeError, match="ranks failed"):
+        launch_ranks(_failing_rank, 2)

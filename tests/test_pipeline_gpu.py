@@ -44,7 +44,7 @@ def _weights(task_type):
 
 def _pipe(task_type, backend=torch.float32):
     cfg, arch, unet_sd, hp, prior_sd, marc, movq_sd, cm, cs = _weights(task_type)
-    return k22.Kandinsky2_1HIP(cfg, unet_sd, prior_sd, "cuda", task_type=task_type, backend_dtype=backend)
+    return k22.Kandinsky2_1HIP(cfg, unet_sd, prior_sd, "cuda", task_type=task_type, conditioner="seeded", backend_dtype=backend)
 
 
 def _oracle_image_emb(pipe, prompt, bs, scale, g):

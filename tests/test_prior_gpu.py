@@ -58,7 +58,7 @@ def _model(fx, backend, cm, cs):
 
 
 @pytest.mark.parametrize("name", FIXTURES)
-@pytest.mark.parametrize("backend,tol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("backend,tol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2), (torch.float16, 4e-3)])
 def test_prior_transformer_vs_reference_golden(golden_dir, name, backend, tol):
     fx = _fixture(golden_dir, name)
     cm, cs, txt_feat, txt_seq, mask, x, g = _inputs(fx["bs"])

@@ -43,7 +43,7 @@ def _inputs(B, h, w, seed=4, hint=False):
 
 
 @pytest.mark.parametrize("controlnet", [False, True])
-@pytest.mark.parametrize("backend,tol", [(torch.float32, 2e-4), (torch.bfloat16, 2.5e-2)])
+@pytest.mark.parametrize("backend,tol", [(torch.float32, 2e-4), (torch.bfloat16, 2.5e-2), (torch.float16, 3.2e-3)])
 def test_unet22_forward_vs_oracle(controlnet, backend, tol):
     cfg, sd, m = _unet(controlnet, backend)
     B, h, w = 4, 16, 24
@@ -67,24 +67,43 @@ def test_unet22_forward_vs_oracle(controlnet, backend, tol):
         m(x.cuda(), 500, added_cond_kwargs={"image_embeds": emb[:2].cuda()} if not controlnet else {"image_embeds": emb.cuda(), "hint": hint[:, :, :8].cuda()})
 
 
-def test_ddpm_scheduler_step_vs_oracle():
-    """DDPMScheduler.step(learned_range, clip +-2) as one k22_sampler_step launch, at every timestep of a 10-step schedule."""
+SCHED_VARIANTS = {
+    "config_2_2": (k22.SCHEDULER_CONFIG_2_2, unet22_ref.SCHED_2_2),                              # fixed_small, no clipping (what the notebook log implies)
+    "learned_range": (k22.SCHEDULER_CONFIG_2_2_LEARNED_RANGE, unet22_ref.SCHED_2_2_LEARNED_RANGE),  # round 2's assumption
+    "diffusers_defaults": ({}, {}),                                                               # betas 1e-4 .. 0.02, fixed_small, clip +-1
+    "other": (dict(k22.SCHEDULER_CONFIG_2_2, beta_schedule="scaled_linear", variance_type="fixed_large", timestep_spacing="trailing",
+                   clip_sample=True, clip_sample_range=1.5),
+              dict(unet22_ref.SCHED_2_2, beta_schedule="scaled_linear", variance_type="fixed_large", timestep_spacing="trailing",
+                   clip_sample=True, clip_sample_range=1.5)),
+}
+
+
+@pytest.mark.parametrize("variant", list(SCHED_VARIANTS))
+def test_ddpm_scheduler_step_vs_oracle(variant):
+    """DDPMScheduler.step as one k22_sampler_step launch at every timestep of a 10-step schedule, for the scheduler_config.json
+    variants (fixed_small = variance channels ignored; learned_range; clipping on / off; spacing).  Oracle unpinned."""
+    cfg_hip, cfg_ref = SCHED_VARIANTS[variant]
     g = torch.Generator().manual_seed(5)
     N, h, w = 2, 8, 8
-    sch = k22.DDPMSchedulerHIP().set_timesteps(10)
-    ref = unet22_ref.RefDDPMScheduler(10)
-    assert sch.timesteps.tolist() == ref.timesteps.tolist() == list(range(900, -1, -100))
+    sch = k22.DDPMSchedulerHIP.from_config(cfg_hip).set_timesteps(10)
+    ref = unet22_ref.RefDDPMScheduler(10, cfg_ref)
+    assert sch.timesteps.tolist() == ref.timesteps.tolist()
     for t in sch.timesteps.tolist():
         mo = torch.randn(N, 8, h, w, generator=g)
         mo[:, 4:] = mo[:, 4:].clamp(-1, 1)
         x, nz = torch.randn(N, 4, h, w, generator=g) * 1.5, torch.randn(N, 4, h, w, generator=g)
-        want = ref.step(mo, t, x, nz)
+        want = ref.step(mo if ref.learned else mo[:, :4], t, x, nz)       # the pipeline drops the variance channels for fixed variance
         got = sch.step(mo.cuda(), t, x.cuda(), noise=nz.cuda()).prev_sample.cpu()
         assert (got - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item()), t
+    # diffusers' randn_tensor accepts a CPU generator for a GPU sample: drawn on the CPU, moved over
+    gc = torch.Generator().manual_seed(7)
+    a = sch.step(mo.cuda(), 100 if 100 in sch._row else sch.timesteps.tolist()[5], x.cuda(), generator=gc).prev_sample
+    assert torch.isfinite(a).all()
 
 
+@pytest.mark.parametrize("variant", ["config_2_2", "learned_range"])
 @pytest.mark.parametrize("controlnet", [False, True])
-def test_decoder_loop_vs_oracle_fp32(controlnet):
+def test_decoder_loop_vs_oracle_fp32(controlnet, variant):
     """KandinskyV22[Controlnet]Pipeline denoising loop (CFG, conditional variance, DDPM step), 5 steps, final latent <= 1e-3."""
     cfg, sd, m = _unet(controlnet, torch.float32)
     bs, h, w, steps, gs = 2, 16, 16, 5, 4.0
@@ -93,11 +112,13 @@ def test_decoder_loop_vs_oracle_fp32(controlnet):
     pos, neg = torch.randn(bs, 1280, generator=g), torch.randn(bs, 1280, generator=g)
     hint = torch.rand(bs, 3, 8 * h, 8 * w, generator=g) if controlnet else None
     nz = torch.randn(steps, bs, 4, h, w, generator=g)
-    want = unet22_ref.decoder_loop(lambda xx, t, e, hh: unet22_ref.unet22_forward(sd, cfg, xx, t, e, hh), lat, pos, neg, steps, gs, nz, hint)
+    cfg_hip, cfg_ref = SCHED_VARIANTS[variant]
+    want = unet22_ref.decoder_loop(lambda xx, t, e, hh: unet22_ref.unet22_forward(sd, cfg, xx, t, e, hh), lat, pos, neg, steps, gs, nz, hint,
+                                   sched_cfg=cfg_ref)
     marc = k22.MoVQArch(k22.MOVQ_CONFIG_2_1["ddconfig"])
     movq = k22.MoVQDecoderHIP(backend_dtype=torch.float32)
     movq.load_state_dict(k22.init_movq_state_dict(marc, seed=0), strict=True)
-    dec = k22.pipeline22.KandinskyV22DecoderHIP(m, movq.to("cuda"))
+    dec = k22.pipeline22.KandinskyV22DecoderHIP(m, movq.to("cuda"), scheduler=k22.DDPMSchedulerHIP.from_config(cfg_hip))
     got = dec(pos.cuda(), neg.cuda(), height=8 * h, width=8 * w, num_inference_steps=steps, guidance_scale=gs,
               hint=None if hint is None else hint.cuda(), latents=lat.cuda(), noise_seq=nz.cuda(), output_type="latent").cpu()
     err = (got - want).abs().max().item()
@@ -136,7 +157,7 @@ def test_scheduler_add_noise_and_blend_kernel():
     """k22_blend_noised: DDPMScheduler.add_noise and the inpainting re-imposition, against the torch expressions"""
     from kandinsky2_amd import _lib
     g = torch.Generator().manual_seed(9)
-    sch = k22.DDPMSchedulerHIP().set_timesteps(10)
+    sch = k22.DDPMSchedulerHIP.from_config(k22.SCHEDULER_CONFIG_2_2).set_timesteps(10)
     ref = unet22_ref.RefDDPMScheduler(10)
     x, nz = torch.randn(3, 4, 12, 20, generator=g), torch.randn(3, 4, 12, 20, generator=g)
     for t in (900, 400, 0):
@@ -223,7 +244,7 @@ def test_kandinsky2_2_wrapper_task_types():
     for task, inp in (("text2img", False), ("img2img", False), ("inpainting", True)):
         arch = k22.make_arch22(k22.tiny_unet22_config(), inpainting=inp)
         mdl = k22.pipeline22.Kandinsky2_2HIP("cuda", task, unet_state_dict=k22.init_unet22_state_dict(arch, seed=0), movq_state_dict=msd,
-                                             unet_config=k22.tiny_unet22_config(), backend_dtype=torch.float32)
+                                             unet_config=k22.tiny_unet22_config(), conditioner="seeded", backend_dtype=torch.float32)
         if task == "text2img":
             out = mdl.generate_text2img("a cat", batch_size=2, decoder_steps=3, h=H, w=H, output_type="uint8")
             mix = mdl.mix_images(["a cat", img], [0.3, 0.7], batch_size=1, decoder_steps=2, h=H, w=H, output_type="uint8")

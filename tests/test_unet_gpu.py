@@ -55,7 +55,7 @@ def _setup(fx, backend_dtype, use_graph=False):
 
 
 @pytest.mark.parametrize("name", ["tiny_text2img", "tiny_inpaint", "full_c1_text2img"])
-@pytest.mark.parametrize("backend,tol", [(torch.float32, 2e-4), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("backend,tol", [(torch.float32, 2e-4), (torch.bfloat16, 2e-2), (torch.float16, 2.5e-3)])
 def test_unet_forward_vs_reference_golden(golden_dir, name, backend, tol):
     fx = _load(golden_dir, name)
     arch, sd, m, x, img, mask, kw = _setup(fx, backend)
