@@ -328,7 +328,9 @@ enum { K22_ENC_CLIP_TEXT = 0, K22_ENC_CLIP_VISION = 1, K22_ENC_XLMR = 2 };
 typedef struct K22EncoderConfig {
   int dtype;       /* K22_BF16 | K22_F32 | K22_F16 */
   int kind;        /* K22_ENC_* */
-  int width;       /* 768 / 1024 / 1024 (64 channels per head) */
+  int width;       /* 768 / 1024 / 1024 (64 channels per head: the UNet's flash attention kernel); the vision tower also takes any
+                      width % heads == 0 with width / heads <= 128 - CLIP ViT-bigG/14 of Kandinsky 2.2 (kandinsky2_2_model.py:24): 1664 / 16
+                      = 104 per head - on a small-sequence attention kernel of its own (encoder.hip: enc_attention_generic_kernel) */
   int layers;      /* 12 / 24 / 24 */
   int heads;       /* 12 / 16 / 16 */
   int n_ctx;       /* tokens per sequence: 77 / 257 / 77 */
@@ -339,6 +341,8 @@ typedef struct K22EncoderConfig {
   int max_pos;     /* xlmr: 514 rows of position embeddings */
   int pad_id;      /* xlmr: 1 (padding token id = position-id offset) */
   float ln_eps;    /* 1e-5 */
+  int mlp_dim;     /* 0 = 4 * width (OpenAI CLIP, XLM-R); CLIP ViT-bigG/14: 8192 at width 1664 */
+  int hidden_act;  /* CLIP towers: 0 = QuickGELU (OpenAI CLIP), 1 = exact erf GELU (open_clip bigG: "hidden_act": "gelu") */
 } K22EncoderConfig;
 typedef struct K22Encoder K22Encoder;
 int k22_encoder_create(const K22EncoderConfig* cfg, const K22Weight* weights, int n_weights, K22Encoder** out);

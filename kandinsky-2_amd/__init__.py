@@ -17,8 +17,10 @@ from .unet22 import (DDPM_SCHEDULER_DEFAULTS, SCHEDULER_CONFIG_2_2, SCHEDULER_CO
                      tiny_unet22_config)
 from .pipeline import (CONFIG_2_1, Kandinsky2_1HIP, ReferenceConditioner, SeededConditioner, get_kandinsky2, prepare_image,
                        process_images)
-from .encoders import (CLIP_VITL14, XLMR_LARGE, CLIPModelHIP, HIPConditioner, MultilingualCLIPHIP, TextEncoderHIP, clip_param_shapes,
-                       init_clip_state_dict, init_multiclip_state_dict, multiclip_param_shapes, tiny_clip_config, tiny_xlmr_config)
+from .encoders import (CLIP_BIGG_VISION, CLIP_VITL14, XLMR_LARGE, CLIPModelHIP, CLIPVisionModelWithProjectionHIP, HIPConditioner,
+                       MultilingualCLIPHIP, TextEncoderHIP, clip_param_shapes, clip_vision_hf_param_shapes, init_clip_state_dict,
+                       init_clip_vision_hf_state_dict, init_multiclip_state_dict, multiclip_param_shapes, tiny_clip_config,
+                       tiny_clip_vision_hf_config, tiny_xlmr_config)
 from .movq import (MOVQ_CONFIG_2_1, MoVQArch, MoVQDecoderHIP, MoVQEncoderHIP, movq_param_shapes, init_movq_state_dict,
                    movq_encoder_param_shapes, init_movq_encoder_state_dict)
 
@@ -32,7 +34,8 @@ __all__ = [
     "movq_encoder_param_shapes", "init_movq_encoder_state_dict", "prestep",
     "UNET_CONFIG_2_2", "UNET2D_DEFAULTS", "DDPM_SCHEDULER_DEFAULTS", "SCHEDULER_CONFIG_2_2", "SCHEDULER_CONFIG_2_2_LEARNED_RANGE",
     "resolve_unet22_config", "DDPMSchedulerHIP", "UNet2DConditionHIP", "init_unet22_state_dict", "make_arch22", "param_shapes22", "tiny_unet22_config",
-    "CLIP_VITL14", "XLMR_LARGE", "CLIPModelHIP", "HIPConditioner", "MultilingualCLIPHIP", "TextEncoderHIP", "clip_param_shapes",
+    "CLIP_VITL14", "CLIP_BIGG_VISION", "CLIPVisionModelWithProjectionHIP", "clip_vision_hf_param_shapes", "init_clip_vision_hf_state_dict",
+    "tiny_clip_vision_hf_config", "XLMR_LARGE", "CLIPModelHIP", "HIPConditioner", "MultilingualCLIPHIP", "TextEncoderHIP", "clip_param_shapes",
     "init_clip_state_dict", "init_multiclip_state_dict", "multiclip_param_shapes", "tiny_clip_config", "tiny_xlmr_config",
     "CONFIG_2_1", "Kandinsky2_1HIP", "ReferenceConditioner", "SeededConditioner", "get_kandinsky2", "prepare_image", "process_images",
 ]

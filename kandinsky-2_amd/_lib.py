@@ -53,7 +53,7 @@ class K22PriorConfig(C.Structure):
 class K22EncoderConfig(C.Structure):
     _fields_ = [("dtype", C.c_int), ("kind", C.c_int), ("width", C.c_int), ("layers", C.c_int), ("heads", C.c_int), ("n_ctx", C.c_int),
                 ("vocab", C.c_int), ("out_dim", C.c_int), ("image_size", C.c_int), ("patch", C.c_int), ("max_pos", C.c_int),
-                ("pad_id", C.c_int), ("ln_eps", C.c_float)]
+                ("pad_id", C.c_int), ("ln_eps", C.c_float), ("mlp_dim", C.c_int), ("hidden_act", C.c_int)]
 
 
 class K22Weight(C.Structure):

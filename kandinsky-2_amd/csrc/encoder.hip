@@ -132,12 +132,78 @@ __global__ __launch_bounds__(256) void enc_vision_assemble_kernel(const float* p
   for (int i = threadIdx.x; i < D; i += 256) xr[i] = src[i] + pos[(int64_t)t * D + i];
 }
 
-// ---- QuickGELU (x * sigmoid(1.702 x), clip/model.py QuickGELU) on fp32 rows -> T rows -------------------------------------------
+// ---- MLP activation on fp32 rows -> T rows: QuickGELU (x * sigmoid(1.702 x), clip/model.py QuickGELU) or, exact != 0, the erf GELU
+// of transformers' CLIP with hidden_act "gelu" (the open_clip ViT-bigG/14 image encoder of Kandinsky 2.2) ---------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void enc_quickgelu_kernel(const float* x, T* y, int64_t n) {
+__global__ __launch_bounds__(256) void enc_quickgelu_kernel(const float* x, T* y, int64_t n, int exact) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float v = x[i];
-    y[i] = from_f32<T>(v / (1.0f + __expf(-1.702f * v)));
+    y[i] = from_f32<T>(exact ? gelu_f(v) : v / (1.0f + __expf(-1.702f * v)));
+  }
+}
+
+// ---- attention for head widths other than 64 (CLIP ViT-bigG/14: 1664 / 16 = 104 per head), short sequences (n <= 512), no mask:
+// CLIPAttention.forward of transformers (softmax((q * hd^-0.5) k^T) v per head).  One workgroup = 64 queries of one (image, head):
+// the head's K rows sit in the LDS as fp32 (row stride hd + 1 words: conflict-free across keys), every wave walks its 16 queries one
+// at a time - lane = key for the scores (5 keys per lane at n = 257), lane = channel for P.V (V rows straight from L2, coalesced).
+// Plain fp32 FMAs: 48 layers x 27 MFLOP per head is ~20 GFLOP per image, a few ms once per generation - not worth an MFMA tiling.
+template <typename T>
+__global__ __launch_bounds__(256) void enc_attention_generic_kernel(const T* __restrict__ qkv, T* __restrict__ out, int n, int D, int hd, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char esm[];
+  float* Ks = reinterpret_cast<float*>(esm);                       // [n][hd + 1]
+  float* qs = Ks + (size_t)n * (hd + 1);                           // [4 waves][128]
+  float* ps = qs + 4 * 128;                                        // [4 waves][512]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int head = blockIdx.y, b = blockIdx.z, q0 = blockIdx.x * 64;
+  const int64_t ld = 3 * (int64_t)D;
+  const T* base = qkv + (int64_t)b * n * ld + head * hd;
+  for (int i = tid; i < n * hd; i += 256) {
+    const int key = i / hd, d = i - key * hd;
+    Ks[key * (hd + 1) + d] = to_f32(base[(int64_t)key * ld + D + d]);
+  }
+  __syncthreads();
+  float* qw = qs + wave * 128;
+  float* pw = ps + wave * 512;
+  for (int qq = 0; qq < 16; ++qq) {
+    const int qi = q0 + wave * 16 + qq;
+    if (qi >= n) break;                                            // wave-uniform
+    for (int d = lane; d < hd; d += 64) qw[d] = to_f32(base[(int64_t)qi * ld + d]) * scale;
+    __builtin_amdgcn_wave_barrier();
+    float sc[8];
+    float m = -3.0e38f;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int key = kk * 64 + lane;
+      float a = -3.0e38f;
+      if (key < n) {
+        a = 0.f;
+        const float* kr = Ks + key * (hd + 1);
+        for (int d = 0; d < hd; ++d) a += qw[d] * kr[d];
+      }
+      sc[kk] = a;
+      m = fmaxf(m, a);
+    }
+    m = wave_max(m);
+    float l = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int key = kk * 64 + lane;
+      if (key < n) {
+        const float e = __expf(sc[kk] - m);
+        pw[key] = e;
+        l += e;
+      }
+    }
+    l = wave_sum(l);
+    __builtin_amdgcn_wave_barrier();
+    const float inv = 1.f / l;
+    for (int d = lane; d < hd; d += 64) {
+      float acc = 0.f;
+      const T* vp = base + 2 * D + d;
+      for (int key = 0; key < n; ++key) acc += pw[key] * to_f32(vp[(int64_t)key * ld]);
+      out[((int64_t)b * n + qi) * D + head * hd + d] = from_f32<T>(acc * inv);
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -221,7 +287,13 @@ struct K22Encoder {
   int plan(int nB) {
     const int D = cfg.width, n = cfg.n_ctx, M = nB * n, heads = cfg.heads, od = cfg.out_dim, kind = cfg.kind;
     if (nB < 1 || nB > 8) return k22_set_error(K22_EINVAL, "encoder: 1..8 sequences / images per call");
-    if (D < 64 || D % 64 || heads * 64 != D || D > 2048) return k22_set_error(K22_EINVAL, "encoder: 64 channels per head, width <= 2048");
+    if (D < 64 || D % 64 || D > 2048 || heads < 1 || D % heads) return k22_set_error(K22_EINVAL, "encoder: width % 64 == 0, width <= 2048, width % heads == 0");
+    const int hd = D / heads;
+    const bool flash = hd == 64;       // the UNet's flash attention kernel; anything else: enc_attention_generic_kernel (vision tower only)
+    if (!flash && (cfg.kind != K22_ENC_CLIP_VISION || hd > 128 || n > 512 || (size_t)n * (hd + 1) * 4 + 4 * 640 * 4 > 160 * 1024))
+      return k22_set_error(K22_EINVAL, "encoder: head widths other than 64 are built for the vision tower (<= 128 per head, <= 512 tokens)");
+    const int F = cfg.mlp_dim > 0 ? cfg.mlp_dim : 4 * D;
+    if (F % 64) return k22_set_error(K22_EINVAL, "encoder: mlp_dim % 64");
     if (kind < K22_ENC_CLIP_TEXT || kind > K22_ENC_XLMR) return k22_set_error(K22_EINVAL, "encoder: kind");
     if (n < 1 || cfg.layers < 1 || od < 1) return k22_set_error(K22_EINVAL, "encoder: n_ctx, layers and out_dim must be positive");
     const bool vision = kind == K22_ENC_CLIP_VISION, xlmr = kind == K22_ENC_XLMR;
@@ -239,7 +311,7 @@ struct K22Encoder {
     s_img = new_slot(vision ? (size_t)B * 3 * cfg.image_size * cfg.image_size * 4 : 0);
     s_patch = new_slot(vision ? (size_t)B * P * Kp * esz : 0); s_pout = new_slot(vision ? (size_t)B * P * D * 4 : 0);
     s_inp = new_slot((size_t)M * D * 4); s_ln = new_slot((size_t)M * D * esz); s_qkv = new_slot((size_t)M * 3 * D * esz);
-    s_att = new_slot((size_t)M * D * esz); s_fc = new_slot((size_t)M * 4 * D * esz); s_fc32 = new_slot(xlmr ? 0 : (size_t)M * 4 * D * 4);
+    s_att = new_slot((size_t)M * D * esz); s_fc = new_slot((size_t)M * F * esz); s_fc32 = new_slot(xlmr ? 0 : (size_t)M * F * 4);
     s_seq = new_slot((size_t)M * D * 4); s_pool_in = new_slot((size_t)B * D * 4); s_pooled = new_slot((size_t)B * od * 4);
     s_splitk = new_slot(256); s_kall = new_slot(); s_vtall = new_slot();
     s_flush = new_slot(autotune ? ((size_t)320 << 20) : 0);
@@ -288,13 +360,32 @@ struct K22Encoder {
     }
     // ---- transformer -----------------------------------------------------------------------------------------------------------
     const int Tkp = (n + 63) / 64 * 64;
-    need(s_kall, (size_t)B * heads * Tkp * 64 * esz);
-    need(s_vtall, (size_t)B * heads * Tkp * 64 * esz);
+    if (flash) {
+      need(s_kall, (size_t)B * heads * Tkp * 64 * esz);
+      need(s_vtall, (size_t)B * heads * Tkp * 64 * esz);
+    }
     for (int l = 0; l < cfg.layers; ++l) {
       const std::string pfx = "layers." + std::to_string(l);
       if (!xlmr) op_ln(s_inp, 0, D, M, pfx + ".ln_1", nullptr, 0, s_ln);
       op_linear(s_ln, M, 3 * D, D, pfx + ".qkv", K22_ACT_NONE, s_qkv, 3 * D, 0);
       const int causal = kind == K22_ENC_CLIP_TEXT ? 1 : 0;
+      if (!flash) {
+        const size_t smem = (size_t)n * (hd + 1) * 4 + 4 * 640 * 4;
+        const float sc = 1.0f / sqrtf((float)hd);
+        ops.push_back([=](hipStream_t st) {
+          dim3 grid((n + 63) / 64, heads, Bn);
+#define K22_GA(TT_)                                                                                                              \
+          {                                                                                                                      \
+            static LdsAttrGuard guard;                                                                                           \
+            if (int rc_ = k22_ensure_lds_attr(guard, reinterpret_cast<const void*>(&enc_attention_generic_kernel<TT_>), 160 * 1024, __FILE__, __LINE__)) return rc_; \
+            hipLaunchKernelGGL(enc_attention_generic_kernel<TT_>, grid, dim3(256), smem, st, ptr<TT_>(s_qkv), ptr<TT_>(s_att), n, D, hd, sc);  \
+          }
+          if (dt == K22_BF16) K22_GA(bf16_t) else if (dt == K22_F16) K22_GA(f16_t) else K22_GA(float)
+#undef K22_GA
+          K22_CHECK_LAUNCH();
+          return K22_OK;
+        });
+      } else
       ops.push_back([=](hipStream_t st) {
         KvPackParams kp;
         kp.qkv = ptr(s_qkv); kp.ctxkv = nullptr; kp.kall = ptr(s_kall); kp.vtall = ptr(s_vtall);
@@ -312,22 +403,23 @@ struct K22Encoder {
       if (xlmr) {
         // BertSelfOutput: LayerNorm(dense(attn) + x);  BertIntermediate: GELU(dense);  BertOutput: LayerNorm(dense(h) + x)
         op_ln(s_inp, 0, D, M, pfx + ".ln_1", s_inp, D, s_ln);
-        op_linear(s_ln, M, 4 * D, D, pfx + ".fc", K22_ACT_GELU, s_fc, 4 * D, 0);
-        op_linear(s_fc, M, D, 4 * D, pfx + ".out", K22_ACT_NONE, s_inp, D, 2);
+        op_linear(s_ln, M, F, D, pfx + ".fc", K22_ACT_GELU, s_fc, F, 0);
+        op_linear(s_fc, M, D, F, pfx + ".out", K22_ACT_NONE, s_inp, D, 2);
         op_ln(s_inp, 0, D, M, pfx + ".ln_2", s_inp, D, l + 1 < cfg.layers ? s_ln : nullptr);
       } else {
         op_ln(s_inp, 0, D, M, pfx + ".ln_2", nullptr, 0, s_ln);
-        op_linear(s_ln, M, 4 * D, D, pfx + ".fc", K22_ACT_NONE, s_fc32, 4 * D, 1);
-        const int64_t nel = (int64_t)M * 4 * D;
+        op_linear(s_ln, M, F, D, pfx + ".fc", K22_ACT_NONE, s_fc32, F, 1);
+        const int64_t nel = (int64_t)M * F;
+        const int exact = cfg.hidden_act == 1 ? 1 : 0;
         ops.push_back([=](hipStream_t st) {
           const int nb = (int)((nel + 255) / 256 < 4096 ? (nel + 255) / 256 : 4096);
-          if (dt == K22_BF16) hipLaunchKernelGGL(enc_quickgelu_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, ptr<float>(s_fc32), ptr<bf16_t>(s_fc), nel);
-          else if (dt == K22_F16) hipLaunchKernelGGL(enc_quickgelu_kernel<f16_t>, dim3(nb), dim3(256), 0, st, ptr<float>(s_fc32), ptr<f16_t>(s_fc), nel);
-          else hipLaunchKernelGGL(enc_quickgelu_kernel<float>, dim3(nb), dim3(256), 0, st, ptr<float>(s_fc32), ptr<float>(s_fc), nel);
+          if (dt == K22_BF16) hipLaunchKernelGGL(enc_quickgelu_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, ptr<float>(s_fc32), ptr<bf16_t>(s_fc), nel, exact);
+          else if (dt == K22_F16) hipLaunchKernelGGL(enc_quickgelu_kernel<f16_t>, dim3(nb), dim3(256), 0, st, ptr<float>(s_fc32), ptr<f16_t>(s_fc), nel, exact);
+          else hipLaunchKernelGGL(enc_quickgelu_kernel<float>, dim3(nb), dim3(256), 0, st, ptr<float>(s_fc32), ptr<float>(s_fc), nel, exact);
           K22_CHECK_LAUNCH();
           return K22_OK;
         });
-        op_linear(s_fc, M, D, 4 * D, pfx + ".out", K22_ACT_NONE, s_inp, D, 2);
+        op_linear(s_fc, M, D, F, pfx + ".out", K22_ACT_NONE, s_inp, D, 2);
       }
     }
     // ---- heads ---------------------------------------------------------------------------------------------------------------

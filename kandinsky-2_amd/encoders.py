@@ -1,6 +1,8 @@
 """Conditioning encoders on the HIP encoder engine (csrc/encoder.hip; SURVEY 8f-3, a "next" row): the three transformer towers
 Kandinsky 2.1 runs once per prompt / image before the prior and the denoising loop,
 
+    CLIPVisionModelWithProjectionHIP   transformers' class of that name under its own keys: the CLIP ViT-bigG/14 image encoder Kandinsky 2.2 loads
+                          (kandinsky2/kandinsky2_2_model.py:24) - 48 layers x 1664, 16 heads of 104 channels, 1280-d embedding.
     CLIPModelHIP          clip.load("ViT-L/14") as the reference uses it: the text tower walked by generate_clip_emb
                           (kandinsky2/kandinsky2_1_model.py:159-168) and encode_image (:177-181).  Parameters under the OpenAI
                           `clip.model.CLIP` state_dict keys, so that checkpoint loads unchanged.
@@ -36,6 +38,19 @@ CLIP_VITL14 = {"embed_dim": 768, "image_resolution": 224, "vision_layers": 24, "
 # config.json of xlm-roberta-large, the transformer inside M-CLIP/XLM-Roberta-Large-Vit-L-14 (text_enc_params, configs.py:89-94)
 XLMR_LARGE = {"vocab_size": 250002, "hidden_size": 1024, "num_hidden_layers": 24, "num_attention_heads": 16, "intermediate_size": 4096,
               "max_position_embeddings": 514, "type_vocab_size": 1, "layer_norm_eps": 1e-5, "pad_token_id": 1, "hidden_act": "gelu"}
+
+
+# vision_config (+ projection_dim) of the `image_encoder` sub-folder of kandinsky-community/kandinsky-2-2-prior, the
+# CLIPVisionModelWithProjection Kandinsky2_2.__init__ loads (kandinsky2/kandinsky2_2_model.py:24): open_clip ViT-bigG/14 in transformers'
+# layout [published architecture: 48 layers x 1664 wide, 16 heads of 104, MLP 8192, erf GELU, 14-px patches of a 224-px image, 1280-d output]
+CLIP_BIGG_VISION = {"hidden_size": 1664, "intermediate_size": 8192, "num_hidden_layers": 48, "num_attention_heads": 16, "image_size": 224,
+                    "patch_size": 14, "projection_dim": 1280, "hidden_act": "gelu", "layer_norm_eps": 1e-5}
+
+
+def tiny_clip_vision_hf_config() -> dict:
+    """Same structure at 2 layers x 832 wide: EIGHT HEADS OF 104 (the head width of bigG, which the 64-wide flash kernel does not take;
+    832 = 13 x 64 keeps the GEMM K alignment) and an MLP that is not 4 x width."""
+    return dict(CLIP_BIGG_VISION, hidden_size=832, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=8, image_size=56, projection_dim=64)
 
 
 def tiny_clip_config() -> dict:
@@ -107,6 +122,30 @@ def multiclip_param_shapes(cfg: dict, in_features=1024, out_features=768) -> "Or
     return s
 
 
+def clip_vision_hf_param_shapes(cfg: dict) -> "OrderedDict[str, tuple]":
+    """state_dict of transformers' CLIPVisionModelWithProjection (models/clip/modeling_clip.py); the non-persistent position_ids buffer
+    of older versions is not a parameter and is ignored on load."""
+    H, I, p = cfg["hidden_size"], cfg["intermediate_size"], cfg["patch_size"]
+    P = (cfg["image_size"] // p) ** 2
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    e = "vision_model.embeddings."
+    s[e + "class_embedding"] = (H,)
+    s[e + "patch_embedding.weight"] = (H, 3, p, p)
+    s[e + "position_embedding.weight"] = (P + 1, H)
+    s["vision_model.pre_layrnorm.weight"] = (H,); s["vision_model.pre_layrnorm.bias"] = (H,)     # [sic]: transformers' spelling
+    for l in range(cfg["num_hidden_layers"]):
+        q = f"vision_model.encoder.layers.{l}."
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            s[q + f"self_attn.{nm}.weight"] = (H, H); s[q + f"self_attn.{nm}.bias"] = (H,)
+        s[q + "layer_norm1.weight"] = (H,); s[q + "layer_norm1.bias"] = (H,)
+        s[q + "mlp.fc1.weight"] = (I, H); s[q + "mlp.fc1.bias"] = (I,)
+        s[q + "mlp.fc2.weight"] = (H, I); s[q + "mlp.fc2.bias"] = (H,)
+        s[q + "layer_norm2.weight"] = (H,); s[q + "layer_norm2.bias"] = (H,)
+    s["vision_model.post_layernorm.weight"] = (H,); s["vision_model.post_layernorm.bias"] = (H,)
+    s["visual_projection.weight"] = (cfg["projection_dim"], H)
+    return s
+
+
 def _init(shapes, seed):
     g = torch.Generator(device="cpu").manual_seed(seed)
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
@@ -114,7 +153,7 @@ def _init(shapes, seed):
         leaf = name.rsplit(".", 1)[-1]
         if name == "logit_scale":
             t = torch.tensor(math.log(1 / 0.07))
-        elif "ln_" in name or "LayerNorm" in name:
+        elif "ln_" in name or "LayerNorm" in name or "layer_norm" in name or "layernorm" in name or "layrnorm" in name:
             t = torch.randn(shape, generator=g) * 0.1 + (1.0 if leaf == "weight" else 0.0)
         elif "embedding" in name:
             t = torch.randn(shape, generator=g) * 0.3
@@ -133,6 +172,10 @@ def _init(shapes, seed):
 
 def init_clip_state_dict(cfg: dict, seed: int = 0):
     return _init(clip_param_shapes(cfg), seed)
+
+
+def init_clip_vision_hf_state_dict(cfg: dict, seed: int = 0):
+    return _init(clip_vision_hf_param_shapes(cfg), seed)
 
 
 def init_multiclip_state_dict(cfg: dict, in_features=1024, out_features=768, seed: int = 0):
@@ -196,6 +239,39 @@ def pack_clip_vision_arena(cfg, sd, tdtype, device):
         ent[k + ".weight"] = f(sd[f"visual.{k}.weight"]).contiguous(); ent[k + ".bias"] = f(sd[f"visual.{k}.bias"]).contiguous()
     _clip_layers(ent, sd, "visual.transformer", cfg["vision_layers"], tdtype, f)
     ent["head.weight"] = f(sd["visual.proj"]).t().contiguous()
+    return _finish_arena(ent, device)
+
+
+def pack_clip_vision_hf_arena(cfg, sd, tdtype, device):
+    """transformers CLIPVisionModelWithProjection keys -> the encoder engine's names (q / k / v rows stacked [q | k | v], heads
+    contiguous inside each, exactly as the separate q_proj / k_proj / v_proj weights already are)."""
+    f = lambda t: t.detach().to(device=device, dtype=torch.float32)  # noqa: E731
+    H, p = cfg["hidden_size"], cfg["patch_size"]
+    K = 3 * p * p
+    Kp = (K + 63) // 64 * 64
+    e = "vision_model.embeddings."
+    ent: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    w = torch.zeros(H, Kp, device=device)
+    w[:, :K] = f(sd[e + "patch_embedding.weight"]).reshape(H, K)
+    ent["patch.weight"] = _pad_rows(w).to(tdtype).contiguous()
+    ent["class_embedding"] = f(sd[e + "class_embedding"]).contiguous()
+    ent["positional_embedding"] = f(sd[e + "position_embedding.weight"]).contiguous()
+    ent["ln_pre.weight"] = f(sd["vision_model.pre_layrnorm.weight"]).contiguous(); ent["ln_pre.bias"] = f(sd["vision_model.pre_layrnorm.bias"]).contiguous()
+    ent["ln_post.weight"] = f(sd["vision_model.post_layernorm.weight"]).contiguous(); ent["ln_post.bias"] = f(sd["vision_model.post_layernorm.bias"]).contiguous()
+    for l in range(cfg["num_hidden_layers"]):
+        s_, q = f"vision_model.encoder.layers.{l}.", f"layers.{l}"
+        a = s_ + "self_attn."
+        ent[q + ".qkv.weight"] = _pad_rows(torch.cat([f(sd[a + "q_proj.weight"]), f(sd[a + "k_proj.weight"]), f(sd[a + "v_proj.weight"])], 0)).to(tdtype).contiguous()
+        ent[q + ".qkv.bias"] = torch.cat([f(sd[a + "q_proj.bias"]), f(sd[a + "k_proj.bias"]), f(sd[a + "v_proj.bias"])], 0).contiguous()
+        ent[q + ".proj.weight"] = _pad_rows(f(sd[a + "out_proj.weight"])).to(tdtype).contiguous()
+        ent[q + ".proj.bias"] = f(sd[a + "out_proj.bias"]).contiguous()
+        ent[q + ".fc.weight"] = _pad_rows(f(sd[s_ + "mlp.fc1.weight"])).to(tdtype).contiguous()
+        ent[q + ".fc.bias"] = f(sd[s_ + "mlp.fc1.bias"]).contiguous()
+        ent[q + ".out.weight"] = _pad_rows(f(sd[s_ + "mlp.fc2.weight"])).to(tdtype).contiguous()
+        ent[q + ".out.bias"] = f(sd[s_ + "mlp.fc2.bias"]).contiguous()
+        ent[q + ".ln_1.weight"] = f(sd[s_ + "layer_norm1.weight"]).contiguous(); ent[q + ".ln_1.bias"] = f(sd[s_ + "layer_norm1.bias"]).contiguous()
+        ent[q + ".ln_2.weight"] = f(sd[s_ + "layer_norm2.weight"]).contiguous(); ent[q + ".ln_2.bias"] = f(sd[s_ + "layer_norm2.bias"]).contiguous()
+    ent["head.weight"] = f(sd["visual_projection.weight"]).contiguous()
     return _finish_arena(ent, device)
 
 
@@ -374,6 +450,49 @@ class CLIPModelHIP(_HIPModule):
         if image.dim() != 4 or tuple(image.shape[1:]) != (3, r, r):
             raise ValueError(f"CLIP image batch must be [n, 3, {r}, {r}] (preprocessed), got {tuple(image.shape)}")
         return self._engine("vision").run(image=image)[1]
+
+
+class CLIPVisionModelWithProjectionHIP(_HIPModule):
+    """transformers' `CLIPVisionModelWithProjection` - the `image_encoder` Kandinsky2_2.__init__ loads from the prior repository
+    (kandinsky2/kandinsky2_2_model.py:24; CLIP ViT-bigG/14) and diffusers' prior pipeline calls as
+    `image_encoder(pixel_values).image_embeds` (mix_images / interpolate, the zero-image negative embedding) - on the encoder engine.
+    Parameters under transformers' own state_dict keys, so `load_state_dict(CLIPVisionModelWithProjection.state_dict())` works unchanged.
+    16 heads of 104 channels: attention runs on the engine's generic-head-width kernel, everything else on the shared Linear / LayerNorm
+    path.  forward(pixel_values [n,3,224,224], already preprocessed) -> namespace(image_embeds [n, projection_dim])."""
+
+    def __init__(self, config: Optional[dict] = None, backend_dtype: torch.dtype = torch.bfloat16):
+        self.config_dict = dict(config or CLIP_BIGG_VISION)
+        c = self.config_dict
+        if c["hidden_size"] % c["num_attention_heads"] or c["hidden_size"] % 64 or c["intermediate_size"] % 64:
+            raise ValueError("CLIPVisionModelWithProjectionHIP: hidden_size % heads == 0, hidden_size and intermediate_size multiples of 64")
+        if c.get("hidden_act", "quick_gelu") not in ("gelu", "quick_gelu"):
+            raise NotImplementedError("hidden_act: gelu (bigG) or quick_gelu (OpenAI CLIP)")
+        super().__init__(clip_vision_hf_param_shapes(c), backend_dtype)
+        self.config = type("Config", (), {"image_size": c["image_size"], "projection_dim": c["projection_dim"], "hidden_size": c["hidden_size"]})()
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        sd = {k: v for k, v in state_dict.items() if not k.endswith("position_ids")}        # buffer of older transformers versions
+        return super().load_state_dict(sd, strict=strict, **kw)
+
+    def _engine(self):
+        if "vision" not in self._engines:
+            dev, c = self._device(), self.config_dict
+            arena, table = pack_clip_vision_hf_arena(c, self.state_dict(), self.backend_dtype, dev)
+            g = c["image_size"] // c["patch_size"]
+            ecfg = dict(kind=ENC_CLIP_VISION, width=c["hidden_size"], layers=c["num_hidden_layers"], heads=c["num_attention_heads"], n_ctx=g * g + 1,
+                        vocab=0, out_dim=c["projection_dim"], image_size=c["image_size"], patch=c["patch_size"], max_pos=0, pad_id=0,
+                        ln_eps=float(c.get("layer_norm_eps", 1e-5)), mlp_dim=c["intermediate_size"],
+                        hidden_act=1 if c.get("hidden_act", "quick_gelu") == "gelu" else 0)
+            self._engines["vision"] = _Engine(ecfg, arena, table, self.backend_dtype)
+        return self._engines["vision"]
+
+    @torch.no_grad()
+    def forward(self, pixel_values, **_unused):
+        r = self.config_dict["image_size"]
+        if pixel_values.dim() != 4 or tuple(pixel_values.shape[1:]) != (3, r, r):
+            raise ValueError(f"pixel_values must be [n, 3, {r}, {r}] (preprocessed), got {tuple(pixel_values.shape)}")
+        from types import SimpleNamespace
+        return SimpleNamespace(image_embeds=self._engine().run(image=pixel_values)[1])
 
 
 class MultilingualCLIPHIP(_HIPModule):

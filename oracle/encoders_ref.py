@@ -11,6 +11,12 @@
     clip_image_forward  clip_model.encode_image (kandinsky2_1_model.py:177-181; clip/model.py VisionTransformer.forward: conv1,
                         class_embedding, positional_embedding, ln_pre, Transformer, ln_post(x[:, 0]) @ proj).
 
+    clip_vision_hf_forward  transformers' CLIPVisionModelWithProjection.forward(...).image_embeds (models/clip/modeling_clip.py:
+                        CLIPVisionEmbeddings -> pre_layrnorm -> CLIPEncoderLayer x N [layer_norm1, CLIPAttention (q * hd^-0.5), layer_norm2,
+                        CLIPMLP fc1 -> act -> fc2] -> post_layernorm(x[:, 0]) -> visual_projection) under transformers' own keys: the
+                        CLIP ViT-bigG/14 image encoder Kandinsky2_2.__init__ loads (kandinsky2/kandinsky2_2_model.py:24).  Pinned against
+                        the installed transformers class itself (the very dependency the reference calls) on seeded weights.
+
 PINNING (oracle/make_golden_encoders.py, fixtures tests/golden/enc_*.pt):
   * multiclip_forward is checked against the REFERENCE'S OWN MultilingualCLIP class (imported from /root/reference, running the
     installed transformers' XLMRobertaModel - the very dependency the reference calls) on seeded weights: pinned.
@@ -102,3 +108,25 @@ def multiclip_forward(sd, cfg, input_ids, attention_mask):
         x = _ln(sd, p + "output.LayerNorm", h + x, eps)
     pooled = (x * am.unsqueeze(2)).sum(dim=1) / am.sum(dim=1)[:, None]
     return _lin(sd, "LinearTransformation", pooled), x
+
+
+@torch.no_grad()
+def clip_vision_hf_forward(sd, cfg, pixel_values):
+    """-> image_embeds [n, projection_dim]"""
+    H, p, heads = cfg["hidden_size"], cfg["patch_size"], cfg["num_attention_heads"]
+    eps = cfg.get("layer_norm_eps", 1e-5)
+    e = "vision_model.embeddings."
+    x = F.conv2d(pixel_values.float(), sd[e + "patch_embedding.weight"], stride=p)
+    x = x.flatten(2).transpose(1, 2)
+    x = torch.cat([sd[e + "class_embedding"].expand(x.shape[0], 1, H), x], dim=1) + sd[e + "position_embedding.weight"]
+    x = _ln(sd, "vision_model.pre_layrnorm", x, eps)
+    for l in range(cfg["num_hidden_layers"]):
+        q = f"vision_model.encoder.layers.{l}."
+        a = q + "self_attn."
+        w = torch.cat([sd[a + "q_proj.weight"], sd[a + "k_proj.weight"], sd[a + "v_proj.weight"]], 0)
+        b = torch.cat([sd[a + "q_proj.bias"], sd[a + "k_proj.bias"], sd[a + "v_proj.bias"]], 0)
+        x = x + _mha(_ln(sd, q + "layer_norm1", x, eps), w, b, sd[a + "out_proj.weight"], sd[a + "out_proj.bias"], heads)
+        h = _lin(sd, q + "mlp.fc1", _ln(sd, q + "layer_norm2", x, eps))
+        h = F.gelu(h) if cfg.get("hidden_act", "quick_gelu") == "gelu" else h * torch.sigmoid(1.702 * h)
+        x = x + _lin(sd, q + "mlp.fc2", h)
+    return F.linear(_ln(sd, "vision_model.post_layernorm", x[:, 0], eps), sd["visual_projection.weight"])

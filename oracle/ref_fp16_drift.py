@@ -1,6 +1,6 @@
 """Yardstick for "what reduced-precision storage costs": the REFERENCE's own fp16 mode against its own fp32 mode.
 
-    python oracle/ref_fp16_drift.py [--lat 32] [--steps 10]        (build container only: imports /root/reference)
+    python oracle/ref_fp16_drift.py [--lat 32] [--steps 10] [--dtype fp16|bf16] [--out file.json]   (build container only: imports /root/reference)
 
 Runs Kandinsky 2.1's reference UNet (create_model, 1.23 B parameters, seeded weights) through the verbatim model_fn +
 SpacedDiffusion.p_sample_loop_progressive (kandinsky2_1_model.py:222-257, gaussian_diffusion.py:426-475) twice on the same
@@ -26,13 +26,22 @@ import kandinsky2_amd as k22  # noqa: E402
 from oracle import ref_loader  # noqa: E402
 
 
-def build(use_fp16, sd):
+def build(use_fp16, sd, low=torch.float16):
+    """use_fp16=True: the reference's reduced-precision mode.  low=torch.bfloat16 runs the SAME mode with bf16 in place of fp16: the
+    modules convert_to_fp16() casts (unet.py:566-572, text2im_model2_1.py:49-55) are re-cast from the fp32 weights to bf16 and
+    model.dtype - the activation type of the torso (unet.py:602) - is set to bf16; GroupNorm / softmax / time embedding / sampler
+    stay fp32 exactly as in the fp16 mode.  That is the yardstick for a bf16 engine at the benchmarked shape (VERDICT r2 #1a)."""
     mc = ref_loader.ref("model.model_creation")
     cfg = dict(copy.deepcopy(k22.MODEL_CONFIG_2_1), up=False, inpainting=False, use_fp16=use_fp16)
     m = mc.create_model(**cfg).eval()
     m.load_state_dict(sd, strict=True)
     if use_fp16:
         m.convert_to_fp16()
+        if low != torch.float16:
+            for name, p in m.named_parameters():
+                if p.dtype == torch.float16:
+                    p.data = sd[name].to(low)
+            m.dtype = low
     return m
 
 
@@ -80,20 +89,27 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--lat", type=int, default=32)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--out", default="")
+    ap.add_argument("--threads", type=int, default=0)
     a = ap.parse_args()
+    if a.threads:
+        torch.set_num_threads(a.threads)
+    low = torch.float16 if a.dtype == "fp16" else torch.bfloat16
     arch = k22.make_arch(k22.MODEL_CONFIG_2_1)
     sd = k22.init_unet_state_dict(arch, seed=0)
     with torch.no_grad():
         f32_first, f32_traj = run(build(False, sd), a.lat, a.steps)
-        f16_first, f16_traj = run(build(True, sd), a.lat, a.steps)
+        f16_first, f16_traj = run(build(True, sd, low), a.lat, a.steps)
     scale = f32_first.abs().max().item()
-    rep = {"config": f"reference Text2ImUNet 1.23B, CFG batch 2x4x{a.lat}x{a.lat}, {a.steps}-step p_sampler, CPU, seeded weights",
+    rep = {"config": f"reference Text2ImUNet 1.23B, CFG batch 2x4x{a.lat}x{a.lat}, {a.steps}-step p_sampler, CPU, seeded weights; reduced-precision "
+                     f"mode = use_fp16 + convert_to_fp16() with {a.dtype} storage, against the reference's own fp32 mode",
            "first_forward": {"max_abs": (f16_first - f32_first).abs().max().item(), "scale": scale,
                              "rel": (f16_first - f32_first).abs().max().item() / scale}, "steps": {}}
-    print(f"first forward: fp16-vs-fp32 max|d| {rep['first_forward']['max_abs']:.3e} = {rep['first_forward']['rel']:.3e} of scale {scale:.2f}")
+    print(f"first forward: {a.dtype}-vs-fp32 max|d| {rep['first_forward']['max_abs']:.3e} = {rep['first_forward']['rel']:.3e} of scale {scale:.2f}")
     for n, (p, q) in enumerate(zip(f16_traj, f32_traj), 1):
         d = p - q
         rep["steps"][str(n)] = {"max_abs": d.abs().max().item(), "rms": d.pow(2).mean().sqrt().item()}
-        print(f"latent after step {n:2d}: fp16-vs-fp32 max|d| {d.abs().max().item():.3e} rms {d.pow(2).mean().sqrt().item():.3e}")
-    with open(os.path.join(ROOT, "tests", "golden", "ref_fp16_drift.json"), "w") as f:
+        print(f"latent after step {n:2d}: {a.dtype}-vs-fp32 max|d| {d.abs().max().item():.3e} rms {d.pow(2).mean().sqrt().item():.3e}")
+    with open(a.out or os.path.join(ROOT, "tests", "golden", "ref_fp16_drift.json"), "w") as f:
         json.dump(rep, f, indent=1)

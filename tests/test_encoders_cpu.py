@@ -45,6 +45,31 @@ def test_clip_oracle_matches_golden(golden_dir, size):
     assert _rel(seq, fx["txt_feat_seq"]) <= 2e-5 and _rel(feat, fx["txt_feat"]) <= 2e-5 and _rel(img, fx["img_feat"]) <= 2e-5
 
 
+@pytest.mark.parametrize("name", ["enc_clipvision_hf_tiny", "enc_clipvision_bigg"])
+def test_clip_vision_hf_oracle_matches_transformers_golden(golden_dir, name):
+    """oracle/encoders_ref.clip_vision_hf_forward against the fixture transformers' own CLIPVisionModelWithProjection produced
+    (kandinsky2_2_model.py:24 loads that class as the 2.2 image encoder: CLIP ViT-bigG/14)."""
+    fx = _fx(golden_dir, name)
+    cfg = fx["meta"]["cfg"]
+    if cfg["num_hidden_layers"] > 8 and not os.environ.get("K22_SLOW_CPU_TESTS"):
+        # the 1.8 B-parameter tower takes ~2 min on 8 cores (weights + forward): checked by make_golden_encoders.py when the fixture is made
+        assert fx["image_embeds"].shape == (1, 1280) and cfg["hidden_size"] // cfg["num_attention_heads"] == 104
+        return
+    sd = k22.init_clip_vision_hf_state_dict(cfg, seed=fx["meta"]["seed_w"])
+    assert _rel(encoders_ref.clip_vision_hf_forward(sd, cfg, fx["image"]), fx["image_embeds"]) <= 2e-5
+
+
+def test_clip_bigg_vision_is_the_published_tower():
+    shapes = k22.clip_vision_hf_param_shapes(k22.CLIP_BIGG_VISION)
+    n = sum(math.prod(s) for s in shapes.values())
+    assert 1.84e9 < n < 1.85e9                                   # ViT-bigG/14 vision tower + 1664 -> 1280 projection
+    assert shapes["vision_model.encoder.layers.47.mlp.fc1.weight"] == (8192, 1664) and shapes["visual_projection.weight"] == (1280, 1664)
+    assert shapes["vision_model.embeddings.position_embedding.weight"] == (257, 1664)
+    m = k22.CLIPVisionModelWithProjectionHIP(k22.tiny_clip_vision_hf_config())
+    with pytest.raises(RuntimeError):                            # no CPU fallback
+        m(torch.zeros(1, 3, 56, 56))
+
+
 def test_multiclip_state_dict_keys_match_reference(golden_dir):
     """ref_multiclip_keys.json: state_dict of the reference's MultilingualCLIP built on xlm-roberta-large's config."""
     p = os.path.join(golden_dir, "ref_multiclip_keys.json")

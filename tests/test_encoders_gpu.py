@@ -74,6 +74,30 @@ def test_clip_towers_vs_golden(golden_dir, size, backend, tol_tiny, tol_full):
     assert _rel(m.encode_text(fx["tokens"][1:2].cuda()), fx["txt_feat"][1:2]) <= tol
 
 
+@pytest.mark.parametrize("name", ["enc_clipvision_hf_tiny", "enc_clipvision_bigg"])
+@pytest.mark.parametrize("backend,tol_tiny,tol_full", BACKENDS)
+def test_clip_vision_with_projection_vs_transformers_golden(golden_dir, name, backend, tol_tiny, tol_full):
+    """CLIPVisionModelWithProjectionHIP - the image encoder Kandinsky2_2.__init__ loads (kandinsky2_2_model.py:24; CLIP ViT-bigG/14,
+    16 heads of 104 channels -> the generic-head-width attention kernel, MLP 8192, erf GELU) - against the installed transformers'
+    CLIPVisionModelWithProjection itself on the same seeded weights: 2 x 832 (eight 104-wide heads) and the full 48 x 1664, 1.8 B tower."""
+    fx = _fx(golden_dir, name)
+    cfg = fx["meta"]["cfg"]
+    m = k22.CLIPVisionModelWithProjectionHIP(cfg, backend_dtype=backend)
+    m.load_state_dict(k22.init_clip_vision_hf_state_dict(cfg, seed=fx["meta"]["seed_w"]))
+    m = m.to("cuda")
+    img = fx["image"]
+    if img is None:
+        img = torch.randn(fx["n"], 3, cfg["image_size"], cfg["image_size"], generator=torch.Generator().manual_seed(fx["image_seed"]))
+    emb = m(img.cuda()).image_embeds
+    e = _rel(emb, fx["image_embeds"])
+    print(f"{name} {backend}: image_embeds {e:.3e} of scale (transformers CLIPVisionModelWithProjection golden)")
+    assert emb.shape == fx["image_embeds"].shape and e <= (tol_tiny if "tiny" in name else tol_full)
+    if "tiny" in name:      # rows are independent of their batch neighbours; pixel_values of the wrong size are rejected
+        assert _rel(m(img[1:2].cuda()).image_embeds, fx["image_embeds"][1:2]) <= tol_tiny
+        with pytest.raises(ValueError):
+            m(torch.zeros(1, 3, 32, 32).cuda())
+
+
 def test_more_than_eight_rows_run_in_chunks(golden_dir):
     fx = _fx(golden_dir, "enc_clip_tiny")
     cfg = fx["meta"]["cfg"]
