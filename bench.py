@@ -53,6 +53,9 @@ def main(argv=None):
                     help="engine storage / MFMA operand type: bf16 (BASELINE's), fp16 (the reference's own use_fp16 mode), fp32 (parity path)")
     ap.add_argument("--sched-steps", type=int, default=50, help="decoder_steps of the schedule being sampled")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-loop-graph", action="store_true",
+                    help="time the per-step path (one UNet graph + sampler launch per step from the host) instead of the whole denoising loop "
+                         "replayed as ONE hipGraph (k22_unet_sample_loop); the loop graph needs --steps to be a multiple of --sched-steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity_paths object (fp16 / fp32 engines + final-latent distances)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end images/sec pass (prior + denoise + MoVQ + uint8)")
@@ -194,23 +197,44 @@ def run(a):
                                       4.0, 1, -clamp, clamp, lo, gamma, scratch.data_ptr(), x_next.data_ptr(), None, B, HW, stream))
         return x_next, x
 
+    # the whole loop as one graph: K timed steps = K / T replays of the T-step loop (same kernels, same bits as the per-step path)
+    use_loop = not (a.no_loop_graph or a.no_graph or v22) and a.steps % T == 0
+    if use_loop:
+        n_loops, warm_loops = a.steps // T, max(1, -(-a.warmup // T))
+        order = list(range(T - 1, -1, -1))
+        ts_exec = ts_rows[torch.as_tensor(order, device=dev)].contiguous()
+        g2 = torch.Generator(device="cpu").manual_seed(4242 + rank)
+        noise_loops = torch.randn((n_loops + warm_loops) * T, B, 4, lat, lat, generator=g2).to(dev)
+
+        def loop(j, x):
+            return m.sample_loop(x, ts_exec, noise_loops[j * T:(j + 1) * T], table, order, 4.0, (-2.0, 2.0), (lo, gamma),
+                                 init_img=init_img, img_mask=img_mask, **kw)
+
     # engine initialisation, outside warm-up and timing whatever W is: the first forward of a plan measures its conv / GEMM
     # tile table on the device and captures the hipGraph (the equivalent of building the model)
     m(torch.cat([x[: a.bs], x[: a.bs]], 0), ts_rows[T - 1], **kw)
     torch.cuda.synchronize()
     measured_here = _lib.lib().k22_tile_table_measured()
     k = 0
-    for _ in range(a.warmup):
-        x, x_next = step(k, x, x_next)
-        k += 1
+    if use_loop:
+        for j in range(warm_loops):        # untimed: >= W steps, and the capture of the loop graph
+            x = loop(j, x)
+    else:
+        for _ in range(a.warmup):
+            x, x_next = step(k, x, x_next)
+            k += 1
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        x, x_next = step(k, x, x_next)
-        k += 1
+    if use_loop:
+        for j in range(n_loops):           # exactly K = n_loops * T steps
+            x = loop(warm_loops + j, x)
+    else:
+        for _ in range(a.steps):
+            x, x_next = step(k, x, x_next)
+            k += 1
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
@@ -270,7 +294,8 @@ def run(a):
                        "head": "2.2" if v22 else "2.1", "tile_configs_measured_in_this_process": measured_here,
                        "images_per_gpu": a.bs, "parallelism": f"prompt-sharded x{world}, weights by one RCCL broadcast",
                        "world_size_observed": world_observed,
-                       "graph": not a.no_graph},
+                       "graph": not a.no_graph,
+                       "loop_graph": bool(use_loop) and f"the {T}-step loop replayed as ONE hipGraph ({a.steps // T} replay(s) = {a.steps} timed steps)"},
             "images_per_sec_denoise_only": round(world * a.bs * a.steps / el / a.sched_steps, 4),
             "finite": finite, "load_s": round(t_load, 1),
             "roofline": roofline, "cpu_baseline": cpu, "parity_paths": parity, "e2e": e2e,
@@ -367,7 +392,8 @@ def parity_paths(m_timed, arch, sd, a, dev):
         for it in range(2):       # the first loop plans / captures; the second is timed
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            out = d.p_sample_loop(model, (B, 4, lat, lat), model_kwargs=kw, guidance_scale=fx["guidance"], noise=x_T, noise_seq=noise_seq)
+            out = d.p_sample_loop(model, (B, 4, lat, lat), model_kwargs=kw, guidance_scale=fx["guidance"], noise=x_T, noise_seq=noise_seq,
+                                  whole_loop_graph=not (a.no_loop_graph or a.no_graph))
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
         model.del_cache()

@@ -110,6 +110,17 @@ int k22_unet_forward(K22UNet* u, const float* x, const float* timesteps, const f
                      const float* inpaint_mask, float* out, int use_graph, void* stream);
 
 /* Number of engine ops in one planned forward (diagnostics). */
+/* The whole classifier-free-guided p_sampler loop of Kandinsky2_1.generate_img (kandinsky2/kandinsky2_1_model.py:222-257 driving
+ * kandinsky2/model/gaussian_diffusion.py:384-475) as ONE hipGraph replay: per step  UNet([x_half | x_half], timesteps[k]) ->
+ * k22_sampler_step(guidance, clamp, percentile threshold, posterior mean, noise_seq[k])  with no host work between steps.
+ * Device buffers, filled by the caller before the call: x [B][4][HW] (in: x_T, out: the final latent; x_tmp: same-size scratch),
+ * timesteps [n_steps][B] in execution order, noise_seq [n_steps][B][4][HW], init_img / mask (inpainting blend of the sampler step, or
+ * NULL), inpaint_image / inpaint_mask (9-channel UNet inputs, or NULL), table [T][8]; table_rows: HOST array, schedule row of step k.
+ * use_graph != 0: captured on first use and replayed while the same buffers / scalars are passed. */
+int k22_unet_sample_loop(K22UNet* u, float* x, float* x_tmp, const float* timesteps, const float* noise_seq, const float* init_img,
+                         const float* mask, const float* inpaint_image, const float* inpaint_mask, const float* table,
+                         const int* table_rows, int n_steps, float guidance, float clamp_lo, float clamp_hi, int pct_index,
+                         double pct_gamma, void* scratch, int use_graph, void* stream);
 int k22_unet_num_ops(const K22UNet* u);
 /* Tile configurations of the convolutions / GEMMs are chosen by measurement during the first k22_unet_forward
  * after k22_unet_plan (default on; env K22_AUTOTUNE=0 or k22_unet_set_autotune(u, 0) before planning = heuristics).

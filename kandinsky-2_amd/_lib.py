@@ -80,6 +80,7 @@ SIGNATURES = {
     "k22_unet_set_condition": (_I, [_P, _P, _P, _P, _P]),
     "k22_unet_set_hint": (_I, [_P, _P, _P]),
     "k22_unet_forward": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
+    "k22_unet_sample_loop": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(_I), _I, _F, _F, _F, _I, _D, _P, _I, _P]),
     "k22_unet_num_ops": (_I, [_P]),
     "k22_unet_set_autotune": (_I, [_P, _I]),
     "k22_unet_tuning_report": (_I, [_P, C.c_char_p, _Z]),

@@ -24,6 +24,7 @@
 #include <vector>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 int launch_step_advance(int* step, int delta, hipStream_t s);
 
@@ -82,6 +83,9 @@ struct K22UNet {
   bool cond_set = false;
   hipGraphExec_t graph_exec = nullptr;
   hipStream_t cap_stream = nullptr;  // private stream used only to CAPTURE (the caller's may be the legacy default stream)
+  // the whole denoising loop as ONE graph (k22_unet_sample_loop): valid for exactly the buffers / scalars it was captured with
+  hipGraphExec_t loop_exec = nullptr;
+  std::vector<unsigned long long> loop_key;
   std::string err;
 
   // persistent slots
@@ -114,6 +118,7 @@ struct K22UNet {
   const float* Wf(const std::string& name) { return reinterpret_cast<const float*>(W_(name)); }
 
   ~K22UNet() {
+    if (loop_exec) (void)hipGraphExecDestroy(loop_exec);
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
   }
@@ -394,6 +399,7 @@ struct K22UNet {
     tuned.clear(); tuned_done = false;
     ws = nullptr; cond_set = false; hint_set = false;
     if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+    if (loop_exec) { (void)hipGraphExecDestroy(loop_exec); loop_exec = nullptr; }
     const int mc = cfg.model_channels, ted = 4 * mc;
 
     // total FiLM width = sum over ResBlocks of 2*Cout, in module order
@@ -728,6 +734,7 @@ int k22_unet_bind(K22UNet* u, void* workspace, size_t workspace_bytes) {
   u->ws = reinterpret_cast<char*>(workspace);
   u->cond_set = false; u->hint_set = false;
   if (u->graph_exec) { (void)hipGraphExecDestroy(u->graph_exec); u->graph_exec = nullptr; }
+  if (u->loop_exec) { (void)hipGraphExecDestroy(u->loop_exec); u->loop_exec = nullptr; }
   return K22_OK;
 }
 
@@ -815,6 +822,119 @@ int k22_unet_forward(K22UNet* u, const float* x, const float* timesteps, const f
   }
   K22_CPY(out, u->ptr(u->s_out), (size_t)u->B * u->cfg.out_channels * hw * 4);
 #undef K22_CPY
+  return K22_OK;
+}
+
+// The whole classifier-free-guided p_sampler loop of Kandinsky2_1.generate_img (kandinsky2_1_model.py:222-257 ->
+// gaussian_diffusion.py:384-475) as ONE hipGraph: for every step  UNet([x_half | x_half], t_k) -> k22_sampler_step  with no host work
+// between steps (the reference returns to Python - and to the CPU for np.percentile - at every step).  All inputs are device buffers
+// the caller fills BEFORE the call: timesteps [n_steps][B] (the values the UNet receives, in execution order), noise_seq
+// [n_steps][B][4][HW] (the ancestral noise of every step, drawn up front), table [T][8] + table_rows[k] (host array: the schedule row
+// of step k).  x [B][4][HW] is updated in place (x_tmp: scratch of the same size).  The captured graph is replayed as long as the
+// same buffers and scalars are passed (a generation service re-uses its buffers); anything else re-captures.
+int k22_unet_sample_loop(K22UNet* u, float* x, float* x_tmp, const float* timesteps, const float* noise_seq, const float* init_img,
+                         const float* mask, const float* inpaint_image, const float* inpaint_mask, const float* table,
+                         const int* table_rows, int n_steps, float guidance, float clamp_lo, float clamp_hi, int pct_index,
+                         double pct_gamma, void* scratch, int use_graph, void* stream) {
+  if (!u || !u->ws) return k22_set_error(K22_EINVAL, "unet_sample_loop: bind a workspace first");
+  if (!u->cond_set) return k22_set_error(K22_EINVAL, "unet_sample_loop: call k22_unet_set_condition first");
+  if (!x || !x_tmp || !timesteps || !noise_seq || !table || !table_rows || !scratch || n_steps < 1)
+    return k22_set_error(K22_EINVAL, "unet_sample_loop: null argument");
+  if (u->B % 2) return k22_set_error(K22_EINVAL, "unet_sample_loop: the batch is the CFG batch [cond | uncond] (even)");
+  if (u->cfg.out_channels != 8) return k22_set_error(K22_EINVAL, "unet_sample_loop: the UNet must predict eps and variance (8 channels)");
+  if (u->cfg.in_channels == 9 && (!inpaint_image || !inpaint_mask)) return k22_set_error(K22_EINVAL, "unet_sample_loop: inpainting UNet needs inpaint_image and inpaint_mask");
+  if (u->cfg.hint_channels && !u->hint_set) return k22_set_error(K22_EINVAL, "unet_sample_loop: call k22_unet_set_hint first");
+  const int B = u->B, HW = u->H * u->W;
+  if (pct_index >= 4 * HW) return k22_set_error(K22_EINVAL, "unet_sample_loop: percentile index out of range");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipError_t e;
+  if (u->autotune && !u->tuned_done) {
+    int rc = u->tune_all(st);
+    if (rc) return rc;
+    u->tuned_done = true;
+  }
+  const size_t half = (size_t)(B / 2) * 4 * HW * sizeof(float);
+  // one pass over the loop on `s`: what is captured is exactly what an eager call runs
+  auto run_loop = [&](hipStream_t s) -> int {
+    hipError_t er;
+    if (u->cfg.in_channels == 9) {
+      er = hipMemcpyAsync(u->ptr(u->s_img), inpaint_image, (size_t)B * 4 * HW * 4, hipMemcpyDeviceToDevice, s);
+      if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
+      er = hipMemcpyAsync(u->ptr(u->s_mask), inpaint_mask, (size_t)B * HW * 4, hipMemcpyDeviceToDevice, s);
+      if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
+    }
+    float* cur = x; float* nxt = x_tmp;
+    for (int k = 0; k < n_steps; ++k) {
+      // model_fn: the UNet sees the first half twice (kandinsky2_1_model.py:223-225)
+      er = hipMemcpyAsync(u->ptr(u->s_xin), cur, half, hipMemcpyDeviceToDevice, s);
+      if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
+      er = hipMemcpyAsync(u->ptr(u->s_xin) + half, cur, half, hipMemcpyDeviceToDevice, s);
+      if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
+      er = hipMemcpyAsync(u->ptr(u->s_t), timesteps + (size_t)k * B, (size_t)B * 4, hipMemcpyDeviceToDevice, s);
+      if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
+      int rc = u->run_ops(s);
+      if (rc) return rc;
+      SamplerParams p = {};
+      p.x = cur; p.model_out = u->ptr<float>(u->s_out); p.noise = noise_seq + (size_t)k * B * 4 * HW; p.init_img = init_img; p.mask = mask;
+      p.table = table; p.step = nullptr; p.step_host = table_rows[k]; p.guidance = guidance; p.clamp_lo = clamp_lo; p.clamp_hi = clamp_hi;
+      p.use_cfg = 1; p.n_lo = pct_index; p.gamma = pct_gamma;
+      p.s_buf = reinterpret_cast<float*>(scratch); p.x0_buf = reinterpret_cast<float*>(scratch) + 64;
+      p.x_out = nxt; p.x0_out = nullptr; p.N = B; p.HW = HW;
+      rc = launch_sampler_step(p, s);
+      if (rc) return rc;
+      float* t_ = cur; cur = nxt; nxt = t_;
+    }
+    if (cur != x) {
+      er = hipMemcpyAsync(x, cur, (size_t)B * 4 * HW * sizeof(float), hipMemcpyDeviceToDevice, s);
+      if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
+    }
+    return K22_OK;
+  };
+  if (!use_graph) return run_loop(st);
+  // key of the captured loop: every pointer and scalar baked into its nodes
+  std::vector<unsigned long long> key = {(unsigned long long)(uintptr_t)x, (unsigned long long)(uintptr_t)x_tmp, (unsigned long long)(uintptr_t)timesteps,
+      (unsigned long long)(uintptr_t)noise_seq, (unsigned long long)(uintptr_t)init_img, (unsigned long long)(uintptr_t)mask,
+      (unsigned long long)(uintptr_t)inpaint_image, (unsigned long long)(uintptr_t)inpaint_mask, (unsigned long long)(uintptr_t)table,
+      (unsigned long long)(uintptr_t)scratch, (unsigned long long)n_steps, (unsigned long long)pct_index};
+  auto bits = [](double v) { unsigned long long b; memcpy(&b, &v, 8); return b; };
+  key.push_back(bits(guidance)); key.push_back(bits(clamp_lo)); key.push_back(bits(clamp_hi)); key.push_back(bits(pct_gamma));
+  for (int k = 0; k < n_steps; ++k) key.push_back((unsigned long long)table_rows[k]);
+  if (!u->loop_exec || key != u->loop_key) {
+    if (u->loop_exec) { (void)hipGraphExecDestroy(u->loop_exec); u->loop_exec = nullptr; }
+    if (!u->graph_exec) {   // first forward of this plan: run one step's ops eagerly (function attributes, code load) on a scratch input
+      e = hipMemsetAsync(u->ptr(u->s_xin), 0, (size_t)B * 4 * HW * 4, st);
+      if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+      e = hipMemcpyAsync(u->ptr(u->s_t), timesteps, (size_t)B * 4, hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+      if (u->cfg.in_channels == 9) {
+        e = hipMemcpyAsync(u->ptr(u->s_img), inpaint_image, (size_t)B * 4 * HW * 4, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+        e = hipMemcpyAsync(u->ptr(u->s_mask), inpaint_mask, (size_t)B * HW * 4, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+      }
+      int rc = u->run_ops(st);
+      if (rc) return rc;
+      e = hipStreamSynchronize(st);
+      if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+    }
+    if (!u->cap_stream) {
+      e = hipStreamCreateWithFlags(&u->cap_stream, hipStreamNonBlocking);
+      if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+    }
+    hipGraph_t g = nullptr;
+    e = hipStreamBeginCapture(u->cap_stream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+    const int rc = run_loop(u->cap_stream);
+    e = hipStreamEndCapture(u->cap_stream, &g);
+    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+    e = hipGraphInstantiate(&u->loop_exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) { u->loop_exec = nullptr; return k22_set_error_hip(e, __FILE__, __LINE__); }
+    u->loop_key = key;
+  }
+  e = hipGraphLaunch(u->loop_exec, st);
+  if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
   return K22_OK;
 }
 

@@ -176,7 +176,7 @@ class SpacedDiffusionHIP:
                       denoised_fn=None, model_kwargs: Optional[dict] = None, device=None, progress: bool = False,
                       init_step: Optional[int] = None, *, guidance_scale: Optional[float] = None,
                       noise_seq: Optional[torch.Tensor] = None, init_img: Optional[torch.Tensor] = None,
-                      img_mask: Optional[torch.Tensor] = None, return_pred_xstart: bool = False):
+                      img_mask: Optional[torch.Tensor] = None, return_pred_xstart: bool = False, whole_loop_graph: bool = False):
         """GaussianDiffusion.p_sample_loop (gaussian_diffusion.py:384-425) with the reference's positional / keyword set, on
         the GPU without a host round trip per step.  Two ways to call it:
 
@@ -187,6 +187,9 @@ class SpacedDiffusionHIP:
           `denoised_fun` (clamp +-2, optional inpainting blend) is recognised by probing and folded into the sampler kernel;
         * fused: pass the Text2ImUNetHIP itself as `model` plus guidance_scale= (and init_img= / img_mask= for inpainting):
           model_fn's guidance and denoised_fun (clamp +-2) are computed inside k22_sampler_step.
+
+          With whole_loop_graph=True the fused call replays the ENTIRE loop as one hipGraph (k22_unet_sample_loop: every UNet forward
+          and sampler step of all steps in one launch, no host work between steps; same arithmetic, same bits).
 
         `shape` = (2*bs, 4, h, w) with halves [cond | uncond].  noise_seq[k] (optional, [n_iters, *shape]) replaces
         randn_like at the k-th executed step (parity tests inject the reference's noise).
@@ -239,6 +242,20 @@ class SpacedDiffusionHIP:
             from tqdm.auto import tqdm
             indices = tqdm(indices)
         stream = _lib.current_stream()
+        if fused and whole_loop_graph and hasattr(model, "sample_loop") and not return_pred_xstart and not progress and len(indices) > 0:
+            # the whole loop as ONE hipGraph replay: noise of every step drawn up front by the same sequence of randn_like calls the
+            # per-step path makes (same generator draws), timesteps and schedule rows in execution order
+            n = len(indices)
+            if noise_seq is not None:
+                nzs = noise_seq[:n].to(dev).float().contiguous()
+            else:
+                nzs = torch.empty(n, *x.shape, device=dev)
+                for k in range(n):
+                    nzs[k] = torch.randn_like(x)
+            rows = torch.as_tensor(indices, device=dev)
+            kw = {k_: v for k_, v in model_kwargs.items()}
+            return model.sample_loop(x, ts_rows[rows].contiguous(), nzs, table, list(indices), guidance_scale, (lo, hi), (pct_lo, pct_gamma),
+                                     init_img=init, img_mask=mask, **kw)
         for k, i in enumerate(indices):
             if fused:
                 half = x[:bs]

@@ -170,7 +170,7 @@ class Kandinsky2_1HIP:
     from config["prior"]["clip_mean_std_path"] (path or a (mean, std) pair).  backend_dtype=torch.float32 selects the parity path."""
 
     def __init__(self, config, model_path, prior_path, device="cuda", task_type="text2img", *, conditioner=None,
-                 backend_dtype: torch.dtype = torch.bfloat16, use_graph: bool = True):
+                 backend_dtype: torch.dtype = torch.bfloat16, use_graph: bool = True, whole_loop_graph: Optional[bool] = None):
         if task_type not in ("text2img", "inpainting"):
             raise ValueError("Only text2img and inpainting is available")
         if torch.device(device).type != "cuda":
@@ -179,6 +179,8 @@ class Kandinsky2_1HIP:
         self.device = device
         self.task_type = task_type
         self.backend_dtype = backend_dtype
+        # p_sampler: the whole denoising loop as ONE hipGraph replay (k22_unet_sample_loop) - on whenever graphs are
+        self.whole_loop_graph = use_graph if whole_loop_graph is None else bool(whole_loop_graph)
         self.use_fp16 = False                       # public tensors are fp32; engine precision is backend_dtype
         self.model_dtype = torch.float32
         self.clip_image_size = config.get("clip_image_size", 224)
@@ -274,7 +276,8 @@ class Kandinsky2_1HIP:
         if sampler == "p_sampler":
             samples = diffusion.p_sample_loop(
                 self.model, (full_batch_size, 4, new_h, new_w), device=self.device, noise=noise, model_kwargs=model_kwargs,
-                init_step=init_step, guidance_scale=guidance_scale, init_img=init_img, img_mask=img_mask, noise_seq=noise_seq)[:batch_size]
+                init_step=init_step, guidance_scale=guidance_scale, init_img=init_img, img_mask=img_mask, noise_seq=noise_seq,
+                whole_loop_graph=self.whole_loop_graph)[:batch_size]
         elif sampler in ("ddim_sampler", "plms_sampler"):
             cls = DDIMSamplerHIP if sampler == "ddim_sampler" else PLMSSamplerHIP
             samples, _ = cls(self.model, diffusion, guidance_scale).sample(

@@ -94,6 +94,7 @@ class Text2ImUNetHIP(nn.Module):
             self._handle = None
         self._arena = None
         self._ws = None
+        self._loop_bufs = None
         self._plan_key = None
         self._cond_key = None
 
@@ -267,6 +268,56 @@ class Text2ImUNetHIP(nn.Module):
             self._handle, xf.data_ptr(), tf.data_ptr(), _lib.ptr(img), _lib.ptr(msk), out.data_ptr(),
             1 if self.use_graph else 0, _lib.current_stream()))
         return out
+
+
+    @torch.no_grad()
+    def sample_loop(self, x, ts_rows, noise_seq, table, table_rows, guidance_scale, clamp, pct, *, full_emb=None, pooled_emb=None,
+                    image_emb=None, inpaint_image=None, inpaint_mask=None, init_img=None, img_mask=None):
+        """The whole guided p_sampler loop as ONE hipGraph replay (k22_unet_sample_loop); returns the final latent [N,4,h,w].
+        x [N,4,h,w] = x_T; ts_rows [n_steps, N] and noise_seq [n_steps, N,4,h,w] in execution order; table [T,8] + table_rows (host ints):
+        the schedule row of every step.  The operands are copied into buffers this module OWNS, so that a second generation of the
+        same shape and step count replays the captured graph (its nodes hold those addresses) instead of capturing 20 000 nodes again."""
+        B, Cx, H, W = x.shape
+        if Cx != 4 or x.device.type != "cuda":
+            raise ValueError("sample_loop: x must be [N,4,h,w] on the GPU")
+        n_steps = len(table_rows)
+        if tuple(ts_rows.shape) != (n_steps, B) or tuple(noise_seq.shape) != (n_steps, B, 4, H, W):
+            raise ValueError("sample_loop: ts_rows must be [n_steps, N] and noise_seq [n_steps, N, 4, h, w]")
+        self._ensure_plan(B, H, W)
+        if self._cond_key is None or not self.cache_text_emb:
+            if full_emb is None or pooled_emb is None or image_emb is None:
+                raise ValueError("full_emb, pooled_emb and image_emb are required")
+            self.set_condition(full_emb, pooled_emb, image_emb)
+            self._cond_key = True
+            self.cache = {"cached": True}
+        if not self.arch.inpainting and (inpaint_image is not None or inpaint_mask is not None):
+            raise ValueError("inpaint_image / inpaint_mask given to a text2img UNet (create it with inpainting=True)")
+        dev = x.device
+        key = (B, H, W, n_steps, tuple(table.shape), init_img is not None, str(dev))
+        bufs = getattr(self, "_loop_bufs", None)
+        if bufs is None or bufs["key"] != key:
+            f32 = dict(dtype=torch.float32, device=dev)
+            bufs = {"key": key, "x": torch.empty(B, 4, H, W, **f32), "tmp": torch.empty(B, 4, H, W, **f32), "ts": torch.empty(n_steps, B, **f32),
+                    "noise": torch.empty(n_steps, B, 4, H, W, **f32), "table": torch.empty(tuple(table.shape), **f32),
+                    "scratch": torch.empty(_lib.lib().k22_sampler_scratch_bytes(B, H * W), dtype=torch.uint8, device=dev),
+                    "init": torch.empty(B, 4, H, W, **f32) if init_img is not None else None,
+                    "mask": torch.empty(B, 1, H, W, **f32) if init_img is not None else None,
+                    "img": torch.zeros(B, 4, H, W, **f32) if self.arch.inpainting else None,
+                    "msk": torch.zeros(B, 1, H, W, **f32) if self.arch.inpainting else None}
+            self._loop_bufs = bufs
+        bufs["x"].copy_(x); bufs["ts"].copy_(ts_rows); bufs["noise"].copy_(noise_seq); bufs["table"].copy_(table)
+        if init_img is not None:
+            bufs["init"].copy_(init_img.float().expand(B, 4, H, W)); bufs["mask"].copy_(img_mask.float().expand(B, 1, H, W))
+        if self.arch.inpainting:
+            bufs["img"].zero_() if inpaint_image is None else bufs["img"].copy_(inpaint_image.float().expand(B, 4, H, W))
+            bufs["msk"].zero_() if inpaint_mask is None else bufs["msk"].copy_(inpaint_mask.float().expand(B, 1, H, W))
+        rows = (C.c_int * n_steps)(*[int(r) for r in table_rows])
+        _lib.check(_lib.lib().k22_unet_sample_loop(
+            self._handle, bufs["x"].data_ptr(), bufs["tmp"].data_ptr(), bufs["ts"].data_ptr(), bufs["noise"].data_ptr(), _lib.ptr(bufs["init"]),
+            _lib.ptr(bufs["mask"]), _lib.ptr(bufs["img"]), _lib.ptr(bufs["msk"]), bufs["table"].data_ptr(), rows, n_steps, float(guidance_scale),
+            float(clamp[0]), float(clamp[1]), int(pct[0]), float(pct[1]), bufs["scratch"].data_ptr(), 1 if self.use_graph else 0,
+            _lib.current_stream()))
+        return bufs["x"].clone()
 
 
 def create_model(backend_dtype: torch.dtype = torch.bfloat16, use_graph: bool = True, inpainting: bool = False,

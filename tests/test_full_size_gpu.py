@@ -175,6 +175,11 @@ def test_full_size_p_sampler_fp32_gate(golden_dir, name):
         whole = d.p_sample_loop(m, (B, 4, lat, lat), model_kwargs=dict(full_emb=full.cuda(), pooled_emb=pooled.cuda(), image_emb=image.cuda()),
                                 guidance_scale=fx["guidance"], noise=x_T.cuda(), noise_seq=noise_seq.cuda()).cpu()
         assert torch.equal(whole, traj["final"])
+        # ... and so does the WHOLE loop replayed as one hipGraph (k22_unet_sample_loop: 50 forwards + 50 sampler steps, one launch)
+        m.del_cache()
+        one_graph = d.p_sample_loop(m, (B, 4, lat, lat), model_kwargs=dict(full_emb=full.cuda(), pooled_emb=pooled.cuda(), image_emb=image.cuda()),
+                                    guidance_scale=fx["guidance"], noise=x_T.cuda(), noise_seq=noise_seq.cuda(), whole_loop_graph=True).cpu()
+        assert torch.equal(one_graph, traj["final"])
 
 
 @pytest.mark.parametrize("name", ["c2_text2img", "c4_inpaint"])

@@ -93,6 +93,49 @@ def test_p_sampler_final_latent_vs_reference_golden_fp32(golden_dir, name):
     assert err <= 1e-3
 
 
+@pytest.mark.parametrize("name", ["tiny_text2img", "tiny_inpaint"])
+@pytest.mark.parametrize("backend", [torch.float32, torch.bfloat16])
+def test_whole_loop_graph_equals_the_stepwise_loop_bit_for_bit(golden_dir, name, backend):
+    """k22_unet_sample_loop - every UNet forward and sampler step of the whole p_sampler loop captured as ONE hipGraph -
+    runs the same kernels on the same operands as the per-step path: equal bits (text2img and the inpainting blend), also on the
+    second generation, which REPLAYS the captured graph with new inputs copied into its buffers, and without graphs (eager loop)."""
+    fx = _load(golden_dir, name)
+    arch, sd, m, _x, img, mask, kw = _setup(fx, backend, use_graph=True)
+    d = k22.create_gaussian_diffusion(**dict(k22.DIFFUSION_CONFIG_2_1, timestep_respacing=str(fx["steps"])))
+    ii, mm = (img.cuda(), mask.cuda()) if fx["inpainting"] else (None, None)
+    shape = (fx["B"], 4, fx["h"], fx["w"])
+    for seed in (42, 43):
+        g = torch.Generator().manual_seed(seed)
+        x_T = torch.randn(*shape, generator=g).cuda()
+        noise_seq = torch.randn(fx["steps"], *shape, generator=g).cuda()
+        m.del_cache()
+        step = d.p_sample_loop(m, shape, model_kwargs=kw, guidance_scale=fx["guidance"], noise=x_T, noise_seq=noise_seq, init_img=ii, img_mask=mm)
+        m.del_cache()
+        whole = d.p_sample_loop(m, shape, model_kwargs=kw, guidance_scale=fx["guidance"], noise=x_T, noise_seq=noise_seq, init_img=ii, img_mask=mm,
+                                whole_loop_graph=True)
+        assert torch.equal(whole, step), (name, backend, seed, (whole - step).abs().max().item())
+    if backend == torch.float32 and seed == 43:
+        g = torch.Generator().manual_seed(42)
+        x_T = torch.randn(*shape, generator=g).cuda()
+        noise_seq = torch.randn(fx["steps"], *shape, generator=g).cuda()
+        m.del_cache()
+        again = d.p_sample_loop(m, shape, model_kwargs=kw, guidance_scale=fx["guidance"], noise=x_T, noise_seq=noise_seq, init_img=ii, img_mask=mm,
+                                whole_loop_graph=True).cpu()
+        assert (again - fx["final"]).abs().max().item() <= 1e-3           # the reference golden, through the one-graph loop
+    # a shorter loop (init_step, as img2img uses it) re-captures; the eager form of the same entry point gives the same bits
+    m.del_cache()
+    a = d.p_sample_loop(m, shape, model_kwargs=kw, guidance_scale=fx["guidance"], noise=x_T, noise_seq=noise_seq, init_img=ii, img_mask=mm, init_step=3)
+    m.del_cache()
+    b = d.p_sample_loop(m, shape, model_kwargs=kw, guidance_scale=fx["guidance"], noise=x_T, noise_seq=noise_seq, init_img=ii, img_mask=mm, init_step=3,
+                        whole_loop_graph=True)
+    assert torch.equal(a, b)
+    m.use_graph = False
+    m.del_cache()
+    c = d.p_sample_loop(m, shape, model_kwargs=kw, guidance_scale=fx["guidance"], noise=x_T, noise_seq=noise_seq, init_img=ii, img_mask=mm, init_step=3,
+                        whole_loop_graph=True)
+    assert torch.equal(a, c)
+
+
 def test_p_sampler_bf16_drift_bounded(golden_dir):
     fx = _load(golden_dir, "tiny_text2img")
     arch, sd, m, _x, img, mask, kw = _setup(fx, torch.bfloat16, use_graph=True)
