@@ -170,7 +170,8 @@ class Kandinsky2_1HIP:
     from config["prior"]["clip_mean_std_path"] (path or a (mean, std) pair).  backend_dtype=torch.float32 selects the parity path."""
 
     def __init__(self, config, model_path, prior_path, device="cuda", task_type="text2img", *, conditioner=None,
-                 backend_dtype: torch.dtype = torch.bfloat16, use_graph: bool = True, whole_loop_graph: Optional[bool] = None):
+                 backend_dtype: torch.dtype = torch.bfloat16, use_graph: bool = True, whole_loop_graph: Optional[bool] = None,
+                 movq_dtype: Optional[torch.dtype] = torch.float32):
         if task_type not in ("text2img", "inpainting"):
             raise ValueError("Only text2img and inpainting is available")
         if torch.device(device).type != "cuda":
@@ -213,7 +214,11 @@ class Kandinsky2_1HIP:
             raise NotImplementedError("only the MOVQ image encoder of Kandinsky 2.1")
         self.use_image_enc, self.scale = True, ie["scale"]
         movq_sd = _load(ie["ckpt_path"])
-        self.image_encoder = _MoVQ(ie["params"], movq_sd, backend_dtype, device)
+        # MoVQ runs once per image (17 ms in bf16 / fp16, 56 ms in fp32 at 768 px, against ~360 ms of denoising) and its output IS the
+        # picture: by default it computes in fp32, where the uint8 image is within ONE grey level of the reference's (bf16 moves pixels by
+        # up to 32 levels, fp16 by up to 5 on the 768-px reference fixture; tests/test_movq_gpu.py).  movq_dtype=None: follow backend_dtype.
+        self.movq_dtype = backend_dtype if movq_dtype is None else movq_dtype
+        self.image_encoder = _MoVQ(ie["params"], movq_sd, self.movq_dtype, device)
 
         self.model = Text2ImUNetHIP(make_arch(mcfg, inpainting=mcfg["inpainting"]), backend_dtype=backend_dtype, use_graph=use_graph,
                                     cache_text_emb=True)
@@ -434,7 +439,8 @@ def _conditioner_from_cache_dir(cache_dir, device, backend_dtype):
 
 
 def get_kandinsky2(device, task_type="text2img", cache_dir="/tmp/kandinsky2", use_auth_token=None, model_version="2.1",
-                   use_flash_attention=False, *, conditioner=None, backend_dtype: torch.dtype = torch.bfloat16, use_graph: bool = True):
+                   use_flash_attention=False, *, conditioner=None, backend_dtype: torch.dtype = torch.bfloat16, use_graph: bool = True,
+                   movq_dtype: Optional[torch.dtype] = torch.float32):
     """`get_kandinsky2` (kandinsky2/__init__.py:164-192) for the HIP engines.  The reference downloads the checkpoints into
     cache_dir (kandinsky2/__init__.py:100-160); this box-local variant reads the same file names from cache_dir and raises if
     they are not there (there is no download path).  use_flash_attention is accepted and ignored: attention always runs in the
@@ -453,9 +459,9 @@ def get_kandinsky2(device, task_type="text2img", cache_dir="/tmp/kandinsky2", us
         if conditioner is None:
             conditioner = _conditioner_from_cache_dir(cache_dir, device, backend_dtype)
         return Kandinsky2_1HIP(config, need[model_name], need["prior_fp16.ckpt"], device, task_type=task_type, conditioner=conditioner,
-                               backend_dtype=backend_dtype, use_graph=use_graph)
+                               backend_dtype=backend_dtype, use_graph=use_graph, movq_dtype=movq_dtype)
     if model_version == "2.2":
         from .pipeline22 import Kandinsky2_2HIP
         return Kandinsky2_2HIP(device=device, task_type=task_type, cache_dir=cache_dir, conditioner=conditioner, backend_dtype=backend_dtype,
-                               use_graph=use_graph)
+                               use_graph=use_graph, movq_dtype=movq_dtype)
     raise ValueError("Only 2.1 and 2.2 are available on the HIP engines")

@@ -11,7 +11,7 @@ ap.add_argument("--bs", type=int, default=1)
 ap.add_argument("--dtype", default="bf16")
 a = ap.parse_args()
 arch = k22.MoVQArch(k22.MOVQ_CONFIG_2_1["ddconfig"])
-m = k22.MoVQDecoderHIP(backend_dtype=torch.bfloat16 if a.dtype == "bf16" else torch.float32)
+m = k22.MoVQDecoderHIP(backend_dtype={"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[a.dtype])
 m.load_state_dict(k22.init_movq_state_dict(arch, seed=0), strict=True)
 m = m.to("cuda")
 lat = a.size // 8
@@ -28,7 +28,7 @@ gflop = {768: 4885.5, 1024: 9647.4}.get(a.size, 4885.5 * (a.size / 768) ** 2) * 
 print(f"MoVQ decode {a.size}x{a.size} bs={a.bs} {a.dtype}: {ms:.2f} ms/image-batch  (~{gflop / ms:.0f} TFLOP/s, finite={bool(torch.isfinite(out).all())}, ws={m._ws.numel() / 2**20:.0f} MiB)")
 
 # encoder (img2img / inpainting pre-step): once per call
-e = k22.MoVQEncoderHIP(backend_dtype=torch.bfloat16 if a.dtype == "bf16" else torch.float32)
+e = k22.MoVQEncoderHIP(backend_dtype={"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[a.dtype])
 e.load_state_dict(k22.init_movq_encoder_state_dict(arch, seed=0), strict=True)
 e = e.to("cuda")
 img = torch.randn(a.bs, 3, a.size, a.size, device="cuda") * 0.5
