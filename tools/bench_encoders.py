@@ -33,8 +33,8 @@ if __name__ == "__main__":
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--reps", type=int, default=20)
     a = ap.parse_args()
-    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    es = 2 if a.dtype == "bf16" else 4
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[a.dtype]
+    es = 4 if a.dtype == "fp32" else 2
     out = {}
     xcfg = dict(k22.XLMR_LARGE, vocab_size=32768)     # the vocabulary only feeds a gather: 32 k rows keep the host-side init short
     te = k22.TextEncoderHIP(xlmr_config=xcfg, state_dict=k22.init_multiclip_state_dict(xcfg, seed=0), backend_dtype=dt).to("cuda")
@@ -54,5 +54,15 @@ if __name__ == "__main__":
     img = torch.randn(1, 3, 224, 224, device="cuda")
     ms = timed(lambda: clip.encode_image(img), a.reps)
     out["clip_image_1x224"] = {"ms": round(ms, 3), "linear_weight_GB_per_s": round(24 * 12 * 1024 * 1024 * es / ms / 1e6, 1)}
+    del clip, te
+    torch.cuda.empty_cache()
+    # Kandinsky 2.2's image encoder: CLIP ViT-bigG/14 (kandinsky2_2_model.py:24), 1.85 B parameters, 16 heads of 104 channels
+    c = k22.CLIP_BIGG_VISION
+    big = k22.CLIPVisionModelWithProjectionHIP(c, backend_dtype=dt)
+    big.load_state_dict(k22.init_clip_vision_hf_state_dict(c, seed=0))
+    big = big.to("cuda")
+    ms = timed(lambda: big(img).image_embeds, max(3, a.reps // 4))
+    wbig = c["num_hidden_layers"] * (4 * c["hidden_size"] ** 2 + 2 * c["hidden_size"] * c["intermediate_size"]) * es
+    out["clip_bigg_image_1x224"] = {"ms": round(ms, 3), "linear_weight_GB_per_s": round(wbig / ms / 1e6, 1)}
     out["dtype"] = a.dtype
     print(json.dumps(out))
