@@ -143,29 +143,36 @@ __global__ __launch_bounds__(256) void enc_quickgelu_kernel(const float* x, T* y
 }
 
 // ---- attention for head widths other than 64 (CLIP ViT-bigG/14: 1664 / 16 = 104 per head), short sequences (n <= 512), no mask:
-// CLIPAttention.forward of transformers (softmax((q * hd^-0.5) k^T) v per head).  One workgroup = 64 queries of one (image, head):
-// the head's K rows sit in the LDS as fp32 (row stride hd + 1 words: conflict-free across keys), every wave walks its 16 queries one
+// CLIPAttention.forward of transformers (softmax((q * hd^-0.5) k^T) v per head).  One workgroup = 16 queries of one (image, head):
+// the head's K rows sit in the LDS as fp32 (row stride hd + 1 words: conflict-free across keys), every wave walks its 4 queries one
 // at a time - lane = key for the scores (5 keys per lane at n = 257), lane = channel for P.V (V rows straight from L2, coalesced).
 // Plain fp32 FMAs: 48 layers x 27 MFLOP per head is ~20 GFLOP per image, a few ms once per generation - not worth an MFMA tiling.
 template <typename T>
 __global__ __launch_bounds__(256) void enc_attention_generic_kernel(const T* __restrict__ qkv, T* __restrict__ out, int n, int D, int hd, float scale) {
   extern __shared__ __attribute__((aligned(16))) char esm[];
-  float* Ks = reinterpret_cast<float*>(esm);                       // [n][hd + 1]
-  float* qs = Ks + (size_t)n * (hd + 1);                           // [4 waves][128]
+  // K and V rows of this (image, head) in the LDS, in the storage type (row stride hd + 2 elements: odd word stride for the 16-bit types,
+  // so that 64 keys read one channel without bank conflicts).  fp32 storage (parity path): K only - V rows come from L2 (K + V would
+  // need 216 KB); that path is for 1e-6 parity checks, not for speed.
+  constexpr bool V_IN_LDS = sizeof(T) == 2;
+  const int rs = hd + 2;
+  T* Ks = reinterpret_cast<T*>(esm);                               // [n][rs]
+  T* Vs = Ks + (size_t)n * rs;                                     // [n][rs] (16-bit types)
+  float* qs = reinterpret_cast<float*>(esm + (((size_t)n * rs * sizeof(T) * (V_IN_LDS ? 2 : 1)) + 15) / 16 * 16);   // [4 waves][128]
   float* ps = qs + 4 * 128;                                        // [4 waves][512]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int head = blockIdx.y, b = blockIdx.z, q0 = blockIdx.x * 64;
+  const int head = blockIdx.y, b = blockIdx.z, q0 = blockIdx.x * 16;   // 16 queries per workgroup (4 per wave): 17 x 16 heads = 272 workgroups per image at n = 257
   const int64_t ld = 3 * (int64_t)D;
   const T* base = qkv + (int64_t)b * n * ld + head * hd;
   for (int i = tid; i < n * hd; i += 256) {
     const int key = i / hd, d = i - key * hd;
-    Ks[key * (hd + 1) + d] = to_f32(base[(int64_t)key * ld + D + d]);
+    Ks[key * rs + d] = base[(int64_t)key * ld + D + d];
+    if (V_IN_LDS) Vs[key * rs + d] = base[(int64_t)key * ld + 2 * D + d];
   }
   __syncthreads();
   float* qw = qs + wave * 128;
   float* pw = ps + wave * 512;
-  for (int qq = 0; qq < 16; ++qq) {
-    const int qi = q0 + wave * 16 + qq;
+  for (int qq = 0; qq < 4; ++qq) {
+    const int qi = q0 + wave * 4 + qq;
     if (qi >= n) break;                                            // wave-uniform
     for (int d = lane; d < hd; d += 64) qw[d] = to_f32(base[(int64_t)qi * ld + d]) * scale;
     __builtin_amdgcn_wave_barrier();
@@ -175,10 +182,11 @@ __global__ __launch_bounds__(256) void enc_attention_generic_kernel(const T* __r
     for (int kk = 0; kk < 8; ++kk) {
       const int key = kk * 64 + lane;
       float a = -3.0e38f;
-      if (key < n) {
+      if (kk * 64 < n) {                                           // wave-uniform: whole key blocks past the sequence cost nothing
         a = 0.f;
-        const float* kr = Ks + key * (hd + 1);
-        for (int d = 0; d < hd; ++d) a += qw[d] * kr[d];
+        const T* kr = Ks + (key < n ? key : n - 1) * rs;
+        for (int d = 0; d < hd; ++d) a += qw[d] * to_f32(kr[d]);
+        if (key >= n) a = -3.0e38f;
       }
       sc[kk] = a;
       m = fmaxf(m, a);
@@ -199,8 +207,13 @@ __global__ __launch_bounds__(256) void enc_attention_generic_kernel(const T* __r
     const float inv = 1.f / l;
     for (int d = lane; d < hd; d += 64) {
       float acc = 0.f;
-      const T* vp = base + 2 * D + d;
-      for (int key = 0; key < n; ++key) acc += pw[key] * to_f32(vp[(int64_t)key * ld]);
+      if (V_IN_LDS) {
+        const T* vp = Vs + d;
+        for (int key = 0; key < n; ++key) acc += pw[key] * to_f32(vp[key * rs]);
+      } else {
+        const T* vp = base + 2 * D + d;
+        for (int key = 0; key < n; ++key) acc += pw[key] * to_f32(vp[(int64_t)key * ld]);
+      }
       out[((int64_t)b * n + qi) * D + head * hd + d] = from_f32<T>(acc * inv);
     }
     __builtin_amdgcn_wave_barrier();
@@ -290,7 +303,8 @@ struct K22Encoder {
     if (D < 64 || D % 64 || D > 2048 || heads < 1 || D % heads) return k22_set_error(K22_EINVAL, "encoder: width % 64 == 0, width <= 2048, width % heads == 0");
     const int hd = D / heads;
     const bool flash = hd == 64;       // the UNet's flash attention kernel; anything else: enc_attention_generic_kernel (vision tower only)
-    if (!flash && (cfg.kind != K22_ENC_CLIP_VISION || hd > 128 || n > 512 || (size_t)n * (hd + 1) * 4 + 4 * 640 * 4 > 160 * 1024))
+    const size_t ga_smem = ((size_t)n * (hd + 2) * esz * (esz == 2 ? 2 : 1) + 15) / 16 * 16 + 4 * 640 * 4;   // enc_attention_generic_kernel
+    if (!flash && (cfg.kind != K22_ENC_CLIP_VISION || hd > 128 || n > 512 || ga_smem > 160 * 1024))
       return k22_set_error(K22_EINVAL, "encoder: head widths other than 64 are built for the vision tower (<= 128 per head, <= 512 tokens)");
     const int F = cfg.mlp_dim > 0 ? cfg.mlp_dim : 4 * D;
     if (F % 64) return k22_set_error(K22_EINVAL, "encoder: mlp_dim % 64");
@@ -370,10 +384,10 @@ struct K22Encoder {
       op_linear(s_ln, M, 3 * D, D, pfx + ".qkv", K22_ACT_NONE, s_qkv, 3 * D, 0);
       const int causal = kind == K22_ENC_CLIP_TEXT ? 1 : 0;
       if (!flash) {
-        const size_t smem = (size_t)n * (hd + 1) * 4 + 4 * 640 * 4;
+        const size_t smem = ga_smem;
         const float sc = 1.0f / sqrtf((float)hd);
         ops.push_back([=](hipStream_t st) {
-          dim3 grid((n + 63) / 64, heads, Bn);
+          dim3 grid((n + 15) / 16, heads, Bn);
 #define K22_GA(TT_)                                                                                                              \
           {                                                                                                                      \
             static LdsAttrGuard guard;                                                                                           \
