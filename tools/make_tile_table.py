@@ -114,12 +114,30 @@ def encoders():
             torch.cuda.empty_cache()
 
 
+def vision_hf():
+    """Kandinsky 2.2's image encoder (CLIPVisionModelWithProjection, CLIP ViT-bigG/14) at 1 / 2 images, and the parity-test tower"""
+    for cfg, imgs, dtypes in ((k22.CLIP_BIGG_VISION, (1, 2), (torch.bfloat16, torch.float32)),
+                              (k22.tiny_clip_vision_hf_config(), (1, 3), (torch.bfloat16, torch.float32))):
+        sd = k22.init_clip_vision_hf_state_dict(cfg, seed=0)
+        for dt in dtypes:
+            m = k22.CLIPVisionModelWithProjectionHIP(cfg, backend_dtype=dt)
+            m.load_state_dict(sd)
+            m = m.to("cuda")
+            for n in imgs:
+                m(torch.zeros(n, 3, cfg["image_size"], cfg["image_size"], device="cuda"))
+            torch.cuda.synchronize()
+            print(f"clip vision (hf keys) width {cfg['hidden_size']} {dt}: table = {_lib.lib().k22_tile_table_size()} entries", flush=True)
+            del m
+            torch.cuda.empty_cache()
+
+
 def main():
     out = next((a for a in sys.argv[1:] if not a.startswith("--")), "gpurun_out/tiles_gfx950.txt")
     quick = "--quick" in sys.argv
     if ENC_ONLY:
         n0 = _lib.lib().k22_tile_table_size()
         encoders()
+        vision_hf()
         n = _lib.lib().k22_tile_table_save(out.encode())
         print(f"{n0} shipped + {n - n0} new = {n} entries -> {out}")
         return
@@ -148,6 +166,7 @@ def main():
         prior(k22.PRIOR_HPARAMS_2_1, [2, 4, 8], dtypes=(torch.bfloat16,))
         prior(k22.PRIOR_HPARAMS_2_1, [4], dtypes=(torch.float32,))
         encoders()
+        vision_hf()
     n = _lib.lib().k22_tile_table_save(out.encode())
     print(f"{n} entries -> {out}")
 
