@@ -260,3 +260,38 @@ def test_kandinsky2_2_wrapper_task_types():
         assert out.shape == (2, H, H, 3) and out.dtype.name == "uint8"
     with pytest.raises(ValueError):
         k22.pipeline22.Kandinsky2_2HIP("cuda", "superres", unet_state_dict={}, movq_state_dict={})
+
+
+def test_kandinsky2_2_builds_itself_from_a_cache_dir(tmp_path):
+    """kandinsky2_2_model.py:26-41 through local files: the decoder repository's unet/ (safetensors + config.json), movq/ (.bin) and
+    scheduler/scheduler_config.json drive architecture, weights and scheduler; the result equals the directly constructed model bit
+    for bit, and a learned_range scheduler_config.json changes the samples (the file decides, nothing is hard-coded)."""
+    import json
+    from safetensors.torch import save_file
+    msd, _, _ = _movq_pair()
+    cfgu = k22.tiny_unet22_config()
+    arch = k22.make_arch22(cfgu)
+    usd = k22.init_unet22_state_dict(arch, seed=0)
+    root = tmp_path / "kandinsky-2-2-decoder"
+    for sub in ("unet", "movq", "scheduler"):
+        (root / sub).mkdir(parents=True)
+    save_file({k: v.contiguous() for k, v in usd.items()}, str(root / "unet" / "diffusion_pytorch_model.safetensors"))
+    json.dump(dict({k: (list(v) if isinstance(v, tuple) else v) for k, v in cfgu.items()}, _class_name="UNet2DConditionModel"), open(root / "unet" / "config.json", "w"))
+    torch.save(msd, str(root / "movq" / "diffusion_pytorch_model.bin"))
+    H = 128
+    g = torch.Generator().manual_seed(21)
+    lat, nz = torch.randn(1, 4, H // 8, H // 8, generator=g).cuda(), torch.randn(3, 1, 4, H // 8, H // 8, generator=g).cuda()
+    outs = {}
+    for name, sc in (("file", k22.SCHEDULER_CONFIG_2_2), ("learned", k22.SCHEDULER_CONFIG_2_2_LEARNED_RANGE)):
+        json.dump(dict(sc, _diffusers_version="0.18.0.dev0"), open(root / "scheduler" / "scheduler_config.json", "w"))
+        mdl = k22.get_kandinsky2("cuda", task_type="text2img", cache_dir=str(tmp_path), model_version="2.2", conditioner="seeded",
+                                 backend_dtype=torch.float32)
+        assert mdl.decoder.scheduler.config.variance_type == sc.get("variance_type", "fixed_small")
+        outs[name] = mdl.generate_text2img("a cat", batch_size=1, decoder_steps=3, h=H, w=H, latents=lat, noise_seq=nz, output_type="latent")
+    direct = k22.pipeline22.Kandinsky2_2HIP("cuda", "text2img", unet_state_dict=usd, movq_state_dict=msd, unet_config=cfgu, conditioner="seeded",
+                                            backend_dtype=torch.float32)
+    want = direct.generate_text2img("a cat", batch_size=1, decoder_steps=3, h=H, w=H, latents=lat, noise_seq=nz, output_type="latent")
+    assert torch.equal(outs["file"], want)
+    assert not torch.equal(outs["learned"], want)
+    with pytest.raises(ValueError, match="conditioner"):
+        k22.get_kandinsky2("cuda", task_type="text2img", cache_dir=str(tmp_path), model_version="2.2")
