@@ -37,8 +37,23 @@ const char* k22_last_error(void);
 /* Tuning knobs (process-wide): "igemm_stages" = 2..4 LDS-DMA pipeline depth (-1 default);
  * "igemm_xcd_remap" = 0/1 XCD-aware workgroup renumbering; "conv_algo" = 0 auto, 1 generic implicit GEMM,
  * 2 LDS-resident halo kernel for the 3x3 convolutions (3-7: its variants, see conv3_halo.hip; 8-9: measurement only);
- * "gemm_algo" = 0 generic implicit-GEMM kernel, 10 = 8-wave BM x 128 tile kernel where it applies. */
+ * "gemm_algo" = 0 generic implicit-GEMM kernel, 10 = 8-wave BM x 128 tile kernel where it applies;
+ * "conv_algo" / "gemm_algo" = 20: the weight-streaming small-M kernel (stream_gemm.hip; bm = 160 / 288 picks 5 / 9 m-blocks
+ * per workgroup, needs the fp32 partial buffer also for splitk == 1). */
 int k22_set_option(const char* name, int value);
+/* Launch counters for tests ("stream_launches": launches of the weight-streaming kernel since the library was loaded);
+ * -1 for an unknown name. */
+long k22_debug_counter(const char* name);
+/* Fragment-major copy of a 16-bit weight matrix [Npad][taps * Kc] for the weight-streaming kernel (1 KB contiguous per MFMA B
+ * fragment; layout in stream_gemm.hip).  k22_stream_frag_bytes = size of the copy (0 for fp32: the kernel is 16-bit only).
+ * k22_debug_set_stream_frag hands the copies (main weights, fused-skip weights or NULL) to the kernel-level test entries below
+ * until reset with NULLs; the engines keep their own copies and never read it. */
+size_t k22_stream_frag_bytes(int Npad, int taps, int Kc, int dtype);
+int k22_stream_repack(const void* W, void* out, int Npad, int taps, int Kc, int dtype, void* stream);
+int k22_debug_set_stream_frag(const void* wfrag, const void* wsfrag);
+/* Parity-test mode: with a scratch buffer set (and no explicit copies), every kernel-level test entry repacks its weights into the
+ * scratch on `stream` before the launch, so the tests' own packing helpers exercise the fragment-major path unchanged.  NULL resets. */
+int k22_debug_set_stream_scratch(void* scratch, size_t bytes);
 
 /* ---- UNet engine --------------------------------------------------------------------------
  * Replaces Text2ImUNet.forward / InpaintText2ImUNet.forward (kandinsky2/model/text2im_model2_1.py:
@@ -240,6 +255,10 @@ int k22_attention(const void* qkv, const void* ctxkv, void* kall, void* vtall, v
  * v -> vtall[b][h][d][S+t] (both [..][Tkp = roundup(S+T,64)]; the first S keys belong to the context). */
 int k22_qkv_project(const void* x, const void* Wp, const float* bias, void* q_out, void* kall, void* vtall,
                     int B, int H, int T, int S, int K, int bm, int bn, int dtype, void* stream);
+/* The same projection on the weight-streaming small-M kernel (unet.py:251 at the 12x12 / 24x24 levels): partial = fp32
+ * scratch [splitk][B*T][3C]; bm = 160 / 288. */
+int k22_qkv_project_stream(const void* x, const void* Wp, const float* bias, void* q_out, void* kall, void* vtall, void* partial,
+                           int B, int H, int T, int S, int K, int bm, int splitk, int dtype, void* stream);
 int k22_linear_smallm(const float* x, const void* W, const float* bias, const float* add, float* out, int M, int N,
                       int K, int act_in, int act_out, int wdtype, void* stream);
 

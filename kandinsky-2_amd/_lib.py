@@ -122,7 +122,13 @@ SIGNATURES = {
     "k22_groupnorm_scratch_bytes": (_Z, [_I, _I]),
     "k22_attention": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "k22_qkv_project": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "k22_qkv_project_stream": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "k22_linear_smallm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "k22_debug_counter": (_L, [C.c_char_p]),
+    "k22_stream_frag_bytes": (C.c_size_t, [_I, _I, _I, _I]),
+    "k22_stream_repack": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "k22_debug_set_stream_frag": (_I, [_P, _P]),
+    "k22_debug_set_stream_scratch": (_I, [_P, C.c_size_t]),
 }
 
 _lib = None

@@ -31,6 +31,51 @@ int k22_set_option(const char* name, int value) {
 }
 const char* k22_last_error(void) { return g_err; }
 
+// Test / bench surface of the weight-streaming kernel's fragment-major weights: k22_stream_repack writes the copy, and the pointers
+// given to k22_debug_set_stream_frag ride along with every LATER kernel-level test entry of this file (k22_gemm, k22_conv3x3*,
+// k22_qkv_project_stream) until they are reset to NULL.  The engines own their copies themselves (engine.hip); nothing in the product
+// path reads these globals.
+#ifdef K22_STREAM_DEBUG
+static unsigned long long* g_dbg_trace = nullptr;
+extern "C" int k22_debug_set_stream_trace(unsigned long long* t) { g_dbg_trace = t; return K22_OK; }
+#define K22_DBG_TRACE(p) (p).st_trace = g_dbg_trace
+#else
+#define K22_DBG_TRACE(p) (void)0
+#endif
+static const void* g_dbg_wfrag = nullptr;
+static const void* g_dbg_wsfrag = nullptr;
+static void* g_dbg_scratch = nullptr;      // "repack on every call" mode for the parity tests (their helpers pack the weights themselves)
+static size_t g_dbg_scratch_bytes = 0;
+static int dbg_frag(IgemmParams& p, int dtype, hipStream_t st) {
+  K22_DBG_TRACE(p);
+  p.Wfrag = g_dbg_wfrag; p.Wsfrag = g_dbg_wsfrag;
+  if (g_dbg_wfrag || !g_dbg_scratch || dtype == K22_F32 || (p.taps != 1 && p.taps != 9) || p.Kc % 64 || p.Npad % 64) return K22_OK;
+  const size_t n1 = stream_frag_bytes(p.Npad, p.taps, p.Kc, dtype);
+  const bool skip = p.S0 != nullptr && p.Ws != nullptr && (p.SK0 + p.SK1) % 64 == 0;
+  const size_t n2 = skip ? stream_frag_bytes(p.Npad, 1, p.SK0 + p.SK1, dtype) : 0;
+  if (n1 + n2 > g_dbg_scratch_bytes) return k22_set_error(K22_ENOMEM, "debug stream scratch too small");
+  if (int rc = launch_stream_repack(p.Wp, g_dbg_scratch, p.Npad, p.taps, p.Kc, dtype, st)) return rc;
+  p.Wfrag = g_dbg_scratch;
+  if (skip) {
+    void* w2 = static_cast<char*>(g_dbg_scratch) + n1;
+    if (int rc = launch_stream_repack(p.Ws, w2, p.Npad, 1, p.SK0 + p.SK1, dtype, st)) return rc;
+    p.Wsfrag = w2;
+  }
+  return K22_OK;
+}
+#define K22_DBG_FRAG(p) do { if (int rc_ = dbg_frag((p), dtype, reinterpret_cast<hipStream_t>(stream))) return rc_; } while (0)
+int k22_debug_set_stream_frag(const void* wfrag, const void* wsfrag) { g_dbg_wfrag = wfrag; g_dbg_wsfrag = wsfrag; return K22_OK; }
+int k22_debug_set_stream_scratch(void* scratch, size_t bytes) { g_dbg_scratch = scratch; g_dbg_scratch_bytes = scratch ? bytes : 0; return K22_OK; }
+size_t k22_stream_frag_bytes(int Npad, int taps, int Kc, int dtype) { return stream_frag_bytes(Npad, taps, Kc, dtype); }
+int k22_stream_repack(const void* W, void* out, int Npad, int taps, int Kc, int dtype, void* stream) {
+  return launch_stream_repack(W, out, Npad, taps, Kc, dtype, reinterpret_cast<hipStream_t>(stream));
+}
+
+long k22_debug_counter(const char* name) {
+  if (name && !strcmp(name, "stream_launches")) return stream_launch_count();
+  return -1;
+}
+
 // ---- multi-GPU: the ONE collective of a job -------------------------------------------------------------
 // Broadcast of the packed weight arena from `root` over an RCCL communicator the caller owns (one process per GPU; prompts are
 // sharded by rank and nothing is exchanged in the step loop).  ncclBroadcast is resolved at call time from the RCCL that is
@@ -102,6 +147,7 @@ int k22_gemm(const void* A0, const void* A1, const void* Wp, const float* bias, 
   p.ldo = ldo; p.ldr = ldr; p.out_mode = out_f32 ? IG_OUT_ROWMAJOR_F32 : IG_OUT_ROWMAJOR; p.act = act;
   p.splitk = splitk; p.force_bm = bm; p.force_bn = bn;
   if (p.splitk == 0) p.splitk = partial ? igemm_choose_splitk(p, dtype) : 1;
+  K22_DBG_FRAG(p);
   return launch_igemm(p, dtype, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -115,6 +161,7 @@ int k22_conv3x3(const void* x_padded, const void* Wp, const float* bias, const v
   p.M = B * H * W; p.N = Cout; p.Npad = Npad; p.Kc = Cin; p.K0 = Cin; p.taps = 9; p.H = H; p.W = W;
   p.ldo = Cout; p.ldr = Cout; p.out_mode = out_mode; p.act = act; p.splitk = splitk; p.force_bm = bm; p.force_bn = bn;
   if (p.splitk == 0) p.splitk = partial ? igemm_choose_splitk(p, dtype) : 1;
+  K22_DBG_FRAG(p);
   return launch_igemm(p, dtype, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -134,6 +181,7 @@ int k22_conv3x3_gnstats(const void* x_padded, const void* Wp, const float* bias,
   if (rpi * B > stats_capacity_rows) return k22_set_error(K22_ENOMEM, "conv3x3_gnstats: stats buffer too small");
   p.stats = stats;
   p.gsum = (group_sums && p.N % 32 == 0) ? group_sums : nullptr;
+  K22_DBG_FRAG(p);
   return launch_igemm(p, dtype, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -145,13 +193,14 @@ int k22_gemm_gnstats(const void* A, const void* Wp, const float* bias, const voi
   p.A0 = A; p.Wp = Wp; p.bias = bias; p.residual = residual; p.out = out; p.partial = reinterpret_cast<float*>(partial);
   p.M = B * H * W; p.N = N; p.Npad = Npad; p.Kc = K; p.K0 = K; p.taps = 1; p.H = H; p.W = W; p.lda0 = K;
   p.ldo = N; p.ldr = N; p.out_mode = IG_OUT_ROWMAJOR; p.act = K22_ACT_NONE; p.splitk = splitk > 0 ? splitk : 1;
-  p.force_bm = bm; p.algo = 10;
+  p.force_bm = bm; p.algo = (bm == 160 || bm == 288) ? 20 : 10;
   const int rpi = igemm_stats_rows_per_image(p, dtype);
   if (rows_per_image) *rows_per_image = rpi;
   if (rpi <= 0) return k22_set_error(K22_EINVAL, "gemm_gnstats: this configuration cannot produce GroupNorm partial sums");
   if (rpi * B > stats_capacity_rows) return k22_set_error(K22_ENOMEM, "gemm_gnstats: stats buffer too small");
   p.stats = stats;
   p.gsum = (group_sums && p.N % 32 == 0) ? group_sums : nullptr;
+  K22_DBG_FRAG(p);
   return launch_igemm(p, dtype, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -165,6 +214,7 @@ int k22_conv3x3_skip(const void* x_padded, const void* Wp, const float* bias, co
   p.ldo = Cout; p.ldr = Cout; p.out_mode = IG_OUT_ROWMAJOR; p.act = K22_ACT_NONE; p.splitk = splitk; p.force_bm = bm; p.force_bn = 0;
   p.S0 = skip0; p.S1 = skip1; p.SK0 = SK0; p.SK1 = SK1; p.Ws = Ws; p.bias2 = bias_s; p.algo = 0;  /* "conv_algo" option 3 selects the 64-byte-row halo kernel */
   if (p.splitk == 0) p.splitk = partial ? igemm_choose_splitk(p, dtype) : 1;
+  K22_DBG_FRAG(p);
   return launch_igemm(p, dtype, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -241,6 +291,21 @@ int k22_qkv_project(const void* x, const void* Wp, const float* bias, void* q_ou
   p.M = B * T; p.N = 3 * C; p.Npad = 3 * C; p.Kc = K; p.K0 = K; p.taps = 1; p.lda0 = K; p.lda1 = 0;
   p.ldo = C; p.ldr = 3 * C; p.out_mode = IG_OUT_QKV; p.act = K22_ACT_NONE; p.splitk = 1; p.force_bm = bm; p.force_bn = bn;
   p.att_T = T; p.att_S = S; p.att_Tkp = Tkp; p.H = 1; p.W = T;   /* rows per image */
+  K22_DBG_FRAG(p);
+  return launch_igemm(p, dtype, reinterpret_cast<hipStream_t>(stream));
+}
+
+int k22_qkv_project_stream(const void* x, const void* Wp, const float* bias, void* q_out, void* kall, void* vtall, void* partial,
+                           int B, int H, int T, int S, int K, int bm, int splitk, int dtype, void* stream) {
+  const int C = H * 64, Tkp = (S + T + 63) / 64 * 64;
+  IgemmParams p = {};
+  p.stages = -1;
+  p.A0 = x; p.Wp = Wp; p.bias = bias; p.out = q_out; p.kall = kall; p.vtall = vtall; p.partial = reinterpret_cast<float*>(partial);
+  p.M = B * T; p.N = 3 * C; p.Npad = 3 * C; p.Kc = K; p.K0 = K; p.taps = 1; p.lda0 = K; p.lda1 = 0;
+  p.ldo = C; p.ldr = 3 * C; p.out_mode = IG_OUT_QKV; p.act = K22_ACT_NONE; p.splitk = splitk > 0 ? splitk : 1; p.force_bm = bm; p.algo = 20;
+  p.att_T = T; p.att_S = S; p.att_Tkp = Tkp; p.H = 1; p.W = T;
+  if (!stream_supported(p, dtype, bm == 288 ? 9 : 5)) return k22_set_error(K22_EINVAL, "qkv_project_stream: unsupported problem");
+  K22_DBG_FRAG(p);
   return launch_igemm(p, dtype, reinterpret_cast<hipStream_t>(stream));
 }
 

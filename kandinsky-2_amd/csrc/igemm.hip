@@ -329,6 +329,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmParams p)
         store4<T>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.ldo + n, v);
       } else if (p.out_mode == IG_OUT_ROWMAJOR_F32) {
         store4<float>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n, v);
+      } else if (p.out_mode == IG_OUT_QKV) {
+        // same destinations as igemm_kernel's epilogue: q row-major, k / v^T behind the context keys of the attention operands
+        const int C = p.N / 3, heads = C >> 6;
+        const int which = n / C, c = n - which * C;
+        const int head = c >> 6, d = c & 63;
+        const int b = m / p.att_T, t = m - b * p.att_T;
+        if (which == 0) {
+          store4<T>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.ldo + c, v);
+        } else if (which == 1) {
+          store4<T>(reinterpret_cast<T*>(p.kall) + ((int64_t)(b * heads + head) * p.att_Tkp + p.att_S + t) * 64 + d, v);
+        } else {
+          T* vt = reinterpret_cast<T*>(p.vtall) + ((int64_t)(b * heads + head) * 64 + d) * p.att_Tkp + p.att_S + t;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vt[(int64_t)e * p.att_Tkp] = from_f32<T>(v[e]);
+        }
       } else {
         const int hw = p.H * p.W;
         const int b = m / hw, rem = m - b * hw;
@@ -438,12 +453,12 @@ static int g_conv_algo = 0;
 void igemm_set_default_stages(int v) { g_stages_override = (v >= 2 && v <= 4) ? v : -1; }
 void igemm_set_xcd_remap(int v) { g_xcd_remap = v ? 1 : 0; }
 #ifdef K22_DEBUG_VARIANTS
-void igemm_set_conv_algo(int v) { g_conv_algo = ((v >= 0 && v <= 9) || (v >= 11 && v <= 14)) ? v : 0; }
+void igemm_set_conv_algo(int v) { g_conv_algo = ((v >= 0 && v <= 9) || (v >= 11 && v <= 14) || v == 20) ? v : 0; }
 #else   // 8, 9, 13, 14 are measurement-only kernels (wrong results): not reachable in a release build
-void igemm_set_conv_algo(int v) { g_conv_algo = ((v >= 0 && v <= 7) || v == 11 || v == 12) ? v : 0; }
+void igemm_set_conv_algo(int v) { g_conv_algo = ((v >= 0 && v <= 7) || v == 11 || v == 12 || v == 20) ? v : 0; }
 #endif
 static int g_gemm_algo = 0;   // 0 = generic igemm_kernel, 10 = gemm8_kernel where it applies (unit tests / kernel benches)
-void igemm_set_gemm_algo(int v) { g_gemm_algo = (v == 10) ? 10 : 0; }
+void igemm_set_gemm_algo(int v) { g_gemm_algo = (v == 10 || v == 20) ? v : 0; }
 
 static int g_default_stages() {
   static int v = -1;
@@ -463,8 +478,25 @@ static IgemmPlan igemm_plan(const IgemmParams& p, int dtype) {
   pl.halo = 0;
   pl.stages = (p.stages >= 2 && p.stages <= 4) ? p.stages : g_default_stages();
   auto blocks = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  // ---- weight-streaming small-M kernel (stream_gemm.hip): p.algo == 20 (tuner candidate) or the conv_algo / gemm_algo option --
+  if (p.algo == 20 || (p.algo == 0 && (p.taps == 9 ? g_conv_algo : g_gemm_algo) == 20)) {
+    const int mb = p.force_bm == 288 ? 9 : 5;
+    if (stream_supported(p, dtype, mb)) {
+      pl.halo = 20; pl.bm = mb * 32; pl.bn = 64;
+      const int nslab = p.Kc / 64;
+      if (p.splitk > 0) {
+        pl.splitk = p.splitk;
+      } else {
+        const int nb = stream_mtiles(p, mb);
+        pl.splitk = nb >= 240 ? 1 : 240 / nb;
+      }
+      if (pl.splitk > nslab) pl.splitk = nslab;
+      if (pl.splitk < 1) pl.splitk = 1;
+      return pl;
+    }
+  }
   // ---- 3x3 convolution: LDS-resident halo kernels when they apply (algo 2 = 128-byte rows, 3 = 64-byte rows) -----
-  const int algo = p.algo ? p.algo : g_conv_algo;
+  const int algo = (p.algo && p.algo != 20) ? p.algo : (g_conv_algo == 20 ? 0 : g_conv_algo);
   if (p.taps == 9 && algo != 1 && p.N >= 128) {
     IgemmParams ph = p;
     ph.algo = ((algo >= 3 && algo <= 9) || (algo >= 11 && algo <= 14)) ? algo : 2;
@@ -548,6 +580,12 @@ static bool reduce_rows_ok(const IgemmParams& p) {
 
 int igemm_stats_rows_per_image(const IgemmParams& p, int dtype) {
   const IgemmPlan pl = igemm_plan(p, dtype);
+  if (pl.halo == 20) {   // always finished by the row-tiled reduction
+    if (p.H <= 0 || p.out_mode == IG_OUT_QKV) return 0;
+    IgemmParams q = p;
+    q.stats = reinterpret_cast<float*>(1);
+    return reduce_rows_ok(q) ? p.H * p.W / 16 : 0;
+  }
   if (p.taps == 1) {
     if (pl.halo != 10 || p.H <= 0 || p.out_mode == IG_OUT_QKV) return 0;
     if (pl.splitk > 1) {
@@ -618,11 +656,24 @@ int launch_igemm(const IgemmParams& p, int dtype, hipStream_t stream) {
   if (p.Npad % 64 != 0 || p.Npad < p.N) return k22_set_error(K22_EINVAL, "igemm: Npad must be roundup(N,64)");
   if (p.K0 < p.Kc && p.A1 == nullptr) return k22_set_error(K22_EINVAL, "igemm: A1 missing for concat operand");
   if (p.out_mode == IG_OUT_QKV) {
-    if (p.taps != 1 || p.N % 192 || (p.ldo & 3) || !p.kall || !p.vtall || p.att_T <= 0 || p.M % p.att_T || p.residual || p.splitk > 1)
-      return k22_set_error(K22_EINVAL, "igemm: bad qkv-projection problem (N = 3*heads*64, no residual, no split-K)");
+    if (p.taps != 1 || p.N % 192 || (p.ldo & 3) || !p.kall || !p.vtall || p.att_T <= 0 || p.M % p.att_T || p.residual)
+      return k22_set_error(K22_EINVAL, "igemm: bad qkv-projection problem (N = 3*heads*64, no residual)");
   }
   IgemmPlan pl = igemm_plan(p, dtype);
-  if (p.out_mode == IG_OUT_QKV) pl.splitk = 1;
+  if (p.out_mode == IG_OUT_QKV && pl.halo != 20) {
+    if (p.splitk > 1) return k22_set_error(K22_EINVAL, "igemm: the qkv projection splits K only on the streaming kernel");
+    pl.splitk = 1;
+  }
+  if (pl.halo == 20) {
+    // weight-streaming kernel: fp32 partial tiles, then the common split-K finish (also for splitk == 1)
+    if (p.partial == nullptr) return k22_set_error(K22_EINVAL, "igemm: the streaming kernel needs the fp32 partial buffer");
+    IgemmParams q = p;
+    q.splitk = pl.splitk;
+    q.xcd_remap = g_xcd_remap;
+    int rc = launch_stream(q, dtype, pl.bm / 32, pl.splitk, stream);
+    if (rc) return rc;
+    return dtype == K22_BF16 ? launch_reduce<bf16_t>(q, stream) : (dtype == K22_F16 ? launch_reduce<f16_t>(q, stream) : launch_reduce<float>(q, stream));
+  }
   if (pl.splitk > 1 && p.partial == nullptr) pl.splitk = 1;
   if (p.res_f32 && pl.halo) return k22_set_error(K22_EINVAL, "igemm: fp32 residual is not supported by the halo kernel");
   if (p.S0 != nullptr && !pl.halo) return k22_set_error(K22_EINVAL, "igemm: the fused 1x1 skip connection needs the halo kernel");

@@ -74,6 +74,12 @@ struct IgemmParams {
   double* gsum;          // optional, with or without stats: per image and per GroupNorm group of the output tensor (32 groups
                          // of N/32 channels) the (sum, sumsq) of the STORED values, [B][32][2], ACCUMULATED with fp64 atomics
                          // (common.h: gn_add_group_sums; zero it before the launch); needs N % 32 == 0 and H, W set
+  // weight-streaming kernel (stream_gemm.hip): the weights again in FRAGMENT-MAJOR order - [n-block of 32 rows][(slab, tap) item][k quarter]
+  // [lane][8 elements] = 1 KB contiguous per MFMA B fragment - written once by launch_stream_repack (Wsfrag: the fused 1x1 skip's weights);
+  // null = fragments are gathered from the row-major Wp / Ws (32 bytes of 32 different lines per load: measured L1-lookup bound)
+  const void* Wfrag; const void* Wsfrag;
+  unsigned long long* st_trace;          // K22_STREAM_DEBUG builds only: 16 stamps per workgroup
+  int st_tm, st_rb, st_mtiles, st_buf;   // set by launch_stream (stream_gemm.hip): rows per m-tile, image rows per band, m-tiles, bytes of one LDS A buffer
 };
 
 // How a producer laid out its GroupNorm partial sums: image b owns rows [b*rows_per_image, (b+1)*rows_per_image).
@@ -92,6 +98,15 @@ int launch_conv3_halo_trace(const IgemmParams& p, int dtype, hipStream_t stream)
 bool gemm8_supported(const IgemmParams& p, int dtype, int bm);
 int gemm8_tiles_per_image(const IgemmParams& p, int bm);
 int launch_gemm8(const IgemmParams& p, int dtype, int bm, int splitk, hipStream_t stream);
+// stream_gemm.hip: weight-streaming kernel for small M (p.algo == 20; bm = 160 / 288 selects 5 / 9 m-blocks per workgroup).
+// It leaves fp32 partial tiles [splitk][M][N] in p.partial (also for splitk == 1); launch_igemm runs the split-K finish.
+bool stream_supported(const IgemmParams& p, int dtype, int mb);
+int stream_mtiles(const IgemmParams& p, int mb);
+int launch_stream(const IgemmParams& p, int dtype, int mb, int splitk, hipStream_t stream);
+long stream_launch_count();
+// bytes of the fragment-major copy of a [Npad][taps * Kc] weight matrix, and the one-time repack (any 16-bit dtype)
+size_t stream_frag_bytes(int Npad, int taps, int Kc, int dtype);
+int launch_stream_repack(const void* W, void* out, int Npad, int taps, int Kc, int dtype, hipStream_t stream);
 void igemm_set_gemm_algo(int v);
 void igemm_set_conv_algo(int v);       // tuning knob: 0 auto, 1 generic, 2 halo
 void igemm_set_default_stages(int v);  // tuning knob: 2..4 LDS-DMA stages, -1 env/default

@@ -147,6 +147,24 @@ inline void tuned_make_candidates(Tuned& t, int dtype) {
       }
     }
   }
+  // weight-streaming small-M kernel (stream_gemm.hip): 5 / 9 m-blocks per workgroup, 64-wide n-tiles, any split-K.  A candidate only
+  // when the owner of the weights made the fragment-major copy (the row-major form of the kernel never won a measurement) and for the 3x3
+  // convolutions (at taps == 1 gemm8 / igemm were faster on every GEMM of the UNet, profiles/r03_stream_kernel_v2.txt)
+  if (dtype != K22_F32 && p.Wfrag != nullptr && p.taps == 9) {
+    for (int mb : {5, 9}) {
+      IgemmParams q = p;
+      q.algo = 20; q.force_bm = mb * 32;
+      if (!stream_supported(q, dtype, mb)) continue;
+      const int nb = stream_mtiles(q, mb);
+      if (nb > 320) continue;
+      const int nslab = p.Kc / 64;
+      for (int sk : {1, 2, 3, 4, 5, 6, 8, 10, 12, 16}) {
+        if (sk > nslab || (sk > 1 && nb * sk > 320)) continue;
+        Cfg c; c.algo = 20; c.bm = mb * 32; c.bn = 0; c.splitk = sk; c.stages = 0;
+        all.push_back(c);
+      }
+    }
+  }
   const int tiles[3][2] = {{128, 128}, {128, 64}, {64, 64}};
   // GEMMs whose weights stream from HBM are latency bound per workgroup (one 8-16 KB tile per round trip with a
   // 2-deep ring): also try deeper rings
@@ -231,7 +249,7 @@ inline void tuned_default_cfg(Tuned& t, int dtype) {
 
 inline size_t tuned_max_splitk_bytes(const Tuned& t, bool autotune) {
   size_t m = 0;
-  auto upd = [&](const Cfg& c) { if (c.splitk > 1) m = std::max(m, (size_t)c.splitk * t.p.M * t.p.N * sizeof(float)); };
+  auto upd = [&](const Cfg& c) { if (c.splitk > 1 || c.algo == 20) m = std::max(m, (size_t)c.splitk * t.p.M * t.p.N * sizeof(float)); };
   upd(t.cfg);
   if (autotune) for (auto& c : t.cands) upd(c);
   return m;
