@@ -22,11 +22,13 @@ extern "C" {
 
 int k22_version(void) { return 100; }
 
+static bool g_gn_fused_test = false;
 int k22_set_option(const char* name, int value) {
   if (name && !strcmp(name, "igemm_stages")) { igemm_set_default_stages(value); return K22_OK; }
   if (name && !strcmp(name, "igemm_xcd_remap")) { igemm_set_xcd_remap(value); return K22_OK; }
   if (name && !strcmp(name, "conv_algo")) { igemm_set_conv_algo(value); return K22_OK; }
   if (name && !strcmp(name, "gemm_algo")) { igemm_set_gemm_algo(value); return K22_OK; }
+  if (name && !strcmp(name, "gn_fused")) { g_gn_fused_test = value != 0; return K22_OK; }   // k22_groupnorm (test entry) only: 0 = gn_coeff + gn_apply
   return k22_set_error(K22_EINVAL, "k22_set_option: unknown option");
 }
 const char* k22_last_error(void) { return g_err; }
@@ -167,7 +169,7 @@ int k22_conv3x3(const void* x_padded, const void* Wp, const float* bias, const v
 
 int k22_conv3x3_gnstats(const void* x_padded, const void* Wp, const float* bias, const void* residual, void* out,
                         void* partial, int B, int H, int W, int Cin, int Cout, int Npad, int splitk, int bm, int bn,
-                        float* stats, int stats_capacity_rows, int* rows_per_image, double* group_sums, int dtype, void* stream) {
+                        float* stats, int stats_capacity_rows, int* rows_per_image, long long* group_sums, int dtype, void* stream) {
   IgemmParams p = {};
   p.stages = -1;
   p.A0 = x_padded; p.Wp = Wp; p.bias = bias; p.residual = residual; p.out = out;
@@ -187,7 +189,7 @@ int k22_conv3x3_gnstats(const void* x_padded, const void* Wp, const float* bias,
 
 int k22_gemm_gnstats(const void* A, const void* Wp, const float* bias, const void* residual, void* out, void* partial,
                      int B, int H, int W, int N, int Npad, int K, int splitk, int bm, float* stats,
-                     int stats_capacity_rows, int* rows_per_image, double* group_sums, int dtype, void* stream) {
+                     int stats_capacity_rows, int* rows_per_image, long long* group_sums, int dtype, void* stream) {
   IgemmParams p = {};
   p.stages = -1;
   p.A0 = A; p.Wp = Wp; p.bias = bias; p.residual = residual; p.out = out; p.partial = reinterpret_cast<float*>(partial);
@@ -248,15 +250,16 @@ int k22_groupnorm(const void* x0, const void* x1, int C0, int C1, int B, int H, 
   cp.src[0].st = partial; cp.src[0].rpi = nsplit; cp.src[0].C = C; cp.src[1].st = nullptr; cp.src[1].rpi = 0; cp.src[1].C = 0;
   cp.HW = HW; cp.C = C; cp.groups = 32; cp.eps = eps; cp.gamma = gamma; cp.beta = beta;
   cp.film = film; cp.film_ld = film_ld; cp.coeff = coeff;
-  rc = launch_gn_coeff(cp, B, st);
-  if (rc) return rc;
   GnApplyParams ap;
   ap.x0 = x0; ap.x1 = x1; ap.C0 = C0; ap.C1 = C1; ap.B = B; ap.H = H; ap.W = W; ap.mode = mode; ap.pad = pad; ap.act = act;
   ap.coeff = coeff; ap.out = out;
+  if (g_gn_fused_test && gn_fused_supported(C, C0, dtype)) return launch_gn_fused(cp, ap, dtype, st);   // coefficients + apply in one launch
+  rc = launch_gn_coeff(cp, B, st);
+  if (rc) return rc;
   return launch_gn_apply(ap, dtype, st);
 }
 
-int k22_groupnorm_from_group_sums(const void* x, int C, int B, int H, int W, const double* group_sums, const float* gamma,
+int k22_groupnorm_from_group_sums(const void* x, int C, int B, int H, int W, const long long* group_sums, const float* gamma,
                                   const float* beta, const float* film, long film_ld, float eps, int act, int mode, int pad,
                                   void* out, int dtype, void* stream) {
   GnApply3Params q = {};

@@ -78,6 +78,21 @@ struct K22UNet {
   int autotune = 1;
   int fuse_skip = 1;
   int gn_onepass = 0;
+  int gn_fused = 0;
+  // weight-streaming kernel (stream_gemm.hip) for the small-M 3x3 convolutions: fragment-major copies of their weights live in the
+  // workspace (one more copy of those weights: ~1.2 GB of the 2.1 UNet in bf16), written once per bind before the first forward
+  int stream_frag = 1;
+  struct FragJob { const void* W; Slot* slot; int Npad, taps, Kc; };
+  std::vector<FragJob> frag_jobs;
+  bool frag_done = false;
+  int repack_frags(hipStream_t st) {
+    for (auto& j : frag_jobs) {
+      int rc = launch_stream_repack(j.W, ptr(j.slot), j.Npad, j.taps, j.Kc, dtype, st);
+      if (rc) return rc;
+    }
+    frag_done = true;
+    return K22_OK;
+  }
   size_t ws_bytes = 0;
   char* ws = nullptr;
   bool cond_set = false;
@@ -106,7 +121,7 @@ struct K22UNet {
   // (s_gsum) that a single memset clears at the start of a forward
   size_t gsum_bytes = 0;
   int64_t new_gsum() { const size_t off = gsum_bytes; gsum_bytes += ((size_t)B * 32 * 16 + 255) / 256 * 256; return (int64_t)off; }
-  double* gsum_at(int64_t off) const { return reinterpret_cast<double*>(ws + s_gsum->off + off); }
+  long long* gsum_at(int64_t off) const { return reinterpret_cast<long long*>(ws + s_gsum->off + off); }
   static void need(Slot* s, size_t bytes) { if (bytes > s->bytes) s->bytes = bytes; }
   template <typename T = char> T* ptr(const Slot* s) const { return reinterpret_cast<T*>(ws + s->off); }
 
@@ -164,6 +179,7 @@ struct K22UNet {
       }, OP_GN, 0.0, (double)Bn * HW * C * esz + (double)Bn * (Ho + 2 * pad) * (Wo + 2 * pad) * C * esz, 1));
         return;
     }
+    const bool one_launch = gn_fused && gn_fused_supported(C, a.C0, dtype);
     L.push_back(Op([=](hipStream_t st) {
       const void* x0 = ptr(a.s0);
       const void* x1 = a.s1 ? ptr(a.s1) : nullptr;
@@ -184,13 +200,14 @@ struct K22UNet {
       cp.gamma = gamma; cp.beta = beta;
       cp.film = film_off >= 0 ? ptr<float>(s_film) + film_off : nullptr; cp.film_ld = film_total;
       cp.coeff = ptr<float>(s_coeff);
-      int rc = launch_gn_coeff(cp, Bn, st);
-      if (rc) return rc;
       GnApplyParams ap;
       ap.x0 = x0; ap.x1 = x1; ap.C0 = a.C0; ap.C1 = a.C1; ap.B = Bn; ap.H = a.H; ap.W = a.W;
       ap.mode = mode; ap.pad = pad; ap.act = act; ap.coeff = ptr<float>(s_coeff); ap.out = ptr(dst);
+      if (one_launch) return launch_gn_fused(cp, ap, dt, st);   // coefficients + apply in one launch (elementwise.hip: gn_fused_kernel)
+      int rc = launch_gn_coeff(cp, Bn, st);
+      if (rc) return rc;
       return launch_gn_apply(ap, dt, st);
-    }, OP_GN, 0.0, gn_bytes, fused ? 2 : 3));
+    }, OP_GN, 0.0, gn_bytes, (fused ? 2 : 3) - (one_launch ? 1 : 0)));
   }
 
   static void apply_cfg(IgemmParams& q, const Cfg& c) { tuned_apply_cfg(q, c); }
@@ -221,6 +238,20 @@ struct K22UNet {
       p.Ws = W_(skip_pfx + ".weight"); p.bias2 = Wf(skip_pfx + ".bias");
     }
     t->want_stats = stats != nullptr;
+    // small M (the 24x24 / 12x12 levels): the weight-streaming kernel becomes a candidate, fed from a fragment-major copy of the weights
+    Slot *wf = nullptr, *wsf = nullptr;
+    if (stream_frag && dtype != K22_F32 && p.M <= 1152 && (stream_supported(p, dtype, 5) || stream_supported(p, dtype, 9))) {
+      wf = new_slot();
+      need(wf, stream_frag_bytes(p.Npad, 9, Cin, dtype));
+      frag_jobs.push_back({p.Wp, wf, p.Npad, 9, Cin});
+      p.Wfrag = reinterpret_cast<const void*>(1);          // marker for the candidate list; the device pointer is set at launch
+      if (skip_in) {
+        wsf = new_slot();
+        need(wsf, stream_frag_bytes(p.Npad, 1, p.SK0 + p.SK1, dtype));
+        frag_jobs.push_back({p.Ws, wsf, p.Npad, 1, p.SK0 + p.SK1});
+        p.Wsfrag = reinterpret_cast<const void*>(1);
+      }
+    }
     make_candidates(*t);
     default_cfg(*t);
     need(s_splitk, max_splitk_bytes(*t));
@@ -237,6 +268,7 @@ struct K22UNet {
       q.stats = t->want_stats ? ptr<float>(stats) : nullptr;
       q.gsum = gs >= 0 ? gsum_at(gs) : nullptr;
       if (q.S0) { q.S0 = ptr(sk.s0); q.S1 = sk.s1 ? ptr(sk.s1) : nullptr; }
+      q.Wfrag = wf ? ptr(wf) : nullptr; q.Wsfrag = wsf ? ptr(wsf) : nullptr;
       return launch_igemm(q, dt, st);
     };
     const double fl = 2.0 * p.M * (double)p.N * 9.0 * p.Kc;
@@ -395,7 +427,7 @@ struct K22UNet {
     if (nH % (1 << n_down) || nW % (1 << n_down)) return k22_set_error(K22_EINVAL, "unet: H, W must be divisible by 2^(levels-1)");
     if (nB > 8) return k22_set_error(K22_EINVAL, "unet: batch (2*bs) must be <= 8 per engine call");
     B = nB; H = nH; W = nW;
-    slots.clear(); ops.clear(); cond_ops.clear(); hint_ops.clear(); s_ctxkv.clear(); gsum_bytes = 0; n_attn = 0; err.clear();
+    slots.clear(); ops.clear(); cond_ops.clear(); hint_ops.clear(); s_ctxkv.clear(); gsum_bytes = 0; frag_jobs.clear(); frag_done = false; n_attn = 0; err.clear();
     tuned.clear(); tuned_done = false;
     ws = nullptr; cond_set = false; hint_set = false;
     if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
@@ -708,6 +740,13 @@ int k22_unet_create(const K22UNetConfig* cfg, const K22Weight* weights, int n_we
     // re-deriving the coefficients in every thread costs more than the coefficient kernel it removes.  Off by default.
     const char* gf = getenv("K22_GN_ONEPASS");
     u->gn_onepass = gf ? (atoi(gf) != 0) : 0;
+    // 1 = GroupNorm coefficients + apply in one launch per GroupNorm (gn_fused_kernel).  Measured (profiles/r03_groupnorm_one_launch_
+    // negative.txt): 1.57 ms against 1.21 ms for gn_coeff + gn_apply on the same box - a dependent phase inside a kernel costs what a
+    // dependent launch costs here, and the large levels lose the load / store overlap of a many-workgroup apply pass.  Off by default.
+    const char* g1 = getenv("K22_GN_FUSED");
+    u->gn_fused = g1 ? (atoi(g1) != 0) : 0;
+    const char* sf = getenv("K22_STREAM");   // 0 = no fragment-major weight copies, no weight-streaming kernel
+    u->stream_frag = sf ? (atoi(sf) != 0) : 1;
     const char* f = getenv("K22_FUSE_SKIP");  // 0 = 1x1 skip connections as separate GEMMs
     u->fuse_skip = f ? (atoi(f) != 0) : 1;
   }
@@ -732,7 +771,7 @@ int k22_unet_bind(K22UNet* u, void* workspace, size_t workspace_bytes) {
   if (workspace_bytes < u->ws_bytes) return k22_set_error(K22_ENOMEM, "unet_bind: workspace too small");
   if ((uintptr_t)workspace % 256) return k22_set_error(K22_EINVAL, "unet_bind: workspace must be 256-byte aligned");
   u->ws = reinterpret_cast<char*>(workspace);
-  u->cond_set = false; u->hint_set = false;
+  u->cond_set = false; u->hint_set = false; u->frag_done = false;
   if (u->graph_exec) { (void)hipGraphExecDestroy(u->graph_exec); u->graph_exec = nullptr; }
   if (u->loop_exec) { (void)hipGraphExecDestroy(u->loop_exec); u->loop_exec = nullptr; }
   return K22_OK;
@@ -789,6 +828,7 @@ int k22_unet_forward(K22UNet* u, const float* x, const float* timesteps, const f
     K22_CPY(u->ptr(u->s_img), inpaint_image, (size_t)u->B * 4 * hw * 4);
     K22_CPY(u->ptr(u->s_mask), inpaint_mask, (size_t)u->B * hw * 4);
   }
+  if (!u->frag_done) { int rc = u->repack_frags(st); if (rc) return rc; }
   if (u->autotune && !u->tuned_done) {
     // first forward on this plan: conv / GEMM problems the tile table does not know are measured on the device
     int rc = u->tune_all(st);
@@ -848,6 +888,7 @@ int k22_unet_sample_loop(K22UNet* u, float* x, float* x_tmp, const float* timest
   if (pct_index >= 4 * HW) return k22_set_error(K22_EINVAL, "unet_sample_loop: percentile index out of range");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipError_t e;
+  if (!u->frag_done) { int rc = u->repack_frags(st); if (rc) return rc; }
   if (u->autotune && !u->tuned_done) {
     int rc = u->tune_all(st);
     if (rc) return rc;

@@ -13,7 +13,23 @@ import sys
 import time
 
 ENC_ONLY = "--encoders-only" in sys.argv     # keep the shipped table and add only the conditioning-tower shapes to it
-if not ENC_ONLY:
+SMALL_CONV = "--small-conv" in sys.argv      # keep the shipped table except the 16-bit 3x3 convolutions with M <= 1152 rows: re-measured here
+                                             # (the weight-streaming kernel joined their candidate list)
+if SMALL_CONV:
+    _here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _src = os.path.join(_here, "kandinsky-2_amd", "tiles_gfx950.txt")
+    _tmp = "/tmp/k22_tiles_without_small_conv.txt"
+    with open(_src) as f, open(_tmp, "w") as g:
+        kept = dropped = 0
+        for line in f:
+            v = line.split()
+            if line.startswith("#") or len(v) < 4 or not (v[0] == "0" and v[1] == "9" and int(v[2]) <= 1152):
+                g.write(line); kept += 1
+            else:
+                dropped += 1
+    print(f"--small-conv: {kept} table lines kept, {dropped} dropped for re-measurement")
+    os.environ["K22_TILE_TABLE"] = _tmp
+elif not ENC_ONLY:
     os.environ["K22_TILE_TABLE"] = "0"      # start empty: everything below is measured here
 os.environ.setdefault("K22_TUNE_REPS", "7")
 os.environ.pop("K22_TUNE_CACHE", None)
@@ -142,6 +158,20 @@ def main():
         print(f"{n0} shipped + {n - n0} new = {n} entries -> {out}")
         return
     tiny = k22.tiny_model_config()
+    if SMALL_CONV:
+        b16 = (torch.bfloat16,)
+        unet(tiny, False, [(2, 16, 16), (4, 8, 24), (4, 16, 16)], dtypes=b16)
+        unet(tiny, True, [(4, 16, 24), (2, 16, 16), (4, 16, 16)], dtypes=b16)
+        t22 = k22.tiny_unet22_config()
+        unet22(t22, False, [(4, 16, 24), (4, 16, 16)], dtypes=b16)
+        unet22(t22, True, [(4, 16, 24), (4, 16, 16)], dtypes=b16)
+        unet(k22.MODEL_CONFIG_2_1, False, [(2, 32, 32), (2, 96, 96), (2, 64, 64), (4, 96, 96), (8, 96, 96), (2, 128, 128), (8, 128, 128)], dtypes=b16)
+        unet(k22.MODEL_CONFIG_2_1, True, [(8, 96, 96), (2, 96, 96)], dtypes=b16)
+        unet22(k22.UNET_CONFIG_2_2, False, [(2, 96, 96), (2, 32, 32)], dtypes=b16)
+        unet22(k22.UNET_CONFIG_2_2, True, [(4, 96, 96)], dtypes=b16)
+        n = _lib.lib().k22_tile_table_save(out.encode())
+        print(f"{n} entries -> {out}")
+        return
     # smoke() / parity-test shapes of the 1/3-width model
     unet(tiny, False, [(2, 16, 16), (4, 8, 24), (4, 16, 16)])
     unet(tiny, True, [(4, 16, 24), (2, 16, 16), (4, 16, 16)])
