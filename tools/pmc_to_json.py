@@ -17,7 +17,7 @@ src, rnd = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "r02")
 fetch = write = 0.0
 calls = 0
 for line in open(src):
-    if "conv3_halo" not in line or "kernel<" not in line:
+    if not (("conv3_halo" in line and "kernel<" in line) or "stream_kernel<" in line):   # the 3x3-convolution launches of a forward
         continue
     m = re.match(r"(.{60})\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)", line)
     if not m:
@@ -30,8 +30,8 @@ launches_per_forward = 72
 forwards = calls / launches_per_forward
 out = {
     "round": rnd,
-    "source": f"{src} (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, python bench.py --steps 3 --warmup 1: {calls} conv3_halo launches = {forwards:.1f} forwards)",
-    "kernel": "conv3_halo_kernel (all instantiations)",
+    "source": f"{src} (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, python bench.py --steps 3 --warmup 1: {calls} 3x3-convolution launches = {forwards:.1f} forwards)",
+    "kernel": "conv3_halo_kernel / conv3_halo_spec_kernel / stream_kernel (all instantiations: the 72 3x3-convolution launches of a forward)",
     "launches_per_step": float(launches_per_forward),
     "fetch_bytes_per_step": fetch * 1024 * 2 / forwards,
     "write_bytes_per_step": write * 1024 / forwards,
