@@ -367,7 +367,8 @@ def e2e_pass(a, arch, sd, dev, tdt, dist_on, world):
             "phases_ms": {"prior_25_steps": round(prior_ms, 2), "movq_decode_uint8": round(movq_ms, 2),
                           "denoise_and_host": round(per_image_ms - prior_ms - movq_ms, 2)},
             "what": f"Kandinsky2_1HIP.generate_text2img, {a.size}x{a.size}, bs {a.bs}/GPU, prior_steps 25, num_steps {a.sched_steps}, p_sampler, "
-                    f"{a.dtype} engines, seeded random weights + stand-in conditioning embeddings (tokenizers / text encoders are not in the timed chain)"}
+                    f"{a.dtype} engines, MoVQ decode in {str(pipe.movq_dtype).replace('torch.', '')}{' (the reference under use_fp16 decodes in half too)' if pipe.movq_dtype != torch.float32 else ''}, "
+                    f"seeded random weights + stand-in conditioning embeddings (tokenizers / text encoders are not in the timed chain)"}
 
 
 def parity_paths(m_timed, arch, sd, a, dev):

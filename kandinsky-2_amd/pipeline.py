@@ -171,7 +171,7 @@ class Kandinsky2_1HIP:
 
     def __init__(self, config, model_path, prior_path, device="cuda", task_type="text2img", *, conditioner=None,
                  backend_dtype: torch.dtype = torch.bfloat16, use_graph: bool = True, whole_loop_graph: Optional[bool] = None,
-                 movq_dtype: Optional[torch.dtype] = torch.float32):
+                 movq_dtype: Optional[torch.dtype] = None):
         if task_type not in ("text2img", "inpainting"):
             raise ValueError("Only text2img and inpainting is available")
         if torch.device(device).type != "cuda":
@@ -214,10 +214,12 @@ class Kandinsky2_1HIP:
             raise NotImplementedError("only the MOVQ image encoder of Kandinsky 2.1")
         self.use_image_enc, self.scale = True, ie["scale"]
         movq_sd = _load(ie["ckpt_path"])
-        # MoVQ runs once per image (17 ms in bf16 / fp16, 56 ms in fp32 at 768 px, against ~360 ms of denoising) and its output IS the
-        # picture: by default it computes in fp32, where the uint8 image is within ONE grey level of the reference's (bf16 moves pixels by
-        # up to 32 levels, fp16 by up to 5 on the 768-px reference fixture; tests/test_movq_gpu.py).  movq_dtype=None: follow backend_dtype.
-        self.movq_dtype = backend_dtype if movq_dtype is None else movq_dtype
+        # MoVQ runs once per image and its output IS the picture.  movq_dtype=None (default) follows the engines' precision the way the reference
+        # does (kandinsky2_1_model.py:92-94, 287-288: under use_fp16 the image encoder is .half() and decodes half latents): fp32 engines (the
+        # parity path) decode in fp32 - uint8 image within ONE grey level of the reference's fp32 decode; 16-bit engines (the product path) decode
+        # in fp16 - within 3 grey levels, 88 % of the bytes identical, at 12 ms instead of 53 (bf16 would move pixels by up to 24 levels, which
+        # is why a bf16 UNet still gets an fp16 MoVQ; tests/test_movq_gpu.py, profiles/r03_movq_precision.txt).
+        self.movq_dtype = (torch.float32 if backend_dtype == torch.float32 else torch.float16) if movq_dtype is None else movq_dtype
         self.image_encoder = _MoVQ(ie["params"], movq_sd, self.movq_dtype, device)
 
         self.model = Text2ImUNetHIP(make_arch(mcfg, inpainting=mcfg["inpainting"]), backend_dtype=backend_dtype, use_graph=use_graph,
@@ -440,7 +442,7 @@ def _conditioner_from_cache_dir(cache_dir, device, backend_dtype):
 
 def get_kandinsky2(device, task_type="text2img", cache_dir="/tmp/kandinsky2", use_auth_token=None, model_version="2.1",
                    use_flash_attention=False, *, conditioner=None, backend_dtype: torch.dtype = torch.bfloat16, use_graph: bool = True,
-                   movq_dtype: Optional[torch.dtype] = torch.float32):
+                   movq_dtype: Optional[torch.dtype] = None):
     """`get_kandinsky2` (kandinsky2/__init__.py:164-192) for the HIP engines.  The reference downloads the checkpoints into
     cache_dir (kandinsky2/__init__.py:100-160); this box-local variant reads the same file names from cache_dir and raises if
     they are not there (there is no download path).  use_flash_attention is accepted and ignored: attention always runs in the

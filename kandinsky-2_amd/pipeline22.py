@@ -238,7 +238,7 @@ class Kandinsky2_2HIP:
 
     def __init__(self, device="cuda", task_type="text2img", *, unet_state_dict=None, movq_state_dict=None, conditioner=None,
                  cache_dir=None, backend_dtype: torch.dtype = torch.bfloat16, use_graph: bool = True, unet_config=None, controlnet=None,
-                 scheduler_config=None, movq_dtype: Optional[torch.dtype] = torch.float32):
+                 scheduler_config=None, movq_dtype: Optional[torch.dtype] = None):
         if task_type not in ("text2img", "img2img", "inpainting"):
             raise ValueError("Only text2img, img2img, inpainting is available")
         if (unet_state_dict is None or movq_state_dict is None) and cache_dir is not None:
@@ -271,7 +271,8 @@ class Kandinsky2_2HIP:
         self.unet = UNet2DConditionHIP(arch, backend_dtype=backend_dtype, use_graph=use_graph)
         self.unet.load_state_dict(unet_state_dict)
         self.unet = self.unet.to(device).eval()
-        mdt = backend_dtype if movq_dtype is None else movq_dtype      # fp32 by default: the uint8 image within one grey level (pipeline.py)
+        # None: fp32 engines decode in fp32, 16-bit engines in fp16 (pipeline.py: within one / three grey levels of the fp32 decode)
+        mdt = (torch.float32 if backend_dtype == torch.float32 else torch.float16) if movq_dtype is None else movq_dtype
         movq = MoVQDecoderHIP(backend_dtype=mdt)
         movq.load_state_dict(movq_state_dict, strict=True)          # decoder keys; a full MOVQ checkpoint's other keys are skipped
         movq = movq.to(device)

@@ -83,6 +83,19 @@ def test_movq_decode_real_sizes_vs_reference_golden(golden_dir, name, backend, t
     assert torch.equal(u8, movq_ref.process_images_u8(out))
     if backend == torch.float32:
         assert du8.max().item() <= 1
+    if backend == torch.float16:
+        # the drivers decode in fp16 beside 16-bit UNets, as the reference does under use_fp16 (kandinsky2_1_model.py:92-94, 287-288).  Yardstick:
+        # the REFERENCE'S OWN MOVQ.half() decode of this very latent against its fp32 decode (oracle/ref_movq_half_drift.py, CPU): the engine
+        # must be at least as close to the fp32 reference image as that
+        import json
+        yp = os.path.join(golden_dir, "ref_movq_half_drift.json")
+        if os.path.exists(yp):
+            y = json.load(open(yp))["cases"][name]
+            frac = (du8 > 0).float().mean().item()
+            print(f"{name}: reference's own half decode: {y['rel']:.3e} of scale, uint8 max diff {y['uint8_max_diff']}, {100 * y['uint8_frac_differ']:.3f} % differ; "
+                  f"fp16 engine: {err / scale:.3e}, {du8.max().item()}, {100 * frac:.3f} %")
+            assert err / scale <= y["rel"] and du8.max().item() <= y["uint8_max_diff"] and frac <= y["uint8_frac_differ"]
+            assert du8.max().item() <= 3 and (du8 > 1).float().mean().item() <= 1e-3
 
 
 def test_movq_decode_is_deterministic_and_batch_independent(golden_dir):
