@@ -1,4 +1,10 @@
-"""Timeline of the weight-streaming kernel (K22_STREAM_DEBUG build, K22_STREAM_DBG=4): per-workgroup cycle stamps."""
+"""Timeline of the weight-streaming kernel: per-workgroup cycle stamps (prologue, every stage, fold + store) of one 3x3 convolution.
+
+Needs a library built with the measurement variants:  make -C kandinsky-2_amd/csrc clean all EXTRA=-DK22_STREAM_DEBUG   (rebuild without it
+afterwards).  K22_STREAM_DBG bits: 8 = stamps (default here), +1 no MFMA, +2 weight ring never refilled, +4 one LDS read per phase.
+
+    python tools/stream_trace.py Cin Cout H splitk [bm]        e.g.  1536 1536 12 5
+"""
 import ctypes as C
 import os
 import sys
