@@ -429,6 +429,40 @@ def test_shipped_tile_table_loads_and_round_trips(tmp_path):
         L.k22_tile_table_load(_lib.TILE_TABLE_PATH.encode())
 
 
+def test_shipped_tile_table_names_the_streaming_kernel_only_where_an_engine_can_run_it():
+    """Table columns: dtype taps M N Kc K0 H W outmode stats | algo bm bn splitk stages | us.  algo 20 = stream_kernel (csrc/stream_gemm.hip): the
+    engine lists it as a candidate only for 16-bit 3x3 convolutions of at most 1152 rows whose weights it holds fragment-major (engine.hip op_conv,
+    tuning.h), with 160- or 288-row tiles, K a multiple of 64 and at most 256 workgroups' worth of split-K.  A line outside that envelope would be
+    ignored at load (tuned_is_candidate) and silently re-measured on every start - i.e. the table would no longer fix the bits."""
+    rows = [l.split() for l in open(_lib.TILE_TABLE_PATH).read().splitlines() if l and not l.startswith("#")]
+    stream = [r for r in rows if r[10] == "20"]
+    assert len(stream) >= 16, "the C2 12x12 level runs the weight-streaming kernel"
+    for r in stream:
+        dtype, taps, M, N, Kc = int(r[0]), int(r[1]), int(r[2]), int(r[3]), int(r[4])
+        bm, bn, splitk = int(r[11]), int(r[12]), int(r[13])
+        assert dtype == 0 and taps == 9 and M <= 1152 and Kc % 64 == 0 and N % 4 == 0, r
+        assert bm in (160, 288) and bn == 0 and 1 <= splitk <= Kc // 64, r
+    # the C2 bench shape: both 1536 -> 1536 convolutions of the 12x12 level (with and without the fused 1x1 skip) are among them
+    assert any(r[2] == "288" and r[3] == "1536" and r[4] == "1536" and r[5] == "1536" for r in stream)
+
+
+def test_fragment_major_weight_layout_formula():
+    """k22_stream_repack's documented permutation (include/k22.h, csrc/stream_gemm.hip), restated on the host: element e of lane l of k quarter w of
+    item (slab, tap) of n-block nb is W[nb * 32 + l % 32][tap * Kc + slab * 64 + 16 w + 8 (l / 32) + e] - i.e. exactly the 16 bytes that lane feeds
+    to v_mfma_f32_32x32x16 (B operand: column = lane % 32, k = 8 (lane / 32) + e within the wave's 16-wide k step).  The GPU test
+    (tests/test_stream_gpu.py::test_repack_is_the_documented_permutation) checks the kernel against the same tensor expression."""
+    Npad, taps, Kc = 64, 9, 128
+    W = torch.arange(Npad * taps * Kc).reshape(Npad, taps * Kc)
+    frag = W.reshape(Npad // 32, 32, taps, Kc // 64, 4, 2, 8).permute(0, 3, 2, 4, 5, 1, 6).reshape(-1)     # nb, slab, tap, w, half, row, e
+    n_items = (Kc // 64) * taps
+    for nb, slab, tap, w, lane, e in [(0, 0, 0, 0, 0, 0), (1, 1, 8, 3, 63, 7), (0, 1, 4, 2, 37, 5), (1, 0, 2, 1, 31, 3)]:
+        it = slab * taps + tap
+        idx = (((nb * n_items + it) * 4 + w) * 64 + lane) * 8 + e
+        assert frag[idx].item() == W[nb * 32 + lane % 32, tap * Kc + slab * 64 + 16 * w + 8 * (lane // 32) + e].item()
+    assert _lib.lib().k22_stream_frag_bytes(Npad, taps, Kc, _lib.K22_BF16) == Npad * taps * Kc * 2
+    assert _lib.lib().k22_stream_frag_bytes(Npad, taps, Kc, _lib.K22_F32) == 0          # 16-bit kernel
+
+
 # ---- the oracle at the FULL shapes of the bench (the fixtures the -m gpu parity tests of tests/test_full_size_gpu.py use) ---------
 def test_oracle_c2_first_forward_matches_reference_golden(golden_dir):
     """C2 (768x768 bs 1 -> CFG batch 2x4x96x96, 1.23 B parameters): the restatement against the reference create_model(...)'s
