@@ -77,19 +77,29 @@ __device__ __forceinline__ void hist_add_aggregated(int* hist, bool valid, uint3
 // iterations of each pass a dependent L2 round trip: 71 us per step at 96x96 for one workgroup's worth of arithmetic.)
 // KPT == 0: generic path for n > 64 * blockDim.x (keys re-read from memory in every pass).
 // Key 0xffffffff marks "no element" (never a valid |x| bit pattern below NaN; the latent is finite).
+// THREE passes over digits of 11 + 11 + 10 bits (2048-bin histogram) instead of four over bytes.  |x0| after the clamp lives in a handful of
+// binades: with 8-bit digits the first pass left half of all keys in one bin (sign + 7 exponent bits: everything in [0.5, 2) shares 0x3f); an
+// 11-bit first digit (sign, exponent, two mantissa bits) leaves < 10 % of the keys valid for passes two and three, where a key costs one
+// ballot.  Measured: the step's three kernels 76 -> 73 us at 96x96 - the FIRST pass (every key through the ballot-aggregated histogram add,
+// 36 keys x 16 waves on one CU) is what the 60 us are, whatever the digit plan; the lever that is left is spreading that pass over more CUs.
+constexpr int K22_RS_BINS = 2048;
 template <int KPT>
 __device__ __forceinline__ uint32_t radix_select(const float* v, const uint32_t* keys, int n, int k, int* hist, uint32_t* bc) {
   const int tid = threadIdx.x;
   uint32_t prefix = 0, mask = 0;
-  for (int shift = 24; shift >= 0; shift -= 8) {
-    for (int i = tid; i < 256; i += blockDim.x) hist[i] = 0;
+#pragma unroll 1
+  for (int pass = 0; pass < 3; ++pass) {
+    const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
+    const int nb = pass == 2 ? 1024 : 2048;
+    const uint32_t dmask = (uint32_t)(nb - 1);
+    for (int i = tid; i < K22_RS_BINS; i += blockDim.x) hist[i] = 0;
     __syncthreads();
     if constexpr (KPT > 0) {
 #pragma unroll
       for (int j = 0; j < KPT; ++j) {
         const uint32_t key = keys[j];
         const bool valid = key != 0xffffffffu && (key & mask) == prefix;
-        hist_add_aggregated(hist, valid, (key >> shift) & 255);
+        hist_add_aggregated(hist, valid, (key >> shift) & dmask);
       }
     } else {
       for (int i0 = 0; i0 < n; i0 += blockDim.x) {
@@ -100,15 +110,15 @@ __device__ __forceinline__ uint32_t radix_select(const float* v, const uint32_t*
           key = __float_as_uint(fabsf(v[i]));
           valid = (key & mask) == prefix;
         }
-        hist_add_aggregated(hist, valid, (key >> shift) & 255);
+        hist_add_aggregated(hist, valid, (key >> shift) & dmask);
       }
     }
     __syncthreads();
     if (tid < 64) {
-      // wave 0: inclusive scan of the 256 bins (4 per lane), then locate the bin holding rank k
-      int c[4], run = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { run += hist[tid * 4 + j]; c[j] = run; }
+      // wave 0: lane l owns bins [l * per, (l + 1) * per); inclusive scan of the lane totals, then the owner of rank k walks its bins
+      const int per = nb >> 6;
+      int run = 0;
+      for (int j = 0; j < per; ++j) run += hist[tid * per + j];
       int incl = run;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
@@ -116,15 +126,18 @@ __device__ __forceinline__ uint32_t radix_select(const float* v, const uint32_t*
         if (tid >= o) incl += t;
       }
       const int excl = incl - run;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int lo = excl + (j ? c[j - 1] : 0), hi = excl + c[j];
-        if (k >= lo && k < hi) { bc[0] = (uint32_t)(tid * 4 + j); bc[1] = (uint32_t)(k - lo); }
+      if (k >= excl && k < incl) {      // exactly one lane: the valid keys number more than k
+        int acc = excl;
+        for (int j = 0; j < per; ++j) {
+          const int c = hist[tid * per + j];
+          if (k < acc + c) { bc[0] = (uint32_t)(tid * per + j); bc[1] = (uint32_t)(k - acc); break; }
+          acc += c;
+        }
       }
     }
     __syncthreads();
     prefix |= bc[0] << shift;
-    mask |= 255u << shift;
+    mask |= dmask << shift;
     k = (int)bc[1];
     __syncthreads();
   }
@@ -133,7 +146,7 @@ __device__ __forceinline__ uint32_t radix_select(const float* v, const uint32_t*
 
 template <int KPT>
 __global__ __launch_bounds__(1024) void sampler_threshold_kernel(SamplerParams p) {
-  __shared__ int hist[256];
+  __shared__ int hist[K22_RS_BINS];
   __shared__ uint32_t bc[2];
   __shared__ unsigned int succ_cnt[2];  // [0] = #keys <= a, [1] = min key > a
   const int n = 4 * p.HW;

@@ -231,7 +231,8 @@ def test_linear_smallm(wdtype):
     assert (out - ref).abs().max().item() < 1e-3
 
 
-@pytest.mark.parametrize("N,H,W,inpaint,step", [(2, 16, 16, False, 3), (4, 8, 12, True, 0), (2, 96, 96, False, 49), (8, 32, 32, True, 7)])
+@pytest.mark.parametrize("N,H,W,inpaint,step", [(2, 16, 16, False, 3), (4, 8, 12, True, 0), (2, 96, 96, False, 49), (8, 32, 32, True, 7),
+                                                 (2, 64, 64, False, 20), (2, 128, 128, False, 30), (2, 160, 176, False, 11)])   # radix select: 16 / 64 keys per thread, the generic path
 def test_sampler_step_matches_oracle(N, H, W, inpaint, step):
     steps = 50
     d = k22.create_gaussian_diffusion(**dict(k22.DIFFUSION_CONFIG_2_1, timestep_respacing=str(steps)))
