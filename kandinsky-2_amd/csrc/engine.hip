@@ -1000,6 +1000,7 @@ int k22_unet_profile(K22UNet* u, int reps, double* ms, double* flops, double* by
   if (!u || !u->ws || !u->cond_set) return k22_set_error(K22_EINVAL, "unet_profile: run k22_unet_forward once first");
   if (reps < 1) reps = 1;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!u->frag_done) { int rc0 = u->repack_frags(st); if (rc0) return rc0; }   // a profile before the first forward of this binding
   const size_t n = u->ops.size();
   std::vector<hipEvent_t> ev(2 * n);
   for (auto& e : ev) { hipError_t r = hipEventCreate(&e); if (r != hipSuccess) return k22_set_error_hip(r, __FILE__, __LINE__); }
