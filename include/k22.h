@@ -31,6 +31,13 @@ extern "C" {
 #define K22_F32 1  /* parity path : fp32 storage, v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain) */
 #define K22_F16 2  /* the reference's own reduced-precision mode (use_fp16 / convert_to_fp16, kandinsky2/model/unet.py:409, 566-572):
                       fp16 storage, v_mfma_f32_32x32x16_f16, fp32 accumulate - bf16's speed and bytes, 3 more mantissa bits */
+#define K22_F16X3 3 /* UNet engine only - SPLIT PRECISION, the arithmetic that holds BASELINE.json's 1e-3 final-latent gate against the
+                      reference p_sampler (kandinsky2/kandinsky2_1_model.py:245-257 -> kandinsky2/model/gaussian_diffusion.py:384-475) at
+                      16-bit MFMA rate: tensors stay fp32, every MFMA operand x is carried as the fp16 pair hi = rne(x), lo = rne(x - hi)
+                      and every product as three v_mfma_f32_32x32x16_f16 (hi.hi + hi.lo + lo.hi) into one fp32 accumulator: ~23
+                      significand bits per operand at 3/16 of the exact-fp32 MFMA cost.  Operand format ("x3 chunks"): 4 bytes per
+                      element, every aligned group of 4 consecutive K elements stored as [hi x4 | lo x4] fp16 (csrc/common.h);
+                      weights are packed so (pre-multiplied by 2^8) by pack.py / k22_x3_pack, activations by their producers. */
 
 int k22_version(void);
 const char* k22_last_error(void);
@@ -65,7 +72,7 @@ int k22_debug_set_stream_scratch(void* scratch, size_t bytes);
  * (kandinsky2/model/model_creation.py:9-83) / CONFIG_2_1["model_config"] (kandinsky2/configs.py:125-149).
  */
 typedef struct K22UNetConfig {
-  int dtype;               /* K22_BF16 | K22_F32 | K22_F16 */
+  int dtype;               /* K22_BF16 | K22_F32 | K22_F16 | K22_F16X3 */
   int in_channels;         /* 4; 9 for the inpainting UNet (x, image*mask, mask); 8 for the 2.2 ControlNet-depth UNet (x, hint latent) */
   int model_channels;      /* 384 */
   int out_channels;        /* 8 = eps + learned variance */
@@ -211,6 +218,13 @@ int k22_sampler_step(const float* x, const float* model_out, const float* noise,
 int k22_gemm(const void* A0, const void* A1, const void* Wp, const float* bias, const void* residual, void* out,
              void* partial, int M, int N, int Npad, int K0, int K1, long lda0, long lda1, int ldo, int ldr,
              int out_f32, int act, int splitk, int bm, int bn, int dtype, void* stream);
+/* fp32 -> x3 chunks (K22_F16X3 operand format): dst[n] (4 bytes per element) from src[n] * scale, n % 4 == 0, 16-byte aligned.
+ * scale = 256 for weights (what pack.py writes and the epilogues undo), 1 for activations.  With dtype == K22_F16X3 the kernel-level
+ * entries take: k22_gemm / k22_gemm_gnstats / k22_qkv_project - A as plain fp32 rows (split at fragment-read time), W in x3 chunks;
+ * k22_conv3x3* - x_padded AND W in x3 chunks (in the engine the GroupNorm-apply kernel writes the input so: k22_groupnorm with
+ * dtype == K22_F16X3 = fp32 in, x3 chunks out), the fused skip operands as plain fp32 rows; k22_attention - fp32 in and out.
+ * Outputs, residuals and biases are fp32. */
+int k22_x3_pack(const float* src, void* dst, long n, float scale, void* stream);
 int k22_conv3x3(const void* x_padded, const void* Wp, const float* bias, const void* residual, void* out,
                 void* partial, int B, int H, int W, int Cin, int Cout, int Npad, int out_mode, int act, int splitk,
                 int bm, int bn, int dtype, void* stream);

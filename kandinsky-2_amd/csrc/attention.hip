@@ -36,6 +36,19 @@ __device__ __forceinline__ void ld_frag_split(Frag<float>& f, const char* tile, 
   f.v[0] = lo.x; f.v[1] = lo.y; f.v[2] = lo.z; f.v[3] = lo.w;
   f.v[4] = hi.x; f.v[5] = hi.y; f.v[6] = hi.z; f.v[7] = hi.w;
 }
+// split precision: the LDS tiles hold x3 chunks (converted once per workgroup while staging: K22_ATT_LSTORE), P and Q are split in registers
+__device__ __forceinline__ void ld_frag_split(Frag<x3_t>& f, const char* tile, int r, int a, int h) {
+  const char* sub = tile + (a >> 1) * 8192;
+  const int al = a & 1;
+  x3_frag_from_chunks(f, *reinterpret_cast<const u32x4_t*>(sub + lds_chunk_off(r, 4 * al + h)),
+                      *reinterpret_cast<const u32x4_t*>(sub + lds_chunk_off(r, 4 * al + 2 + h)));
+}
+__device__ __forceinline__ void make_pfrag(Frag<x3_t>& f, const float* p) {
+  x3_frag_from_f32(f, make_float4(p[0], p[1], p[2], p[3]), make_float4(p[4], p[5], p[6], p[7]));
+}
+__device__ __forceinline__ void ld_qfrag(Frag<x3_t>& f, const x3_t* p) {
+  x3_frag_from_f32(f, *reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4));
+}
 __device__ __forceinline__ void make_pfrag(Frag<bf16_t>& f, const float* p) {
   f.v = u32x4_t{pack2_bf16(p[0], p[1]),
                 pack2_bf16(p[2], p[3]),
@@ -62,6 +75,7 @@ template <typename T> __device__ __forceinline__ float exp2_t(float x);
 template <> __device__ __forceinline__ float exp2_t<bf16_t>(float x) { return __builtin_amdgcn_exp2f(x); }
 template <> __device__ __forceinline__ float exp2_t<f16_t>(float x) { return __builtin_amdgcn_exp2f(x); }
 template <> __device__ __forceinline__ float exp2_t<float>(float x) { return exp2f(x); }
+template <> __device__ __forceinline__ float exp2_t<x3_t>(float x) { return exp2f(x); }
 
 // The online softmax is the issue-bound part of this kernel (measured at T = 2304: waves ISSUING 49 % of their cycles,
 // matrix pipe 18 % busy), so its instruction count is what matters:
@@ -124,8 +138,13 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttentionParams p) {
     _Pragma("unroll") for (int i = 0; i < LCH; ++i) {                                                    \
       const int q = tid + i * 256, row = q / CPR, cc = q - row * CPR;                                    \
       const int off = (cc >> 3) * 8192 + lds_chunk_off(row, cc & 7);                                     \
+      if constexpr (is_x3<T>::value) {   /* fp32 K / V^T rows -> x3 chunks, once per workgroup */           \
+        *reinterpret_cast<u32x4_t*>(Ks + off) = x3_split4(__builtin_bit_cast(float4, kreg[i]));           \
+        *reinterpret_cast<u32x4_t*>(Vs + off) = x3_split4(__builtin_bit_cast(float4, vreg[i]));           \
+      } else {                                                                                           \
       *reinterpret_cast<u32x4_t*>(Ks + off) = kreg[i];                                                   \
       *reinterpret_cast<u32x4_t*>(Vs + off) = vreg[i];                                                   \
+      }                                                                                                  \
     }                                                                                                    \
   }
 
@@ -227,6 +246,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttentionParams p) {
           w.x = pack2<T>(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
           w.y = pack2<T>(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
           *reinterpret_cast<uint2*>(orow + d) = w;
+        } else if (is_x3<T>::value && p.out_x3) {   // the proj_out GEMM reads this tensor as its A operand: x3 chunks
+          *reinterpret_cast<u32x4_t*>(orow + d) = x3_split4(o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
         } else {
           *reinterpret_cast<float4*>(orow + d) =
               make_float4(o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
@@ -241,6 +262,7 @@ int launch_attention(const AttentionParams& p, int dtype, hipStream_t s) {
   if (dtype == K22_BF16) hipLaunchKernelGGL(attention_kernel<bf16_t>, grid, dim3(256), 0, s, p);
   else if (dtype == K22_F16) hipLaunchKernelGGL(attention_kernel<f16_t>, grid, dim3(256), 0, s, p);
   else if (dtype == K22_F32) hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(256), 0, s, p);
+  else if (dtype == K22_F16X3) hipLaunchKernelGGL(attention_kernel<x3_t>, grid, dim3(256), 0, s, p);
   else return k22_set_error(K22_EINVAL, "attention: bad dtype");
   K22_CHECK_LAUNCH();
   return K22_OK;

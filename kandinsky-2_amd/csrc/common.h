@@ -19,11 +19,16 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
-enum K22DType { K22_BF16 = 0, K22_F32 = 1, K22_F16 = 2 };
+// K22_F16X3 (round 4, UNet engine only) = the SPLIT-PRECISION arithmetic: fp32 tensors, every MFMA operand x carried as the fp16 pair
+// hi = rne(x), lo = rne(x - hi) and every product as THREE v_mfma_f32_32x32x16_f16 (hi.hi + hi.lo + lo.hi, one fp32 accumulator):
+// ~23 significand bits per operand at 3/16 of the exact-fp32 MFMA cost.  See x3_t below.
+enum K22DType { K22_BF16 = 0, K22_F32 = 1, K22_F16 = 2, K22_F16X3 = 3 };
 // bytes per element / elements per 128-byte LDS row of a storage type code
-inline int k22_esz(int dtype) { return dtype == K22_F32 ? 4 : 2; }
-inline int k22_bk(int dtype) { return dtype == K22_F32 ? 32 : 64; }
+inline int k22_esz(int dtype) { return (dtype == K22_F32 || dtype == K22_F16X3) ? 4 : 2; }
+inline int k22_bk(int dtype) { return (dtype == K22_F32 || dtype == K22_F16X3) ? 32 : 64; }
 inline bool k22_dtype_ok(int dtype) { return dtype == K22_BF16 || dtype == K22_F32 || dtype == K22_F16; }
+// what the kernels that only move / normalise data are instantiated on for an engine of arithmetic type `dtype`
+inline int k22_storage_dtype(int dtype) { return dtype == K22_F16X3 ? (int)K22_F32 : dtype; }
 enum K22Act { K22_ACT_NONE = 0, K22_ACT_SILU = 1, K22_ACT_GELU = 2 };
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
@@ -71,6 +76,29 @@ __device__ __forceinline__ float apply_act(float x, int act) {
   return x;
 }
 
+// ---- split-precision operand format ("x3 chunk") ------------------------------------------------------------------------------
+// An MFMA operand tensor of the K22_F16X3 arithmetic occupies 4 bytes per element like fp32, but every aligned group of FOUR
+// consecutive K elements (16 bytes) is stored as [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] in fp16, hi = rne_f16(x), lo = rne_f16(x - hi)
+// (x - hi is exact in fp32).  fp16 subnormals are kept (the kernel mode never flushes them), so |x| >= 2^-2 is carried to 2^-23
+// relative and anything smaller to 2^-25 absolute.  A fragment of a 32x32x16 atom (8 consecutive K of one row) is two chunks:
+// two ds_read_b128, no conversion instruction.  WEIGHTS are packed in this format once (pack.py), pre-multiplied by the exact
+// power of two K22_X3_WSCALE so that their lo halves stay normal; the epilogues multiply the accumulators by 1 / K22_X3_WSCALE.
+// ACTIVATIONS are written in it by their producers (GroupNorm-apply, the attention epilogue) or converted from fp32 rows at
+// fragment-read time where the producer is not one of ours (`a_raw` operands: 1x1 skip connections, the conditioning GEMMs).
+struct x3_t { float f; };   // storage tag: sizeof == 4; as a STORED tensor type it behaves as float (epilogue outputs are fp32)
+constexpr float K22_X3_WSCALE = 256.0f;
+constexpr float K22_X3_WSCALE_INV = 1.0f / 256.0f;
+__device__ __forceinline__ u32x4_t x3_split4(float x0, float x1, float x2, float x3) {
+  const uint32_t h01 = pack2_f16(x0, x1), h23 = pack2_f16(x2, x3);
+  const f16x2_t a = __builtin_bit_cast(f16x2_t, h01), b = __builtin_bit_cast(f16x2_t, h23);
+  return u32x4_t{h01, h23, pack2_f16(x0 - (float)a[0], x1 - (float)a[1]), pack2_f16(x2 - (float)b[0], x3 - (float)b[1])};
+}
+__device__ __forceinline__ u32x4_t x3_split4(const float4 v) { return x3_split4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ float to_f32(x3_t v) { return v.f; }
+template <> __device__ __forceinline__ x3_t from_f32<x3_t>(float f) { return x3_t{f}; }
+template <typename T> struct is_x3 { static constexpr bool value = false; };
+template <> struct is_x3<x3_t> { static constexpr bool value = true; };
+
 // ---- per-type tile traits ------------------------------------------------------------
 template <typename T> struct TT;
 template <> struct TT<bf16_t> {
@@ -84,12 +112,26 @@ template <> struct TT<float> {
   static constexpr int EPC = 4;
   static constexpr int KSTEPS = 2;
 };
+template <> struct TT<x3_t> : TT<float> {};
+// ds_read_b128s per fragment / MFMA instructions per 32x32x16 atom (the consumers' interleave of conv3_halo_spec_kernel)
+template <typename T> struct FragCost { static constexpr int READS = sizeof(T) == 2 ? 1 : 2, MFMAS = sizeof(T) == 2 ? 1 : 8; };
+template <> struct FragCost<x3_t> { static constexpr int READS = 2, MFMAS = 3; };
 
 // A/B fragment of one 32x32x16 atom: 8 consecutive K elements of one row.
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { u32x4_t v; };
 template <> struct Frag<f16_t> { u32x4_t v; };
 template <> struct Frag<float> { float v[8]; };
+template <> struct Frag<x3_t> { u32x4_t hi, lo; };
+// two x3 chunks (K elements 0-3 and 4-7 of the fragment) -> fragment: register renaming only
+__device__ __forceinline__ void x3_frag_from_chunks(Frag<x3_t>& f, const u32x4_t c0, const u32x4_t c1) {
+  f.hi = u32x4_t{c0.x, c0.y, c1.x, c1.y};
+  f.lo = u32x4_t{c0.z, c0.w, c1.z, c1.w};
+}
+// eight fp32 values -> fragment (the `a_raw` operands: 20 VALU per fragment)
+__device__ __forceinline__ void x3_frag_from_f32(Frag<x3_t>& f, const float4 a, const float4 b) {
+  x3_frag_from_chunks(f, x3_split4(a), x3_split4(b));
+}
 
 // Swizzled LDS tile: row r (128 B), logical chunk c (16 B) lives at physical chunk c ^ ((r >> 1) & 7).
 // ds_read_b128 is serviced in 16-lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) over 64 banks
@@ -111,6 +153,20 @@ __device__ __forceinline__ void ld_frag(Frag<float>& f, const char* tile, int r,
   f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
   f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
 }
+// split-precision operand already in x3 chunks (weights; activations written by our producers): same two chunks as the fp32 form
+__device__ __forceinline__ void ld_frag(Frag<x3_t>& f, const char* tile, int r, int ks, int h) {
+  x3_frag_from_chunks(f, *reinterpret_cast<const u32x4_t*>(tile + lds_chunk_off(r, 4 * ks + 2 * h)),
+                      *reinterpret_cast<const u32x4_t*>(tile + lds_chunk_off(r, 4 * ks + 2 * h + 1)));
+}
+// RAW = the LDS image holds plain fp32 rows (x3 arithmetic only): convert while reading.  Every other type: ld_frag.
+template <bool RAW, typename T> __device__ __forceinline__ void ld_frag_a(Frag<T>& f, const char* tile, int r, int ks, int h) {
+  if constexpr (RAW && is_x3<T>::value) {
+    x3_frag_from_f32(f, *reinterpret_cast<const float4*>(tile + lds_chunk_off(r, 4 * ks + 2 * h)),
+                     *reinterpret_cast<const float4*>(tile + lds_chunk_off(r, 4 * ks + 2 * h + 1)));
+  } else {
+    ld_frag(f, tile, r, ks, h);
+  }
+}
 
 // acc(32x32, C layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) += A(32x16) * B(16x32)
 // A fragment: row = lane&31; B fragment: col = lane&31; both hold K = 8*(lane>>5) + j.
@@ -125,6 +181,17 @@ __device__ __forceinline__ void mma_atom(f32x16_t& acc, const Frag<float>& a, co
   // 8 exact-fp32 MFMAs (K=2 each): call j pairs element j of lane-half 0 with element j of lane-half 1.
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], acc, 0, 0, 0);
+}
+
+// split precision: hi.hi + hi.lo + lo.hi into ONE fp32 accumulator (the dropped lo.lo term is <= 2^-24 of the product)
+__device__ __forceinline__ void mma_atom(f32x16_t& acc, const Frag<x3_t>& a, const Frag<x3_t>& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a.hi), __builtin_bit_cast(f16x8_t, b.hi), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a.hi), __builtin_bit_cast(f16x8_t, b.lo), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a.lo), __builtin_bit_cast(f16x8_t, b.hi), acc, 0, 0, 0);
+}
+// factor the epilogues apply to an accumulator before anything else (undoes the weights' power-of-two pre-scale)
+template <typename T> __device__ __forceinline__ float acc_unscale(float v) {
+  if constexpr (is_x3<T>::value) return v * K22_X3_WSCALE_INV; else return v;
 }
 
 __device__ __forceinline__ int c_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
@@ -212,6 +279,7 @@ template <> struct Vec16<float> {
     (&raw.x)[2 * pair + 1] = hi;
   }
 };
+template <> struct Vec16<x3_t> : Vec16<float> {};
 
 #define K22_CHECK_LAUNCH()                                   \
   do {                                                       \

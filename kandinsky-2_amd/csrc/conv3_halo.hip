@@ -49,6 +49,21 @@ __device__ __forceinline__ void ld_frag_at(Frag<float>& f, const char* rowp, int
   f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
 }
 
+// split precision: the operand is in x3 chunks (weights; activations written by gn_apply / the attention epilogue)
+__device__ __forceinline__ void ld_frag_at(Frag<x3_t>& f, const char* rowp, int sw, int ks, int h) {
+  x3_frag_from_chunks(f, *reinterpret_cast<const u32x4_t*>(rowp + (((4 * ks + 2 * h) ^ sw) << 4)),
+                      *reinterpret_cast<const u32x4_t*>(rowp + (((4 * ks + 2 * h + 1) ^ sw) << 4)));
+}
+// RAW operands (x3 arithmetic only): plain fp32 rows in the LDS, split while they are read; every other type = ld_frag_at
+template <bool RAW, typename T> __device__ __forceinline__ void ld_frag_at_a(Frag<T>& f, const char* rowp, int sw, int ks, int h) {
+  if constexpr (RAW && is_x3<T>::value) {
+    x3_frag_from_f32(f, *reinterpret_cast<const float4*>(rowp + (((4 * ks + 2 * h) ^ sw) << 4)),
+                     *reinterpret_cast<const float4*>(rowp + (((4 * ks + 2 * h + 1) ^ sw) << 4)));
+  } else {
+    ld_frag_at(f, rowp, sw, ks, h);
+  }
+}
+
 template <typename T> __device__ __forceinline__ void store8(T* dst, const float* v);
 template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* dst, const float* v) {
   uint4 w;
@@ -70,6 +85,7 @@ template <> __device__ __forceinline__ void store8<float>(float* dst, const floa
   *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
   *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
+template <> __device__ __forceinline__ void store8<x3_t>(x3_t* dst, const float* v) { store8<float>(reinterpret_cast<float*>(dst), v); }
 template <typename T> __device__ __forceinline__ void load8f(const T* src, float* v);
 template <> __device__ __forceinline__ void load8f<bf16_t>(const bf16_t* src, float* v) {
   const uint4 r = *reinterpret_cast<const uint4*>(src);
@@ -86,11 +102,13 @@ template <> __device__ __forceinline__ void load8f<float>(const float* src, floa
   const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
+template <> __device__ __forceinline__ void load8f<x3_t>(const x3_t* src, float* v) { load8f<float>(reinterpret_cast<const float*>(src), v); }
 // value as it will be read back from memory (the GroupNorm statistics are those of the stored tensor)
 template <typename T> __device__ __forceinline__ float stored(float v);
 template <> __device__ __forceinline__ float stored<bf16_t>(float v) { return bf16_to_f32(f32_to_bf16(v)); }
 template <> __device__ __forceinline__ float stored<f16_t>(float v) { return (float)(f16_t)v; }
 template <> __device__ __forceinline__ float stored<float>(float v) { return v; }
+template <> __device__ __forceinline__ float stored<x3_t>(float v) { return v; }
 
 __device__ __forceinline__ int xcd_remap_h(int bid, int nblocks) {
   const int q = nblocks >> 3, r = nblocks & 7, x = bid & 7;
@@ -219,7 +237,7 @@ __device__ __forceinline__ void halo_tail(const IgemmParams& p, f32x16_t (&acc)[
         for (int ks = 0; ks < KSTEPS; ++ks) {
           Frag<T> a[MI], b[NI];
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi) ld_frag_at(a[mi], sA + (abase + mi * 32) * 128, bsw, ks, h);
+          for (int mi = 0; mi < MI; ++mi) ld_frag_at_a<true>(a[mi], sA + (abase + mi * 32) * 128, bsw, ks, h);   // S0 / S1: plain T rows
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) ld_frag_at(b[ni], sB + brow[ni], bsw, ks, h);
 #pragma unroll
@@ -247,7 +265,8 @@ __device__ __forceinline__ void halo_tail(const IgemmParams& p, f32x16_t (&acc)[
       for (int j = 0; j < 4; ++j) {
         const int col = wn * (BN / WN) + ni * 32 + 8 * j + 4 * h;
         *reinterpret_cast<float4*>(smem + row * TS + col * 4) =
-            make_float4(acc[mi][ni][4 * j], acc[mi][ni][4 * j + 1], acc[mi][ni][4 * j + 2], acc[mi][ni][4 * j + 3]);
+            make_float4(acc_unscale<T>(acc[mi][ni][4 * j]), acc_unscale<T>(acc[mi][ni][4 * j + 1]), acc_unscale<T>(acc[mi][ni][4 * j + 2]),
+                        acc_unscale<T>(acc[mi][ni][4 * j + 3]));
       }
   }
   __syncthreads();
@@ -805,8 +824,8 @@ __global__ __launch_bounds__(512) void conv3_halo_spec_kernel(const IgemmParams 
       // One block of the pipeline = NRD fragment reads (of the NEXT group) + NMF MFMAs (of the group read one block ago), which
       // are independent of each other: one read is scheduled behind every MPR MFMAs (0x008 = MFMA, 0x100 = DS read), so that
       // each ds_read_b128 issues under the 32 cycles the MFMA before it occupies the pipe.
-      constexpr int NRD = (MI + NI) * (sizeof(T) == 2 ? 1 : 2);
-      constexpr int NMF = MI * NI * (sizeof(T) == 2 ? 1 : 8);
+      constexpr int NRD = (MI + NI) * FragCost<T>::READS;
+      constexpr int NMF = MI * NI * FragCost<T>::MFMAS;
       constexpr int MPR = NMF / NRD;
 #define K22_SP_INTERLEAVE()                                                                                \
       {                                                                                                    \
@@ -888,7 +907,7 @@ __global__ __launch_bounds__(512) void conv3_halo_spec_kernel(const IgemmParams 
 // two-stage LDS ring, no LDS-DMA - was built, parity-green, and measured equal: 1.29 ms against 1.26-1.31 ms for the GEMMs of one
 // step.  The K loop of these GEMMs is not bound by the LDS-DMA issue cost; removed.)
 // ================================================================================================================
-template <typename T, int BM, int NST>
+template <typename T, int BM, int NST, bool ARAW = false>
 __global__ __launch_bounds__(512) void gemm8_kernel(const IgemmParams p) {
   using TR = TT<T>;
   constexpr int BK = TR::BK, EPC = TR::EPC, KSTEPS = TR::KSTEPS;
@@ -984,7 +1003,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const IgemmParams p) {
       for (int ks = 0; ks < KSTEPS; ++ks) {
         Frag<T> a[MI], b[NI];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) ld_frag_at(a[mi], St + arow[mi], sw, ks, h);
+        for (int mi = 0; mi < MI; ++mi) ld_frag_at_a<ARAW>(a[mi], St + arow[mi], sw, ks, h);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) ld_frag_at(b[ni], St + brow[ni], sw, ks, h);
 #pragma unroll
@@ -1460,7 +1479,7 @@ static size_t gemm8_smem_bytes(int bm, int nst) {
 int gemm8_tiles_per_image(const IgemmParams& p, int bm) { return ((p.H > 0 ? p.H * p.W : p.M) + bm - 1) / bm; }
 
 bool gemm8_supported(const IgemmParams& p, int dtype, int bm) {
-  const int BK = (dtype == K22_F32) ? 32 : 64;
+  const int BK = k22_bk(dtype);
   if (p.taps != 1 || (bm != 256 && bm != 128) || p.N < 128) return false;
   if (p.K0 != p.Kc || p.S0 != nullptr || p.res_f32) return false;          // one A operand, no fused skip, T residual
   if (p.out_mode != IG_OUT_ROWMAJOR && p.out_mode != IG_OUT_ROWMAJOR_F32 && p.out_mode != IG_OUT_QKV) return false;
@@ -1472,16 +1491,17 @@ bool gemm8_supported(const IgemmParams& p, int dtype, int bm) {
   return true;
 }
 
-template <typename T, int BM, int NST>
+template <typename T, int BM, int NST, bool ARAW = false>
 static int launch_gemm8_cfg(const IgemmParams& p, int splitk, hipStream_t stream) {
+  if constexpr (is_x3<T>::value && !ARAW) { if (p.a_raw) return launch_gemm8_cfg<T, BM, NST, true>(p, splitk, stream); }
   const size_t smem = gemm8_smem_bytes(BM, NST);
   static LdsAttrGuard attr_guard;
-  if (int rc_ = k22_ensure_lds_attr(attr_guard, reinterpret_cast<const void*>(&gemm8_kernel<T, BM, NST>), 160 * 1024, __FILE__, __LINE__)) return rc_;
+  if (int rc_ = k22_ensure_lds_attr(attr_guard, reinterpret_cast<const void*>(&gemm8_kernel<T, BM, NST, ARAW>), 160 * 1024, __FILE__, __LINE__)) return rc_;
   IgemmParams q = p;
   q.splitk = splitk;
   const int hw = p.H > 0 ? p.H * p.W : p.M;
   const int nblocks = (p.M / hw) * gemm8_tiles_per_image(p, BM) * ((p.N + HALO_BN - 1) / HALO_BN) * splitk;
-  hipLaunchKernelGGL((gemm8_kernel<T, BM, NST>), dim3(nblocks), dim3(512), smem, stream, q);
+  hipLaunchKernelGGL((gemm8_kernel<T, BM, NST, ARAW>), dim3(nblocks), dim3(512), smem, stream, q);
   K22_CHECK_LAUNCH();
   return K22_OK;
 }
@@ -1498,13 +1518,20 @@ int launch_gemm8(const IgemmParams& p, int dtype, int bm, int splitk, hipStream_
     if (bm == 256) return launch_gemm8_cfg<f16_t, 256, 3>(p, splitk, stream);
     return nst == 2 ? launch_gemm8_cfg<f16_t, 128, 2>(p, splitk, stream) : launch_gemm8_cfg<f16_t, 128, 4>(p, splitk, stream);
   }
+  if (dtype == K22_F16X3) {
+    if (bm == 256) return launch_gemm8_cfg<x3_t, 256, 3>(p, splitk, stream);
+    return nst == 2 ? launch_gemm8_cfg<x3_t, 128, 2>(p, splitk, stream) : launch_gemm8_cfg<x3_t, 128, 4>(p, splitk, stream);
+  }
   if (bm == 256) return launch_gemm8_cfg<float, 256, 3>(p, splitk, stream);
   return nst == 2 ? launch_gemm8_cfg<float, 128, 2>(p, splitk, stream) : launch_gemm8_cfg<float, 128, 4>(p, splitk, stream);
 }
 
 bool conv3_halo_supported(const IgemmParams& p, int dtype, int bm) {
-  const int BK = (dtype == K22_F32) ? 32 : 64;
+  const int BK = k22_bk(dtype);
   if (p.taps != 9 || (bm != 256 && bm != 128)) return false;
+  // split precision: the input is read in x3 chunks; instantiated forms = the lock-step kernel with asm LDS-DMA (algo 2 / 5 / 6 / 7 all
+  // run it) and the specialised kernel (11 / 12)
+  if (dtype == K22_F16X3 && (p.a_raw || p.algo == 3 || p.algo == 4)) return false;
   if (p.out_mode != IG_OUT_ROWMAJOR && p.out_mode != IG_OUT_ROWMAJOR_F32) return false;
   if (p.N % 8 || p.ldo % 8 || (p.residual && p.ldr % 8) || p.Kc % BK) return false;
   if (p.H <= 0 || p.W <= 0 || p.M % (p.H * p.W)) return false;
@@ -1628,6 +1655,15 @@ int launch_conv3_halo_trace(const IgemmParams& p, int dtype, hipStream_t stream)
 // 5 the 128-byte-row kernel with loader-wave specialisation, anything else the symmetric 128-byte-row one.
 int launch_conv3_halo(const IgemmParams& p, int dtype, int bm, int splitk, hipStream_t stream) {
   if (!conv3_halo_supported(p, dtype, bm)) return k22_set_error(K22_EINVAL, "conv3_halo: unsupported problem");
+  if (dtype == K22_F16X3) {
+    int nb = halo_pick_nbst(p, bm);
+    if (p.stages >= 2 && p.stages < nb) nb = p.stages == 5 ? 4 : p.stages;
+    if (p.algo == 11) return bm == 256 ? launch_halo_spec_nbst<x3_t, 256, false>(p, nb, splitk, stream) : launch_halo_spec_nbst<x3_t, 128, false>(p, nb, splitk, stream);
+    // BM = 256: two fragment sets of 8 registers per fragment do not fit beside 128 accumulators (as for fp32): compiler-scheduled consumers
+    if (p.algo == 12) return bm == 256 ? launch_halo_spec_nbst<x3_t, 256, false>(p, nb, splitk, stream) : launch_halo_spec_nbst<x3_t, 128, true>(p, nb, splitk, stream);
+    if (p.algo == 13 || p.algo == 14 || p.algo == 8 || p.algo == 9) return k22_set_error(K22_EINVAL, "conv3_halo: no measurement-only variants in split precision");
+    return bm == 256 ? launch_halo_nbst<x3_t, 256, 8, 2>(p, nb, splitk, stream) : launch_halo_nbst<x3_t, 128, 8, 2>(p, nb, splitk, stream);
+  }
   if (p.algo == 4 && dtype != K22_F16) {   // (fp16: not instantiated - never a tuner candidate; the default kernel below)
     int nbst = halo4_pick_nbst(p, bm);
     if (p.stages >= 2 && p.stages < nbst) nbst = p.stages;

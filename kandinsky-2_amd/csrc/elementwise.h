@@ -26,6 +26,8 @@ struct GnApplyParams {
   int act;              // K22Act
   const float* coeff;
   void* out;
+  int out_x3;           // fp32 launches only (the K22_F16X3 engine): write the output in x3 chunks (common.h) - what the consuming
+                        // convolution / GEMM of the split-precision arithmetic reads as its A operand
 };
 // GroupNorm of a tensor whose producer accumulated its per-group sums (common.h: gn_add_group_sums): no statistics pass
 // and no coefficient kernel; every thread derives mean / rstd of its (at most two) groups from gsum and folds gamma, beta
@@ -84,6 +86,7 @@ struct AttentionParams {
   int causal;                   // 1: key j attends only to queries t >= j (prior transformer, prior.py:326-334)
   const float* key_valid;       // optional [B][kv_ld]: 0 = padding key (masked for every query); keys >= kv_n are valid
   int kv_ld, kv_n;
+  int out_x3;                   // K22_F16X3 only: write `out` in x3 chunks (common.h) - the operand format of the GEMM that reads it
 };
 struct SamplerParams {
   const float* x;          // [N][4][HW] current latent (fp32 NCHW)
@@ -104,6 +107,7 @@ struct SamplerParams {
   int N, HW;
 };
 
+int launch_x3_pack(const float* in, void* out, int64_t n, float scale, hipStream_t s);
 int gn_nsplit(int B, int HW);
 int launch_gn_stats(const GnStatsParams& p, int dtype, hipStream_t s);
 int launch_gn_coeff(const GnCoeffParams& p, int B, hipStream_t s);

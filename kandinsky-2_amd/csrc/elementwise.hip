@@ -244,6 +244,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyParams p) {
 #pragma unroll
     for (int k = 0; k < EPV / 2; ++k) o.set2(k, r[2 * k], r[2 * k + 1]);
   }
+  if constexpr (sizeof(T) == 4) {
+    // split-precision engine: the consumer is an MFMA kernel that reads its A operand in x3 chunks (common.h); a zero stays zero
+    if (p.out_x3) { *reinterpret_cast<u32x4_t*>(out) = x3_split4(o.raw); return; }
+  }
   *reinterpret_cast<decltype(o.raw)*>(out) = o.raw;
 }
 
@@ -818,6 +822,24 @@ __global__ __launch_bounds__(256) void kv_pack_kernel(KvPackParams p) {
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
+// fp32 -> x3 chunks (common.h): the operand format of the split-precision arithmetic.  scale = K22_X3_WSCALE for weights, 1 for activations.
+__global__ __launch_bounds__(256) void x3_pack_kernel(const float4* __restrict__ in, u32x4_t* __restrict__ out, int64_t n4, float scale) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = in[i];
+    out[i] = x3_split4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+  }
+}
+int launch_x3_pack(const float* in, void* out, int64_t n, float scale, hipStream_t s) {
+  if (n % 4 || ((uintptr_t)in | (uintptr_t)out) % 16) return k22_set_error(K22_EINVAL, "x3_pack: n % 4 == 0 and 16-byte aligned buffers");
+  const int64_t n4 = n / 4;
+  int nb = (int)((n4 + 255) / 256);
+  if (nb > 4096) nb = 4096;
+  if (nb < 1) return K22_OK;
+  hipLaunchKernelGGL(x3_pack_kernel, dim3(nb), dim3(256), 0, s, reinterpret_cast<const float4*>(in), reinterpret_cast<u32x4_t*>(out), n4, scale);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+
 static inline int grid_for(int64_t total, int threads, int cap) {
   int64_t nb = (total + threads - 1) / threads;
   if (nb > cap) nb = cap;
@@ -856,6 +878,7 @@ int launch_gn_apply(const GnApplyParams& p, int dtype, hipStream_t s) {
   const int C = p.C0 + p.C1;
   const int epv = dtype == K22_F32 ? 4 : 8;
   if (C % epv || p.C0 % epv) return k22_set_error(K22_EINVAL, "gn_apply: channel alignment");
+  if (p.out_x3 && dtype != K22_F32) return k22_set_error(K22_EINVAL, "gn_apply: x3-chunk output is an option of the fp32 launch");
   const int Ho = p.mode == 1 ? p.H / 2 : (p.mode == 2 ? p.H * 2 : p.H);
   const int Wo = p.mode == 1 ? p.W / 2 : (p.mode == 2 ? p.W * 2 : p.W);
   const int Hp = Ho + 2 * p.pad, Wp = Wo + 2 * p.pad;

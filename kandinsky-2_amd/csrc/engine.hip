@@ -63,7 +63,9 @@ struct Act {  // unpadded NHWC activation, optionally a virtual channel concat o
 
 struct K22UNet {
   K22UNetConfig cfg;
-  int dtype; size_t esz;
+  int dtype;   // arithmetic type of the MFMA kernels (K22DType; K22_F16X3 = split precision)
+  int sdt;     // type of everything the data-movement kernels touch: dtype, except fp32 for the split-precision arithmetic
+  size_t esz;
   std::unordered_map<std::string, const void*> w;
 
   // ---- plan state ----
@@ -162,9 +164,10 @@ struct K22UNet {
     const float* gamma = Wf(pfx + ".weight");
     const float* beta = Wf(pfx + ".bias");
     const Act a = in;
-    const int dt = dtype;
+    const int dt = sdt;
+    const int x3 = dtype == K22_F16X3 ? 1 : 0;   // every GroupNorm output feeds a convolution or the qkv GEMM: written in x3 chunks
     const double gn_bytes = (double)Bn * HW * C * esz * (fused ? 1.0 : 2.0) + (double)Bn * (Ho + 2 * pad) * (Wo + 2 * pad) * C * esz;
-    if (gn_onepass && a.s1 == nullptr && a.gs0 >= 0 && gn_apply3_supported(C, dtype)) {
+    if (gn_onepass && !x3 && a.s1 == nullptr && a.gs0 >= 0 && gn_apply3_supported(C, dtype)) {
       // the producer accumulated this tensor's group sums: one kernel, no statistics / coefficient pass
       const int64_t gs = a.gs0;
       const double inv_n = 1.0 / ((double)HW * (double)(C / 32));
@@ -179,7 +182,7 @@ struct K22UNet {
       }, OP_GN, 0.0, (double)Bn * HW * C * esz + (double)Bn * (Ho + 2 * pad) * (Wo + 2 * pad) * C * esz, 1));
         return;
     }
-    const bool one_launch = gn_fused && gn_fused_supported(C, a.C0, dtype);
+    const bool one_launch = gn_fused && !x3 && gn_fused_supported(C, a.C0, dtype);
     L.push_back(Op([=](hipStream_t st) {
       const void* x0 = ptr(a.s0);
       const void* x1 = a.s1 ? ptr(a.s1) : nullptr;
@@ -200,9 +203,9 @@ struct K22UNet {
       cp.gamma = gamma; cp.beta = beta;
       cp.film = film_off >= 0 ? ptr<float>(s_film) + film_off : nullptr; cp.film_ld = film_total;
       cp.coeff = ptr<float>(s_coeff);
-      GnApplyParams ap;
+      GnApplyParams ap = {};
       ap.x0 = x0; ap.x1 = x1; ap.C0 = a.C0; ap.C1 = a.C1; ap.B = Bn; ap.H = a.H; ap.W = a.W;
-      ap.mode = mode; ap.pad = pad; ap.act = act; ap.coeff = ptr<float>(s_coeff); ap.out = ptr(dst);
+      ap.mode = mode; ap.pad = pad; ap.act = act; ap.coeff = ptr<float>(s_coeff); ap.out = ptr(dst); ap.out_x3 = x3;
       if (one_launch) return launch_gn_fused(cp, ap, dt, st);   // coefficients + apply in one launch (elementwise.hip: gn_fused_kernel)
       int rc = launch_gn_coeff(cp, Bn, st);
       if (rc) return rc;
@@ -240,7 +243,7 @@ struct K22UNet {
     t->want_stats = stats != nullptr;
     // small M (the 24x24 / 12x12 levels): the weight-streaming kernel becomes a candidate, fed from a fragment-major copy of the weights
     Slot *wf = nullptr, *wsf = nullptr;
-    if (stream_frag && dtype != K22_F32 && p.M <= 1152 && (stream_supported(p, dtype, 5) || stream_supported(p, dtype, 9))) {
+    if (stream_frag && k22_esz(dtype) == 2 && p.M <= 1152 && (stream_supported(p, dtype, 5) || stream_supported(p, dtype, 9))) {
       wf = new_slot();
       need(wf, stream_frag_bytes(p.Npad, 9, Cin, dtype));
       frag_jobs.push_back({p.Wp, wf, p.Npad, 9, Cin});
@@ -280,8 +283,9 @@ struct K22UNet {
   // GEMM over unpadded rows (1x1 conv / linear); `in` may be a virtual concat.
   // `stats` (optional) receives the GroupNorm partial sums of the output (image-shaped inputs only: in.H * in.W rows
   // per image); whether a configuration that can deliver them exists is reported by the returned want_stats.
+  // a_raw: `in` holds plain T rows that no producer of ours wrote in x3 chunks (split-precision arithmetic only; ignored otherwise)
   Tuned* op_gemm(OpList& L, const Act& in, int M, int N, const std::string& pfx,
-                 const Act* residual, Slot* dst, int ldo = 0, int out_mode = IG_OUT_ROWMAJOR, Slot* stats = nullptr) {
+                 const Act* residual, Slot* dst, int ldo = 0, int out_mode = IG_OUT_ROWMAJOR, Slot* stats = nullptr, bool a_raw = false) {
     tuned.emplace_back();
     Tuned* t = &tuned.back();
     IgemmParams& p = t->p;
@@ -292,6 +296,7 @@ struct K22UNet {
     if (in.H > 0 && in.W > 0 && M % (in.H * in.W) == 0 && M / (in.H * in.W) == B) { p.H = in.H; p.W = in.W; }  // rows per image
     if (out_mode == IG_OUT_QKV) p.att_T = in.H * in.W;
     p.Wp = W_(pfx + ".weight"); p.bias = Wf(pfx + ".bias");
+    p.a_raw = (a_raw && dtype == K22_F16X3) ? 1 : 0;
     t->want_stats = stats != nullptr && p.H > 0;
     make_candidates(*t);
     if (t->want_stats && t->cands.empty()) { t->want_stats = false; make_candidates(*t); }
@@ -339,7 +344,7 @@ struct K22UNet {
     if (updown) {
       if (Cin != Cout || in.s1) { if (err.empty()) err = "updown ResBlock with channel change is not supported"; }
       need(s_S, (size_t)B * Ho * Wo * Cin * esz);
-      const Act a = in; const int Bn = B, dt = dtype;
+      const Act a = in; const int Bn = B, dt = sdt;
       ops.push_back([=](hipStream_t st) { return launch_resample(ptr(a.s0), ptr(s_S), Bn, a.H, a.W, Cin, updown, dt, st); });
       skip.s0 = s_S;
     } else if (Cin != Cout) {
@@ -356,7 +361,7 @@ struct K22UNet {
         if (t2->want_stats) { out.p0 = t2; out.st0 = dst_stats; out.gs0 = t2->gsum_off; }
         return out;
       }
-      op_gemm(ops, in, B * Ho * Wo, Cout, pfx + ".skip_connection", nullptr, s_S);
+      op_gemm(ops, in, B * Ho * Wo, Cout, pfx + ".skip_connection", nullptr, s_S, 0, IG_OUT_ROWMAJOR, nullptr, /*a_raw=*/true);
       skip.s0 = s_S;
     } else {
       if (in.s1) { if (err.empty()) err = "identity skip over a concat input"; }
@@ -382,15 +387,15 @@ struct K22UNet {
     // encoder_kv (step-invariant) + context part of K_all / V^T_all (and zero padding) -> cond_ops
     Slot* ckv = new_slot((size_t)B * S * 2 * C * esz);
     s_ctxkv.push_back(ckv);
-    const int Bn = B, dt = dtype;
+    const int Bn = B, dt = dtype, sd = sdt;
     {
       Act c; c.s0 = s_ctx; c.C0 = cfg.ctx_dim; c.H = 1; c.W = S;
-      op_gemm(cond_ops, c, B * S, 2 * C, pfx + ".encoder_kv", nullptr, ckv);
+      op_gemm(cond_ops, c, B * S, 2 * C, pfx + ".encoder_kv", nullptr, ckv, 0, IG_OUT_ROWMAJOR, nullptr, /*a_raw=*/true);
       cond_ops.push_back(Op([=](hipStream_t st) {
         KvPackParams kp;
         kp.qkv = nullptr; kp.ctxkv = ptr(ckv); kp.kall = ptr(kall); kp.vtall = ptr(vtall);
         kp.B = Bn; kp.H = Hh; kp.T = 0; kp.S = S; kp.Tkp = Tkp;
-        return launch_kv_pack(kp, dt, st);
+        return launch_kv_pack(kp, sd, st);
       }));
     }
     // qkv projection in IG_OUT_QKV mode
@@ -405,6 +410,7 @@ struct K22UNet {
       AttentionParams ap = {};
       ap.q = ptr(s_QKV); ap.ldq = C; ap.kall = ptr(kall); ap.vtall = ptr(vtall); ap.out = ptr(s_ATT); ap.ldo = C;
       ap.B = Bn; ap.H = Hh; ap.T = T; ap.Tk = Tk; ap.Tkp = Tkp; ap.scale = 0.125f;
+      ap.out_x3 = dt == K22_F16X3 ? 1 : 0;   // proj_out reads it as an x3-chunk operand
       return launch_attention(ap, dt, st);
     }, OP_ATTN, 4.0 * Bn * Hh * (double)T * Tk * 64.0, 0.0, 1));
     Act a; a.s0 = s_ATT; a.C0 = C; a.H = in.H; a.W = in.W;
@@ -489,7 +495,7 @@ struct K22UNet {
       const float* w0 = Wf("time_embed.0.weight"); const float* b0 = Wf("time_embed.0.bias");
       const float* w2 = Wf("time_embed.2.weight"); const float* b2 = Wf("time_embed.2.bias");
       const void* we = W_("emb_layers.weight"); const float* be = Wf("emb_layers.bias");
-      const int Bn = B, dt = dtype; const int64_t ft = film_total;
+      const int Bn = B, dt = sdt; const int64_t ft = film_total;
       ops.push_back([=](hipStream_t st) {
         int rc = launch_timestep_embedding(ptr<float>(s_t), freqs, ptr<float>(s_temb), Bn, mc / 2, st);
         if (rc) return rc;
@@ -518,7 +524,7 @@ struct K22UNet {
       ConvInParams cp = {};
       cp.w = Wf("input_blocks.0.0.weight"); cp.bias = Wf("input_blocks.0.0.bias");
       cp.B = B; cp.H = H; cp.W = W; cp.Cin = cfg.in_channels; cp.Cout = ch;
-      const int dt = dtype; const bool inpaint = cfg.in_channels == 9, hinted = cfg.in_channels == 8;
+      const int dt = sdt; const bool inpaint = cfg.in_channels == 9, hinted = cfg.in_channels == 8;
       const int premul = (hinted || cfg.head_type == 1) ? 1 : 0;   // 2.2: channels 4-7 arrive as they are (hint latent / masked image)
       ops.push_back([=](hipStream_t st) {
         ConvInParams q = cp;
@@ -609,7 +615,7 @@ struct K22UNet {
   //   ctx[b][0:S] = LayerNorm_768( Linear(image_dim -> S*768)(image_emb[b]) viewed [S][768] )      (encoder_hid_proj)
   //   emb        += LayerNorm_1536( Linear(image_dim -> 1536)(image_emb[b]) )                       (add_embedding)
   void build_cond_ops_22() {
-    const int mc = cfg.model_channels, ted = 4 * mc, Bn = B, dt = dtype;
+    const int mc = cfg.model_channels, ted = 4 * mc, Bn = B, dt = sdt;
     const int cd = cfg.ctx_dim, S = cfg.ctx_len, di = cfg.image_dim;
     const float* w_cp = Wf("head22.ctx_proj.weight"); const float* b_cp = Wf("head22.ctx_proj.bias");
     const float* g_cn = Wf("head22.ctx_norm.weight"); const float* b_cn = Wf("head22.ctx_norm.bias");
@@ -659,7 +665,7 @@ struct K22UNet {
 
   // Text2ImUNet.get_text_emb (text2im_model2_1.py:57-80), pooling_type == "from_model".
   void build_cond_ops() {
-    const int mc = cfg.model_channels, ted = 4 * mc, Bn = B, dt = dtype;
+    const int mc = cfg.model_channels, ted = 4 * mc, Bn = B, dt = sdt, adt = dtype;
     const int nie = cfg.n_image_embs, cd = cfg.ctx_dim, S = cfg.ctx_len, ntext = S - nie;
     const float* w_cs = Wf("clip_to_seq.weight"); const float* b_cs = Wf("clip_to_seq.bias");
     const float* w_pn = Wf("proj_n.weight"); const float* b_pn = Wf("proj_n.bias");
@@ -698,6 +704,7 @@ struct K22UNet {
     p.stages = -1;
       p.M = ntext; p.N = cd; p.Npad = (cd + 63) / 64 * 64; p.Kc = d1; p.K0 = d1; p.taps = 1; p.lda0 = d1; p.ldo = cd;
       p.out_mode = IG_OUT_ROWMAJOR; p.splitk = 1;
+      p.a_raw = dtype == K22_F16X3 ? 1 : 0;   // s_fullT: plain rows written by cast_rows
       p.Wp = W_("to_model_dim_n.weight"); p.bias = Wf("to_model_dim_n.bias");
       const size_t es = esz;
       cond_ops.push_back([=](hipStream_t st) {
@@ -705,7 +712,7 @@ struct K22UNet {
           IgemmParams q = p;
           q.A0 = ptr(s_fullT) + (size_t)b * ntext * d1 * es;
           q.out = ptr(s_ctx) + ((size_t)b * S + nie) * cd * es;
-          int rc = launch_igemm(q, dt, st);
+          int rc = launch_igemm(q, adt, st);
           if (rc) return rc;
         }
         return K22_OK;
@@ -721,7 +728,7 @@ extern "C" {
 
 int k22_unet_create(const K22UNetConfig* cfg, const K22Weight* weights, int n_weights, K22UNet** out) {
   if (!cfg || !out) return k22_set_error(K22_EINVAL, "unet_create: null argument");
-  if (!k22_dtype_ok(cfg->dtype)) return k22_set_error(K22_EINVAL, "unet_create: dtype");
+  if (!k22_dtype_ok(cfg->dtype) && cfg->dtype != K22_F16X3) return k22_set_error(K22_EINVAL, "unet_create: dtype");
   if (cfg->num_head_channels != 64) return k22_set_error(K22_EINVAL, "unet_create: only num_head_channels == 64");
   if (cfg->model_channels % 128) return k22_set_error(K22_EINVAL, "unet_create: model_channels % 128");
   if (cfg->n_levels < 1 || cfg->n_levels > 8) return k22_set_error(K22_EINVAL, "unet_create: n_levels");
@@ -731,7 +738,7 @@ int k22_unet_create(const K22UNetConfig* cfg, const K22Weight* weights, int n_we
     return k22_set_error(K22_EINVAL, "unet_create: hint_channels = 3 goes with in_channels = 8 (latent + hint latent), else 0");
   if (cfg->head_type == 1 && cfg->n_image_embs != cfg->ctx_len) return k22_set_error(K22_EINVAL, "unet_create: the 2.2 head has image tokens only (n_image_embs == ctx_len)");
   K22UNet* u = new K22UNet();
-  u->cfg = *cfg; u->dtype = cfg->dtype; u->esz = cfg->dtype == K22_F32 ? 4 : 2;
+  u->cfg = *cfg; u->dtype = cfg->dtype; u->sdt = k22_storage_dtype(cfg->dtype); u->esz = k22_esz(cfg->dtype);
   {
     const char* e = getenv("K22_AUTOTUNE");  // 0 = heuristics only (no measurement at the first forward)
     u->autotune = e ? (atoi(e) != 0) : 1;

@@ -48,6 +48,7 @@ template <> __device__ __forceinline__ void store4<f16_t>(f16_t* dst, const floa
 template <> __device__ __forceinline__ void store4<float>(float* dst, const float* v) {
   *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
 }
+template <> __device__ __forceinline__ void store4<x3_t>(x3_t* dst, const float* v) { store4<float>(reinterpret_cast<float*>(dst), v); }
 template <typename T> __device__ __forceinline__ void load4f(const T* src, float* v);
 template <> __device__ __forceinline__ void load4f<bf16_t>(const bf16_t* src, float* v) {
   const uint2 r = *reinterpret_cast<const uint2*>(src);
@@ -63,6 +64,8 @@ template <> __device__ __forceinline__ void load4f<float>(const float* src, floa
   v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
 }
 
+template <> __device__ __forceinline__ void load4f<x3_t>(const x3_t* src, float* v) { load4f<float>(reinterpret_cast<const float*>(src), v); }
+
 // Logical block index of hardware block `bid` (XCD = bid % 8): XCD x gets the contiguous range
 // [start_x, start_x + count_x) of logical indices, in dispatch order.  Bijective for any nblocks.
 __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
@@ -70,7 +73,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-template <typename T, int BM, int BN, int STAGES>
+// ARAW (K22_F16X3 only): the A operand is plain fp32 rows, split into fp16 halves while its fragments are read (p.a_raw).
+template <typename T, int BM, int BN, int STAGES, bool ARAW = false>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   using TR = TT<T>;
   constexpr int BK = TR::BK, EPC = TR::EPC, KSTEPS = TR::KSTEPS;
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         for (int ks = 0; ks < KSTEPS; ++ks) {
           Frag<T> a[MI], b[NI];
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi) ld_frag(a[mi], As, wm * (BM / 2) + mi * 32 + l31, ks, h);
+          for (int mi = 0; mi < MI; ++mi) ld_frag_a<ARAW>(a[mi], As, wm * (BM / 2) + mi * 32 + l31, ks, h);
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) ld_frag(b[ni], Bs, wn * (BN / 2) + ni * 32 + l31, ks, h);
 #pragma unroll
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         if (n >= p.N) continue;
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * j + e];
+        for (int e = 0; e < 4; ++e) v[e] = acc_unscale<T>(acc[mi][ni][4 * j + e]);
         if (part != nullptr) {
           if (vec_ok) {
             *reinterpret_cast<float4*>(part + (int64_t)m * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
@@ -472,7 +476,7 @@ static int g_default_stages() {
 }
 
 static IgemmPlan igemm_plan(const IgemmParams& p, int dtype) {
-  const int BK = (dtype == K22_F32) ? 32 : 64;
+  const int BK = k22_bk(dtype);
   const int nkt = p.taps * (p.Kc / BK);
   IgemmPlan pl;
   pl.halo = 0;
@@ -497,7 +501,7 @@ static IgemmPlan igemm_plan(const IgemmParams& p, int dtype) {
   }
   // ---- 3x3 convolution: LDS-resident halo kernels when they apply (algo 2 = 128-byte rows, 3 = 64-byte rows) -----
   const int algo = (p.algo && p.algo != 20) ? p.algo : (g_conv_algo == 20 ? 0 : g_conv_algo);
-  if (p.taps == 9 && algo != 1 && p.N >= 128) {
+  if (p.taps == 9 && algo != 1 && p.N >= 128 && !p.a_raw) {   // (the halo kernels read their input in x3 chunks only)
     IgemmParams ph = p;
     ph.algo = ((algo >= 3 && algo <= 9) || (algo >= 11 && algo <= 14)) ? algo : 2;
     int bm = 0;
@@ -617,23 +621,33 @@ static int launch_reduce(const IgemmParams& q, hipStream_t stream) {
   return K22_OK;
 }
 
-template <typename T, int BM, int BN, int STAGES>
+template <typename T, int BM, int BN, int STAGES, bool ARAW = false>
 static int launch_cfg(const IgemmParams& p, int splitk, hipStream_t stream) {
   constexpr int smem = STAGES * (BM + BN) * 128;
   static LdsAttrGuard attr_guard;
-  if (int rc_ = k22_ensure_lds_attr(attr_guard, reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, STAGES>), smem, __FILE__, __LINE__)) return rc_;
+  if (int rc_ = k22_ensure_lds_attr(attr_guard, reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, STAGES, ARAW>), smem, __FILE__, __LINE__)) return rc_;
   IgemmParams q = p;
   q.splitk = splitk;
   q.xcd_remap = g_xcd_remap;
   const int nblocks = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * splitk;
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, STAGES>), dim3(nblocks), dim3(256), smem, stream, q);
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, STAGES, ARAW>), dim3(nblocks), dim3(256), smem, stream, q);
   K22_CHECK_LAUNCH();
-  if (splitk > 1) return launch_reduce<T>(q, stream);
+  if (splitk > 1) {
+    if constexpr (is_x3<T>::value) return launch_reduce<float>(q, stream);   // an x3 epilogue stores fp32
+    else return launch_reduce<T>(q, stream);
+  }
   return K22_OK;
 }
 
 template <typename T, int BM, int BN>
 static int launch_stages(const IgemmParams& p, const IgemmPlan& pl, hipStream_t stream) {
+  if constexpr (is_x3<T>::value) {
+    if (p.a_raw) {
+      if (pl.stages == 2) return launch_cfg<T, BM, BN, 2, true>(p, pl.splitk, stream);
+      if (pl.stages == 3) return launch_cfg<T, BM, BN, 3, true>(p, pl.splitk, stream);
+      return launch_cfg<T, BM, BN, 4, true>(p, pl.splitk, stream);
+    }
+  }
   if (pl.stages == 2) return launch_cfg<T, BM, BN, 2>(p, pl.splitk, stream);
   if (pl.stages == 3) return launch_cfg<T, BM, BN, 3>(p, pl.splitk, stream);
   return launch_cfg<T, BM, BN, 4>(p, pl.splitk, stream);
@@ -648,8 +662,14 @@ static int launch_typed(const IgemmParams& p, const IgemmPlan& pl, hipStream_t s
   return k22_set_error(K22_EINVAL, "igemm: unsupported tile configuration");
 }
 
+// split-K finish of an engine of arithmetic type `dtype`: the partials are fp32 and so is what an x3 epilogue stores
+static int launch_reduce_dt(const IgemmParams& q, int dtype, hipStream_t stream) {
+  return dtype == K22_BF16 ? launch_reduce<bf16_t>(q, stream) : (dtype == K22_F16 ? launch_reduce<f16_t>(q, stream) : launch_reduce<float>(q, stream));
+}
+
 int launch_igemm(const IgemmParams& p, int dtype, hipStream_t stream) {
-  const int BK = (dtype == K22_F32) ? 32 : 64;
+  const int BK = k22_bk(dtype);
+  if (p.a_raw && dtype != K22_F16X3) return k22_set_error(K22_EINVAL, "igemm: a_raw is an option of the split-precision arithmetic only");
   if (p.M <= 0 || p.N <= 0) return K22_OK;
   if (p.taps != 1 && p.taps != 9) return k22_set_error(K22_EINVAL, "igemm: taps must be 1 or 9");
   if (p.Kc % BK != 0 || p.K0 % BK != 0) return k22_set_error(K22_EINVAL, "igemm: K per tap must be a multiple of 64 (bf16) / 32 (fp32)");
@@ -672,7 +692,7 @@ int launch_igemm(const IgemmParams& p, int dtype, hipStream_t stream) {
     q.xcd_remap = g_xcd_remap;
     int rc = launch_stream(q, dtype, pl.bm / 32, pl.splitk, stream);
     if (rc) return rc;
-    return dtype == K22_BF16 ? launch_reduce<bf16_t>(q, stream) : (dtype == K22_F16 ? launch_reduce<f16_t>(q, stream) : launch_reduce<float>(q, stream));
+    return launch_reduce_dt(q, dtype, stream);
   }
   if (pl.splitk > 1 && p.partial == nullptr) pl.splitk = 1;
   if (p.res_f32 && pl.halo) return k22_set_error(K22_EINVAL, "igemm: fp32 residual is not supported by the halo kernel");
@@ -686,7 +706,7 @@ int launch_igemm(const IgemmParams& p, int dtype, hipStream_t stream) {
     if (q.stages < 2 && g_stages_override >= 0) q.stages = g_stages_override;   // "igemm_stages" option (benches / tests)
     int rc = launch_gemm8(q, dtype, pl.bm, pl.splitk, stream);
     if (rc || pl.splitk == 1) return rc;
-    return dtype == K22_BF16 ? launch_reduce<bf16_t>(q, stream) : (dtype == K22_F16 ? launch_reduce<f16_t>(q, stream) : launch_reduce<float>(q, stream));
+    return launch_reduce_dt(q, dtype, stream);
   }
   if (pl.halo) {
     IgemmParams q = p;
@@ -696,10 +716,11 @@ int launch_igemm(const IgemmParams& p, int dtype, hipStream_t stream) {
     if (q.stages < 2 && g_stages_override >= 0) q.stages = g_stages_override;   // "igemm_stages" option (benches / tests)
     int rc = launch_conv3_halo(q, dtype, pl.bm, pl.splitk, stream);
     if (rc || pl.splitk == 1) return rc;
-    return dtype == K22_BF16 ? launch_reduce<bf16_t>(q, stream) : (dtype == K22_F16 ? launch_reduce<f16_t>(q, stream) : launch_reduce<float>(q, stream));
+    return launch_reduce_dt(q, dtype, stream);
   }
   if (dtype == K22_BF16) return launch_typed<bf16_t>(p, pl, stream);
   else if (dtype == K22_F16) return launch_typed<f16_t>(p, pl, stream);
   if (dtype == K22_F32) return launch_typed<float>(p, pl, stream);
+  if (dtype == K22_F16X3) return launch_typed<x3_t>(p, pl, stream);
   return k22_set_error(K22_EINVAL, "igemm: bad dtype");
 }

@@ -78,6 +78,9 @@ struct IgemmParams {
   // [lane][8 elements] = 1 KB contiguous per MFMA B fragment - written once by launch_stream_repack (Wsfrag: the fused 1x1 skip's weights);
   // null = fragments are gathered from the row-major Wp / Ws (32 bytes of 32 different lines per load: measured L1-lookup bound)
   const void* Wfrag; const void* Wsfrag;
+  int a_raw;             // K22_F16X3 only: 1 = the A operand (A0 / A1) is plain fp32 rows, converted to split halves at fragment-read
+                         // time (generic kernel and gemm8 only); 0 = A is in x3 chunks (common.h), written so by its producer.
+                         // The fused-skip operands S0 / S1 are always plain fp32 rows; weights are always x3 chunks.
   unsigned long long* st_trace;          // K22_STREAM_DEBUG builds only: 16 stamps per workgroup
   int st_tm, st_rb, st_mtiles, st_buf;   // set by launch_stream (stream_gemm.hip): rows per m-tile, image rows per band, m-tiles, bytes of one LDS A buffer
 };

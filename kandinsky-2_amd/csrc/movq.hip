@@ -125,7 +125,7 @@ struct K22MoVQ {
       cp.coeff = ptr<float>(s_coeff);
       rc = launch_gn_coeff(cp, Bn, st);
       if (rc) return rc;
-      GnApplyParams ap;
+      GnApplyParams ap = {};
       ap.x0 = ptr(a.s); ap.x1 = nullptr; ap.C0 = C; ap.C1 = 0; ap.B = Bn; ap.H = a.H; ap.W = a.W; ap.mode = 0; ap.pad = pad; ap.act = act;
       ap.coeff = ptr<float>(s_coeff); ap.out = ptr(dst);
       return launch_gn_apply(ap, dt, st);

@@ -103,7 +103,7 @@ inline void tuned_apply_cfg(IgemmParams& q, const Cfg& c) {
 
 inline void tuned_make_candidates(Tuned& t, int dtype) {
   const IgemmParams& p = t.p;
-  const int BK = dtype == K22_F32 ? 32 : 64;
+  const int BK = k22_bk(dtype);
   const int nkt = p.taps * (p.Kc / BK);
   std::vector<Cfg> all;
   if (p.taps == 9) {
@@ -115,6 +115,7 @@ inline void tuned_make_candidates(Tuned& t, int dtype) {
     // 11 = producer / consumer wave specialisation (conv3_halo_spec_kernel)
     for (int algo : {2, 7, 6, 3, 11, 12}) {
       if (algo == 3 && p.H > 16) continue;
+      if (dtype == K22_F16X3 && (algo == 2 || algo == 6)) continue;   // split precision: one lock-step form (7) + the specialised ones
       IgemmParams ph = p;
       ph.algo = algo;
       const int nsplit_max = (p.Kc / BK) * (algo == 3 ? 2 : 1);
@@ -150,7 +151,7 @@ inline void tuned_make_candidates(Tuned& t, int dtype) {
   // weight-streaming small-M kernel (stream_gemm.hip): 5 / 9 m-blocks per workgroup, 64-wide n-tiles, any split-K.  A candidate only
   // when the owner of the weights made the fragment-major copy (the row-major form of the kernel never won a measurement) and for the 3x3
   // convolutions (at taps == 1 gemm8 / igemm were faster on every GEMM of the UNet, profiles/r03_stream_kernel_v2.txt)
-  if (dtype != K22_F32 && p.Wfrag != nullptr && p.taps == 9) {
+  if (k22_esz(dtype) == 2 && p.Wfrag != nullptr && p.taps == 9) {
     for (int mb : {5, 9}) {
       IgemmParams q = p;
       q.algo = 20; q.force_bm = mb * 32;
@@ -200,7 +201,7 @@ inline TileKey tuned_key(const Tuned& t, int dtype) {
   // fp16 runs the same kernels on the same bytes at the same MFMA rate as bf16: one table line serves both 16-bit types
   if (dtype == K22_F16) dtype = K22_BF16;
   return TileKey(dtype, p.taps, p.M, p.N, p.Kc, p.K0 + (p.S0 ? 100000 * (p.SK0 + p.SK1) : 0), p.H, p.W,
-                 p.out_mode + 16 * p.res_f32 + 32 * p.act, t.want_stats);
+                 p.out_mode + 16 * p.res_f32 + 32 * p.act + 256 * p.a_raw, t.want_stats);
 }
 
 // a table line from an older build may name a configuration this build would not generate: only candidates are accepted

@@ -1,6 +1,8 @@
 """state_dict -> packed weight arena for the HIP engine.
 
-Layouts (T = engine dtype, bf16 or fp32; everything else fp32):
+Layouts (T = engine dtype: bf16, fp16 or fp32; for the split-precision engine "f16x3" the MFMA weights - conv3x3, conv1x1 / conv1d /
+linear, qkv, encoder_kv - are x3 chunks (to_x3 below: fp16 hi / lo pairs of the fp32 weight x 2^8, 4 bytes per element) and the
+emb_layers GEMV weights fp32; everything else fp32):
   conv3x3  [O,I,3,3] -> T [roundup(O,64)][ky][kx][I]   (K = tap-major then channel, contiguous)
   conv1x1 / conv1d k=1 / linear feeding the MFMA GEMM -> T [roundup(O,64)][I]
   AttentionBlock.qkv  rows re-ordered  head*192 + {q,k,v}*64 + d  ->  {q,k,v}*C + head*64 + d
@@ -33,7 +35,21 @@ def _pad_rows(w: torch.Tensor, mult: int = 64) -> torch.Tensor:
     return torch.cat([w, pad], 0)
 
 
-def packed_entries(arch: UNetArch, sd: Dict[str, torch.Tensor], tdtype: torch.dtype, device) -> "OrderedDict[str, torch.Tensor]":
+def to_x3(w: torch.Tensor, scale: float = 256.0) -> torch.Tensor:
+    """fp32 [..., K] (K % 4 == 0) -> the split-precision operand format of the K22_F16X3 arithmetic (csrc/common.h, "x3 chunks"):
+    every group of 4 consecutive K elements becomes [hi0..hi3 | lo0..lo3] in fp16 with hi = rne(x * scale), lo = rne(x * scale - hi);
+    returned as a float32-typed tensor of the SAME shape (4 bytes per element, bit pattern = the fp16 pairs)."""
+    if w.shape[-1] % 4:
+        raise ValueError("to_x3: the K dimension must be a multiple of 4")
+    ws = w.float() * scale
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.float()).to(torch.float16)
+    sh = tuple(w.shape)
+    g = sh[:-1] + (sh[-1] // 4, 4)
+    return torch.stack([hi.reshape(g), lo.reshape(g)], dim=-2).reshape(sh[:-1] + (sh[-1] * 2,)).contiguous().view(torch.float32)
+
+
+def packed_entries(arch: UNetArch, sd: Dict[str, torch.Tensor], tdtype, device) -> "OrderedDict[str, torch.Tensor]":
     f32 = torch.float32
     out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     head22 = arch.head == "2.2"
@@ -45,13 +61,19 @@ def packed_entries(arch: UNetArch, sd: Dict[str, torch.Tensor], tdtype: torch.dt
     def get(name):
         return sd[name].detach().to(device=device, dtype=f32)
 
+    x3 = tdtype == "f16x3"   # split-precision engine: MFMA weights in x3 chunks, everything else fp32
+    vdtype = f32 if x3 else tdtype   # weights read by the vector (non-MFMA) kernels
+
+    def cast(w):
+        return to_x3(w) if x3 else w.to(tdtype).contiguous()
+
     def conv3(name):
         w = get(name)  # [O,I,3,3]
-        return _pad_rows(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)).to(tdtype).contiguous()
+        return cast(_pad_rows(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)))
 
     def mat(name):
         w = get(name)
-        return _pad_rows(w.reshape(w.shape[0], -1)).to(tdtype).contiguous()
+        return cast(_pad_rows(w.reshape(w.shape[0], -1)))
 
     half = arch.model_channels // 2
     out["time_freqs"] = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=f32) / half).to(device)
@@ -99,13 +121,13 @@ def packed_entries(arch: UNetArch, sd: Dict[str, torch.Tensor], tdtype: torch.dt
                 bq = get(pfx + ".qkv.bias").reshape(h, 3, 64).permute(1, 0, 2).reshape(-1)
                 wk = get(pfx + ".encoder_kv.weight").reshape(h, 2, 64, arch.model_dim).permute(1, 0, 2, 3).reshape(2 * c, -1)
                 bk = get(pfx + ".encoder_kv.bias").reshape(h, 2, 64).permute(1, 0, 2).reshape(-1)
-            out[pfx + ".qkv.weight"] = _pad_rows(wq).to(tdtype).contiguous()
+            out[pfx + ".qkv.weight"] = cast(_pad_rows(wq))
             out[pfx + ".qkv.bias"] = bq.contiguous()
-            out[pfx + ".encoder_kv.weight"] = _pad_rows(wk).to(tdtype).contiguous()
+            out[pfx + ".encoder_kv.weight"] = cast(_pad_rows(wk))
             out[pfx + ".encoder_kv.bias"] = bk.contiguous()
             out[pfx + ".proj_out.weight"] = mat(pfx + ".proj_out.weight")
             out[pfx + ".proj_out.bias"] = get(pfx + ".proj_out.bias")
-    out["emb_layers.weight"] = torch.cat(emb_w, 0).to(tdtype).contiguous()
+    out["emb_layers.weight"] = torch.cat(emb_w, 0).to(vdtype).contiguous()
     out["emb_layers.bias"] = torch.cat(emb_b, 0).contiguous()
     out["out.0.weight"] = get("out.0.weight")
     out["out.0.bias"] = get("out.0.bias")
@@ -114,7 +136,7 @@ def packed_entries(arch: UNetArch, sd: Dict[str, torch.Tensor], tdtype: torch.dt
     return out
 
 
-def pack_arena(arch: UNetArch, sd: Dict[str, torch.Tensor], tdtype: torch.dtype, device) -> Tuple[torch.Tensor, "OrderedDict[str, Tuple[int, int]]"]:
+def pack_arena(arch: UNetArch, sd: Dict[str, torch.Tensor], tdtype, device) -> Tuple[torch.Tensor, "OrderedDict[str, Tuple[int, int]]"]:
     """Returns (arena uint8 tensor on `device`, name -> (byte offset, byte size))."""
     entries = packed_entries(arch, sd, tdtype, device)
     table: "OrderedDict[str, Tuple[int, int]]" = OrderedDict()

@@ -34,15 +34,17 @@ class Text2ImUNetHIP(nn.Module):
     """MI355X-native Text2ImUNet (kandinsky2/model/text2im_model2_1.py:13-103).
 
     backend_dtype: torch.bfloat16 (BASELINE's dtype, bf16 MFMA), torch.float16 (the reference's own use_fp16 mode: same MFMA rate,
-    3 more mantissa bits - the mode that holds <= 3e-3 on the 50-step final latent) or torch.float32 (parity path, exact-fp32 MFMA).
+    3 more mantissa bits - the mode that holds <= 3e-3 on the 50-step final latent), torch.float32 (parity path, exact-fp32 MFMA) or
+    "f16x3" (kandinsky2_amd.F16X3, split precision: fp32 tensors, every MFMA operand as an fp16 (hi, lo) pair, three fp16 MFMAs per
+    product - within 1e-3 of the reference p_sampler's final latent, BASELINE.json's gate, at several times the fp32 engine's speed).
     use_graph: replay each forward as one captured hipGraph.
     """
 
     def __init__(self, arch: UNetArch, backend_dtype: torch.dtype = torch.bfloat16, use_graph: bool = True,
                  cache_text_emb: bool = True, meta_params: bool = False):
         super().__init__()
-        if backend_dtype not in (torch.bfloat16, torch.float16, torch.float32):
-            raise ValueError("backend_dtype must be torch.bfloat16, torch.float16 or torch.float32")
+        if backend_dtype not in (torch.bfloat16, torch.float16, torch.float32, _lib.F16X3):
+            raise ValueError('backend_dtype must be torch.bfloat16, torch.float16, torch.float32 or "f16x3" (split precision)')
         self.arch = arch
         self.backend_dtype = backend_dtype
         self.use_graph = use_graph

@@ -16,7 +16,18 @@ A mode is a '+'-joined subset of
     u  the intermediate convolution output of a ResBlock (in_layers conv -> out_layers GroupNorm)
     a  attention operands: ctx / encoder_kv, q, k, v, softmax probabilities P, the attention output
 
+    s  the input of a ResBlock's 1x1 skip_connection, AS AN MFMA OPERAND (the tensor itself stays what `h` made it)
+
 followed by ':bf16' or ':fp16' ('all' = w+h+g+u+a, the engine's storage map; 'none' = no rounding = the oracle itself).
+
+Round 4 - SPLIT-PRECISION candidates.  The tensors stay fp32 in memory; what is emulated is the MFMA OPERAND:
+    :x3      x -> hi + lo with hi = rne_fp16(x), lo = rne_fp16(x - hi)  (fp16 subnormals kept: 2^-25 absolute floor), i.e. what
+             three v_mfma_f32_32x32x16_f16 (hi.hi + hi.lo + lo.hi, fp32 accumulate) see of an fp32 operand; the dropped lo.lo
+             term is <= 2^-24 of a product and is not emulated
+    :x3w     the same on x * 2^8 (the packed weights are pre-scaled by an exact power of two so that lo stays normal), / 2^8
+    :bf16x3  hi + lo with bf16 halves (16 mantissa bits)
+A mode may join several 'kinds:type' parts with '/', e.g. 'w:x3w/g+a+s:x3' = weights split, every activation operand split (three
+MFMAs); 'w:x3w/g+a+s:fp16' = weights split, activations rounded to fp16 as operands (two MFMAs).
 Nothing here is product code; bench.py / tests only read the committed result (tests/golden/drift_ablation.json).
 """
 import argparse
@@ -36,16 +47,40 @@ import kandinsky2_amd as k22  # noqa: E402
 from oracle import diffusion_ref, unet_ref  # noqa: E402
 
 
+X3W_SCALE = 256.0
+
+
+def _split(x, dt):
+    hi = x.to(dt).float()
+    return hi + (x - hi).to(dt).float()
+
+
+ROUNDERS = {
+    "bf16": lambda x: x.to(torch.bfloat16).float(),
+    "fp16": lambda x: x.to(torch.float16).float(),
+    "": lambda x: x.to(torch.bfloat16).float(),
+    "x3": lambda x: _split(x, torch.float16),
+    "x3w": lambda x: _split(x * X3W_SCALE, torch.float16) / X3W_SCALE,
+    "bf16x3": lambda x: _split(x, torch.bfloat16),
+}
+
+
 class Rounder:
     def __init__(self, mode):
-        kinds, _, dt = mode.partition(":")
-        self.dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "": torch.bfloat16}[dt]
-        if kinds == "all":
-            kinds = "w+h+g+u+a"
-        self.kinds = set() if kinds == "none" else set(kinds.split("+"))
+        self.fn = {}
+        for part in mode.split("/"):
+            kinds, _, dt = part.partition(":")
+            if kinds == "all":
+                kinds = "w+h+g+u+a"
+            if kinds == "none":
+                continue
+            for k in kinds.split("+"):
+                self.fn[k] = ROUNDERS[dt]
+        self.kinds = set(self.fn)
 
     def __call__(self, x, kind):
-        return x.to(self.dt).float() if kind in self.kinds else x
+        f = self.fn.get(kind)
+        return f(x) if f is not None else x
 
 
 W_SUFFIXES = (".in_layers.2.weight", ".out_layers.3.weight", ".skip_connection.weight", ".qkv.weight", ".proj_out.weight",
@@ -57,7 +92,7 @@ def round_weights(sd, r):
     for k, v in sd.items():
         if "w" in r.kinds and (k.endswith(W_SUFFIXES) or k == "to_model_dim_n.weight") and k.split(".")[0] in (
                 "input_blocks", "middle_block", "output_blocks", "to_model_dim_n"):
-            out[k] = v.to(r.dt).float()
+            out[k] = r(v, "w")
         else:
             out[k] = v
     return out
@@ -81,7 +116,7 @@ def res_block(sd, pfx, x, emb, updown, r):
     h = gn(h, sd[pfx + ".out_layers.0.weight"], sd[pfx + ".out_layers.0.bias"], False) * (1 + scale) + shift
     h = F.conv2d(r(F.silu(h), "g"), sd[pfx + ".out_layers.3.weight"], sd[pfx + ".out_layers.3.bias"], padding=1)
     if (pfx + ".skip_connection.weight") in sd:   # fused into the second convolution's accumulator by the engine: no rounding
-        x = F.conv2d(x, sd[pfx + ".skip_connection.weight"], sd[pfx + ".skip_connection.bias"])
+        x = F.conv2d(r(x, "s"), sd[pfx + ".skip_connection.weight"], sd[pfx + ".skip_connection.bias"])
     return r(x + h, "h")
 
 

@@ -15,6 +15,7 @@ import time
 ENC_ONLY = "--encoders-only" in sys.argv     # keep the shipped table and add only the conditioning-tower shapes to it
 SMALL_CONV = "--small-conv" in sys.argv      # keep the shipped table except the 16-bit 3x3 convolutions with M <= 1152 rows: re-measured here
                                              # (the weight-streaming kernel joined their candidate list)
+X3_ONLY = "--x3-only" in sys.argv           # keep the shipped table and add only the split-precision (K22_F16X3) lines
 if SMALL_CONV:
     _here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     _src = os.path.join(_here, "kandinsky-2_amd", "tiles_gfx950.txt")
@@ -29,7 +30,7 @@ if SMALL_CONV:
                 dropped += 1
     print(f"--small-conv: {kept} table lines kept, {dropped} dropped for re-measurement")
     os.environ["K22_TILE_TABLE"] = _tmp
-elif not ENC_ONLY:
+elif not ENC_ONLY and not X3_ONLY:
     os.environ["K22_TILE_TABLE"] = "0"      # start empty: everything below is measured here
 os.environ.setdefault("K22_TUNE_REPS", "7")
 os.environ.pop("K22_TUNE_CACHE", None)
@@ -158,6 +159,16 @@ def main():
         print(f"{n0} shipped + {n - n0} new = {n} entries -> {out}")
         return
     tiny = k22.tiny_model_config()
+    if X3_ONLY:
+        x3 = (k22.F16X3,)
+        n0 = _lib.lib().k22_tile_table_size()
+        unet(tiny, False, [(2, 16, 16), (4, 8, 24), (4, 16, 16)], dtypes=x3)
+        unet(tiny, True, [(4, 16, 24), (2, 16, 16), (4, 16, 16)], dtypes=x3)
+        unet(k22.MODEL_CONFIG_2_1, False, [(2, 32, 32), (2, 96, 96), (8, 128, 128)], dtypes=x3)
+        unet(k22.MODEL_CONFIG_2_1, True, [(8, 96, 96)], dtypes=x3)
+        n = _lib.lib().k22_tile_table_save(out.encode())
+        print(f"{n0} shipped + {n - n0} new = {n} entries -> {out}")
+        return
     if SMALL_CONV:
         b16 = (torch.bfloat16,)
         unet(tiny, False, [(2, 16, 16), (4, 8, 24), (4, 16, 16)], dtypes=b16)
