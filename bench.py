@@ -49,7 +49,7 @@ def main(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=768, help="image side in pixels (latent = size/8)")
     ap.add_argument("--bs", type=int, default=1, help="images per GPU (CFG batch = 2*bs)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32", "f16x3"],
                     help="engine storage / MFMA operand type: bf16 (BASELINE's), fp16 (the reference's own use_fp16 mode), fp32 (parity path)")
     ap.add_argument("--sched-steps", type=int, default=50, help="decoder_steps of the schedule being sampled")
     ap.add_argument("--no-graph", action="store_true")
@@ -126,7 +126,7 @@ def run(a):
         mcfg = k22.tiny_model_config() if a.tiny else k22.MODEL_CONFIG_2_1
         arch = k22.make_arch(mcfg, inpainting=a.inpaint)
         Model, init_sd = k22.Text2ImUNetHIP, k22.init_unet_state_dict
-    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[a.dtype]
+    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32, "f16x3": k22.F16X3}[a.dtype]
     lat = a.size // 8
     B = 2 * a.bs
 
@@ -289,7 +289,7 @@ def run(a):
             "config": {"workload": f"Kandinsky-2.x {'ControlNet-depth' if a.controlnet else ('inpainting' if a.inpaint else 'text2img')} {a.size}x{a.size}, "
                                    f"decoder_steps={a.sched_steps}, bs={a.bs}/GPU (CFG batch {B}x4x{lat}x{lat}), " +
                                    (f"2.2 decoder UNet ({'tiny' if a.tiny else '1.25B'}, diffusers UNet2DConditionModel layout, 32 image tokens"
-                                    f"{', hint stack' if a.controlnet else ''}) + DDPM learned-range step; parity UNPINNED (diffusers absent)" if v22 else
+                                    f"{', hint stack' if a.controlnet else ''}) + DDPMScheduler step per SCHEDULER_CONFIG_2_2 (variance_type {k22.SCHEDULER_CONFIG_2_2.get('variance_type', 'fixed_small')}); parity UNPINNED (diffusers absent)" if v22 else
                                     f"2.1-architecture UNet ({'tiny' if a.tiny else '1.23B'}) p_sampler step; parity pinned against the reference's modules"),
                        "head": "2.2" if v22 else "2.1", "tile_configs_measured_in_this_process": measured_here,
                        "images_per_gpu": a.bs, "parallelism": f"prompt-sharded x{world}, weights by one RCCL broadcast",
@@ -404,7 +404,9 @@ def parity_paths(m_timed, arch, sd, a, dev):
     res = {"reference": "tests/golden/c2_text2img.pt: the reference's create_model + SpacedDiffusion.p_sample_loop (fp32), C2 shape, 50 steps, "
                         "fixed seed, injected noise; gate of the north star: 1e-3 max-abs on the final latent",
            a.dtype: one(m_timed)}
-    for name, dt in (("fp16", torch.float16), ("fp32", torch.float32)):
+    # f16x3 = the split-precision engine (fp32 tensors, fp16 (hi, lo) operand pairs, three fp16 MFMAs per product): the path built to
+    # hold the 1e-3 gate at 16-bit MFMA rate
+    for name, dt in (("fp16", torch.float16), ("f16x3", k22.F16X3), ("fp32", torch.float32)):
         if name == a.dtype:
             continue
         mm = k22.Text2ImUNetHIP(arch, backend_dtype=dt, use_graph=not a.no_graph)
@@ -422,7 +424,9 @@ def measure_roofline(m, a):
     prof = m.profile(reps=3)
     conv = prof["conv3x3"]
     peak = PEAK_F32_TFLOPS if a.dtype == "fp32" else PEAK_BF16_TFLOPS      # fp16 and bf16 MFMA run at the same dense rate
-    conv_tf = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+    # split precision issues three fp16 MFMAs per algorithmic product: its matrix-pipe rate is 3x the algorithmic FLOP rate
+    mfma_per_flop = 3.0 if a.dtype == "f16x3" else 1.0
+    conv_tf = mfma_per_flop * conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
     tot_ms = sum(v["ms"] for v in prof.values())
     tot_fl = sum(v["flops"] for v in prof.values())
     gn = prof["groupnorm"]
@@ -437,8 +441,9 @@ def measure_roofline(m, a):
         traffic = pj.get("hbm_bytes_per_launch")
         traffic_src = f"profiles/pmc_conv.json ({pj.get('round', 'r01')}: rocprofv3 --pmc passes of this command on another box; not live)"
     roofline = {
-        "kernel": "conv3_halo_kernel (3x3 convolutions of the ResBlocks: LDS-resident halo implicit GEMM, incl. "
-                  "split-K finish; 83% of the step's FLOPs)",
+        "kernel": "conv3_halo_spec_kernel + conv3_halo_kernel + stream_kernel (the three LDS-resident-halo / weight-streaming implicit-GEMM kernels the "
+                  "tile table picks among for the 3x3 convolutions of the ResBlocks: ~49 / 7 / 16 of the 72 launches of a C2 forward; incl. the split-K "
+                  "finishes; 83% of the step's FLOPs)",
         "bound": "mfma",
         "achieved": round(conv_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(conv_tf / peak, 4),
         "traffic": traffic, "traffic_source": traffic_src,

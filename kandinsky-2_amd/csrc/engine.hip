@@ -98,6 +98,7 @@ struct K22UNet {
   size_t ws_bytes = 0;
   char* ws = nullptr;
   bool cond_set = false;
+  bool warmed = false;   // one eager pass of the op list has run on this plan (function attributes set, code loaded): capture may start
   hipGraphExec_t graph_exec = nullptr;
   hipStream_t cap_stream = nullptr;  // private stream used only to CAPTURE (the caller's may be the legacy default stream)
   // the whole denoising loop as ONE graph (k22_unet_sample_loop): valid for exactly the buffers / scalars it was captured with
@@ -148,6 +149,7 @@ struct K22UNet {
     for (auto& op : ops) { int rc = op(st); if (rc) return rc; }
     return K22_OK;
   }
+  int run_ops_eager(hipStream_t st) { const int rc = run_ops(st); if (rc == K22_OK) warmed = true; return rc; }
 
   // ------------------------------------------------------------------------------------------
   void op_gn(OpList& L, const Act& in, const std::string& pfx, int64_t film_off,
@@ -257,6 +259,17 @@ struct K22UNet {
     }
     make_candidates(*t);
     default_cfg(*t);
+    // The fragment-major copy costs one more copy of this layer's weights in every plan's workspace and a repack per bind:
+    // keep it only where the weight-streaming kernel can actually run - the tile table (or the fixed heuristic, autotune off) names it
+    // for this problem, or the problem is unknown and will be measured with it as a candidate.
+    if (wf && t->cfg.algo != 20 && (t->from_table || !autotune)) {
+      wf->bytes = 0; wf = nullptr;
+      if (wsf) { wsf->bytes = 0; wsf = nullptr; frag_jobs.pop_back(); }
+      frag_jobs.pop_back();
+      p.Wfrag = nullptr; p.Wsfrag = nullptr;
+      make_candidates(*t);
+      default_cfg(*t);
+    }
     need(s_splitk, max_splitk_bytes(*t));
     if (t->want_stats) need(stats, (size_t)B * max_rpi(*t) * Cout * 2 * sizeof(float));
     const int64_t gs = (gn_onepass && t->want_stats && Cout % 32 == 0) ? new_gsum() : -1;
@@ -434,7 +447,7 @@ struct K22UNet {
     if (nB > 8) return k22_set_error(K22_EINVAL, "unet: batch (2*bs) must be <= 8 per engine call");
     B = nB; H = nH; W = nW;
     slots.clear(); ops.clear(); cond_ops.clear(); hint_ops.clear(); s_ctxkv.clear(); gsum_bytes = 0; frag_jobs.clear(); frag_done = false; n_attn = 0; err.clear();
-    tuned.clear(); tuned_done = false;
+    tuned.clear(); tuned_done = false; warmed = false;
     ws = nullptr; cond_set = false; hint_set = false;
     if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
     if (loop_exec) { (void)hipGraphExecDestroy(loop_exec); loop_exec = nullptr; }
@@ -845,7 +858,7 @@ int k22_unet_forward(K22UNet* u, const float* x, const float* timesteps, const f
   if (use_graph) {
     if (!u->graph_exec) {
       // warm-up eagerly once (sets function attributes), then capture
-      { int rc = u->run_ops(st); if (rc) return rc; }
+      if (!u->warmed) { int rc = u->run_ops_eager(st); if (rc) return rc; }
       hipGraph_t g = nullptr;
       if (!u->cap_stream) {
         e = hipStreamCreateWithFlags(&u->cap_stream, hipStreamNonBlocking);
@@ -864,7 +877,7 @@ int k22_unet_forward(K22UNet* u, const float* x, const float* timesteps, const f
     e = hipGraphLaunch(u->graph_exec, st);
     if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
   } else {
-    int rc = u->run_ops(st);
+    int rc = u->run_ops_eager(st);
     if (rc) return rc;
   }
   K22_CPY(out, u->ptr(u->s_out), (size_t)u->B * u->cfg.out_channels * hw * 4);
@@ -949,7 +962,8 @@ int k22_unet_sample_loop(K22UNet* u, float* x, float* x_tmp, const float* timest
   for (int k = 0; k < n_steps; ++k) key.push_back((unsigned long long)table_rows[k]);
   if (!u->loop_exec || key != u->loop_key) {
     if (u->loop_exec) { (void)hipGraphExecDestroy(u->loop_exec); u->loop_exec = nullptr; }
-    if (!u->graph_exec) {   // first forward of this plan: run one step's ops eagerly (function attributes, code load) on a scratch input
+    if (!u->warmed) {   // first forward of this plan: run one step's ops eagerly (function attributes, code load) on a scratch input; a re-capture
+                        // for other scalars / buffers (guidance, step count: they are baked into the graph's nodes) does not repeat it
       e = hipMemsetAsync(u->ptr(u->s_xin), 0, (size_t)B * 4 * HW * 4, st);
       if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
       e = hipMemcpyAsync(u->ptr(u->s_t), timesteps, (size_t)B * 4, hipMemcpyDeviceToDevice, st);
@@ -960,7 +974,7 @@ int k22_unet_sample_loop(K22UNet* u, float* x, float* x_tmp, const float* timest
         e = hipMemcpyAsync(u->ptr(u->s_mask), inpaint_mask, (size_t)B * HW * 4, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
       }
-      int rc = u->run_ops(st);
+      int rc = u->run_ops_eager(st);
       if (rc) return rc;
       e = hipStreamSynchronize(st);
       if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);

@@ -83,13 +83,28 @@ def launch_ranks(fn: Callable, world: int, args: Sequence = (), devices_visible:
     procs = [ctx.Process(target=_rank_entry, args=(r, world, port, fn, tuple(args))) for r in range(world)]
     for p in procs:
         p.start()
+    # ONE deadline for the whole job, all ranks polled together: the first rank that dies takes the others down at once (ranks that
+    # lose a peer block in their next RCCL collective and would otherwise be waited for one timeout each)
+    import time
+    deadline = time.monotonic() + timeout_s
     bad = []
-    for r, p in enumerate(procs):
-        p.join(timeout_s)
-        if p.is_alive():
-            p.terminate()
-            bad.append((r, "timeout"))
-        elif p.exitcode != 0:
-            bad.append((r, p.exitcode))
+    while True:
+        alive = [p for p in procs if p.is_alive()]
+        bad = [(r, p.exitcode) for r, p in enumerate(procs) if not p.is_alive() and p.exitcode != 0]
+        if bad or not alive:
+            break
+        if time.monotonic() > deadline:
+            bad = [(r, "timeout") for r, p in enumerate(procs) if p.is_alive()]
+            break
+        time.sleep(0.05)
     if bad:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        for p in procs:
+            p.join(10.0)
+            if p.is_alive():
+                p.kill()
         raise RuntimeError(f"launch_ranks: ranks failed: {bad}")
+    for p in procs:
+        p.join()

@@ -204,8 +204,10 @@ class Kandinsky2_1HIP:
 
         ms = self.config["prior"]["clip_mean_std_path"]
         clip_mean, clip_std = _load(ms) if isinstance(ms, (str, os.PathLike)) else ms
+        # the split-precision arithmetic ("f16x3") exists in the UNet engine only: beside it the prior (and MoVQ below) run their fp32 parity path
+        aux_dtype = torch.float32 if isinstance(backend_dtype, str) else backend_dtype
         self.prior = PriorDiffusionModelHIP(hp, self.config["prior"]["params"]["diffusion"], clip_mean.reshape(-1), clip_std.reshape(-1),
-                                            backend_dtype=backend_dtype)
+                                            backend_dtype=aux_dtype)
         self.prior.load_state_dict(_load(prior_path), strict=False)
         self.prior = self.prior.to(device)
 
@@ -219,7 +221,7 @@ class Kandinsky2_1HIP:
         # parity path) decode in fp32 - uint8 image within ONE grey level of the reference's fp32 decode; 16-bit engines (the product path) decode
         # in fp16 - within 3 grey levels, 88 % of the bytes identical, at 12 ms instead of 53 (bf16 would move pixels by up to 24 levels, which
         # is why a bf16 UNet still gets an fp16 MoVQ; tests/test_movq_gpu.py, profiles/r03_movq_precision.txt).
-        self.movq_dtype = (torch.float32 if backend_dtype == torch.float32 else torch.float16) if movq_dtype is None else movq_dtype
+        self.movq_dtype = (torch.float32 if aux_dtype == torch.float32 else torch.float16) if movq_dtype is None else movq_dtype
         self.image_encoder = _MoVQ(ie["params"], movq_sd, self.movq_dtype, device)
 
         self.model = Text2ImUNetHIP(make_arch(mcfg, inpainting=mcfg["inpainting"]), backend_dtype=backend_dtype, use_graph=use_graph,
@@ -414,10 +416,15 @@ class _MoVQ:
         return self
 
 
-def _conditioner_from_cache_dir(cache_dir, device, backend_dtype):
+def _conditioner_from_cache_dir(cache_dir, device, backend_dtype, tokenizer2=None):
     """The encoders Kandinsky2_1.__init__ builds (kandinsky2_1_model.py:57-66; files as kandinsky2/__init__.py:124-160 stores them):
     cache_dir/text_encoder (XLM-R tokenizer + pytorch_model.bin of MultilingualCLIP) and cache_dir/ViT-L-14.pt, on the HIP encoder
-    engine.  Raises - never substitutes seeded noise - when a file or a tokenizer dependency is missing."""
+    engine.  tokenizer2 = the CLIP byte-pair tokenizer OBJECT (what the reference builds as kandinsky2.model.prior.CustomizedTokenizer():
+    callable as tokenizer2.padded_tokens_and_mask(...)): string processing on the host is out of this package's scope, so the caller
+    hands it in - the product path imports nothing from the reference package.  Raises - never substitutes seeded noise - when a file
+    or the tokenizer is missing."""
+    if isinstance(backend_dtype, str):
+        backend_dtype = torch.float32   # the split-precision arithmetic exists in the UNet engine only
     from .encoders import CLIPModelHIP, HIPConditioner, TextEncoderHIP
     te_dir, clip_pt = os.path.join(cache_dir, "text_encoder"), os.path.join(cache_dir, "ViT-L-14.pt")
     missing = [p for p in (os.path.join(te_dir, "pytorch_model.bin"), clip_pt) if not os.path.exists(p)]
@@ -426,12 +433,10 @@ def _conditioner_from_cache_dir(cache_dir, device, backend_dtype):
                                 "(conditioner='seeded' is the offline benchmark stand-in)")
     from transformers import AutoTokenizer
     tokenizer1 = AutoTokenizer.from_pretrained(te_dir)
-    try:
-        from kandinsky2.model.prior import CustomizedTokenizer   # the reference's own BPE wrapper (needs the `clip` package)
-        tokenizer2 = CustomizedTokenizer()
-    except Exception as e:  # noqa: BLE001
-        raise RuntimeError("the CLIP BPE tokenizer (kandinsky2.model.prior.CustomizedTokenizer, which needs OpenAI `clip`) is not "
-                           "importable; pass conditioner=HIPConditioner(..., tokenizer2=...) explicitly") from e
+    if tokenizer2 is None:
+        raise ValueError("get_kandinsky2(..., cache_dir=) builds the encoders itself but needs the CLIP byte-pair tokenizer object: pass "
+                         "tokenizer2=kandinsky2.model.prior.CustomizedTokenizer() (the reference's wrapper around OpenAI clip's BPE), or a "
+                         "ready conditioner=HIPConditioner(text_encoder, tokenizer1, tokenizer2, clip_model)")
     clip_sd = torch.jit.load(clip_pt, map_location="cpu").state_dict()   # the OpenAI checkpoint is a TorchScript archive (clip.load)
     clip_model = CLIPModelHIP(backend_dtype=backend_dtype)
     clip_model.load_state_dict({k: v.float() for k, v in clip_sd.items() if k in clip_model.state_dict()}, strict=True)
@@ -442,7 +447,7 @@ def _conditioner_from_cache_dir(cache_dir, device, backend_dtype):
 
 def get_kandinsky2(device, task_type="text2img", cache_dir="/tmp/kandinsky2", use_auth_token=None, model_version="2.1",
                    use_flash_attention=False, *, conditioner=None, backend_dtype: torch.dtype = torch.bfloat16, use_graph: bool = True,
-                   movq_dtype: Optional[torch.dtype] = None):
+                   movq_dtype: Optional[torch.dtype] = None, tokenizer2=None):
     """`get_kandinsky2` (kandinsky2/__init__.py:164-192) for the HIP engines.  The reference downloads the checkpoints into
     cache_dir (kandinsky2/__init__.py:100-160); this box-local variant reads the same file names from cache_dir and raises if
     they are not there (there is no download path).  use_flash_attention is accepted and ignored: attention always runs in the
@@ -459,7 +464,7 @@ def get_kandinsky2(device, task_type="text2img", cache_dir="/tmp/kandinsky2", us
         config["prior"]["clip_mean_std_path"] = need["ViT-L-14_stats.th"]
         config["image_enc_params"]["ckpt_path"] = need["movq_final.ckpt"]
         if conditioner is None:
-            conditioner = _conditioner_from_cache_dir(cache_dir, device, backend_dtype)
+            conditioner = _conditioner_from_cache_dir(cache_dir, device, backend_dtype, tokenizer2)
         return Kandinsky2_1HIP(config, need[model_name], need["prior_fp16.ckpt"], device, task_type=task_type, conditioner=conditioner,
                                backend_dtype=backend_dtype, use_graph=use_graph, movq_dtype=movq_dtype)
     if model_version == "2.2":

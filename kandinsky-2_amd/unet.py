@@ -69,9 +69,7 @@ class Text2ImUNetHIP(nn.Module):
         (fp32 accumulation, GroupNorm statistics, softmax and sampler state stay fp32, as in the reference's fp16 mode).  An engine
         built with backend_dtype=torch.float32 is the parity path and stays fp32 until convert_to_fp16() is asked for explicitly."""
         if self.backend_dtype != torch.float16:
-            if getattr(self, "_adopted", False) and not any(p.numel() for p in self.parameters()):
-                raise RuntimeError("convert_to_fp16: the fp32 parameters were released (prepare(free_params=True)); construct with "
-                                   "backend_dtype=torch.float16 instead")
+            self._need_fp32_params("convert_to_fp16", "backend_dtype=torch.float16")
             self.backend_dtype = torch.float16
             self._release()   # re-pack lazily in fp16
         return self
@@ -79,11 +77,18 @@ class Text2ImUNetHIP(nn.Module):
     def convert_to_fp32(self):
         """unet.py:574-580: back to the fp32 parity path"""
         if self.backend_dtype != torch.float32:
-            if getattr(self, "_adopted", False) and not any(p.numel() for p in self.parameters()):
-                raise RuntimeError("convert_to_fp32: the fp32 parameters were released (prepare(free_params=True))")
+            self._need_fp32_params("convert_to_fp32", "backend_dtype=torch.float32")
             self.backend_dtype = torch.float32
             self._release()
         return self
+
+    def _need_fp32_params(self, what: str, ctor_hint: str):
+        """A dtype change re-packs the arena from the fp32 parameters: refuse when they are gone (released after packing, never
+        materialised - meta_params - or replaced by an arena adopted from a broadcast), instead of dropping a working engine."""
+        ps = list(self.parameters())
+        if any(p.is_meta for p in ps) or (getattr(self, "_adopted", False) and not any(p.numel() for p in ps)) or getattr(self, "_arena_adopted", False):
+            raise RuntimeError(f"{what}: this module has no fp32 parameters to re-pack from (prepare(free_params=True), meta_params=True or "
+                               f"an adopted / broadcast arena); construct it with {ctor_hint} instead")
 
     def del_cache(self):
         self.cache = None
@@ -133,6 +138,7 @@ class Text2ImUNetHIP(nn.Module):
             raise RuntimeError("Text2ImUNetHIP runs on the GPU only (no CPU fallback): move it with .to('cuda')")
         L = _lib.lib()
         self._release()
+        self._arena_adopted = arena is not None
         if arena is None:
             arena, table = pack_arena(self.arch, self.state_dict(), self.backend_dtype, dev)
         else:
