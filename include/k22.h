@@ -255,6 +255,15 @@ int k22_gemm_gnstats(const void* A, const void* Wp, const float* bias, const voi
  * MFMA was issued).  tools/conv_trace.py prints the per-phase cycle budget. */
 int k22_debug_conv_trace(const void* x_padded, const void* Wp, const float* bias, void* out, int B, int H, int W, int Cin, int Cout,
                          int Npad, unsigned long long* trace, void* stream);
+/* Fused form of k22_groupnorm + k22_conv3x3 (round 4; north_star: "ResBlock conv3x3 / GroupNorm / SiLU fused with LDS-staged input tiles"):
+ * out = conv3x3(act(GroupNorm32(cat(x0, x1)) [*(1 + scale) + shift])) + bias + residual, kandinsky2/model/nn.py:26-37 + unet.py:150-152,
+ * 174-180, 212-216.  The convolution (conv3_halo_spec_kernel: algo 11 / 12) reads the RAW unpadded NHWC tensors; its producer waves apply
+ * the per-channel coefficients (and the zero border) to the halo tile in the LDS right after the LDS-DMA lands: no normalised copy of the
+ * activation is written or read.  x0 [B][H][W][C0] (+ x1 [B][H][W][C1]) of the engine's storage type (fp32 for K22_F16X3), Wp packed as
+ * for k22_conv3x3, film as for k22_groupnorm; scratch >= k22_groupnorm_scratch_bytes(B, C0 + C1).  Same bits as the two-call form. */
+int k22_conv3x3_gn(const void* x0, const void* x1, int C0, int C1, const float* gamma, const float* beta, const float* film, long film_ld,
+                   float eps, int act, void* scratch, const void* Wp, const float* bias, const void* residual, void* out, void* partial,
+                   int B, int H, int W, int Cout, int Npad, int splitk, int bm, int algo, int dtype, void* stream);
 /* GroupNorm32 (+FiLM, +activation, +resample, +zero border as k22_groupnorm) of ONE tensor whose per-group sums are already
  * known (accumulated by the producing conv / GEMM, see above, fixed point): a single pass, no statistics or coefficient kernel.
  * C a multiple of 32, at most 3072. */

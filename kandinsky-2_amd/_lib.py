@@ -122,6 +122,7 @@ SIGNATURES = {
     "k22_gemm_gnstats": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, C.POINTER(_I), _P, _I, _P]),
     "k22_groupnorm_from_group_sums": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _L, _F, _I, _I, _I, _P, _I, _P]),
     "k22_conv3x3_gnstats": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, C.POINTER(_I), _P, _I, _P]),
+    "k22_conv3x3_gn": (_I, [_P, _P, _I, _I, _P, _P, _P, _L, _F, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "k22_debug_conv_trace": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "k22_groupnorm": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _L, _F, _I, _I, _I, _P, _P, _I, _P]),
     "k22_groupnorm_scratch_bytes": (_Z, [_I, _I]),

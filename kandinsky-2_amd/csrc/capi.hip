@@ -268,6 +268,36 @@ int k22_groupnorm(const void* x0, const void* x1, int C0, int C1, int B, int H, 
   return launch_gn_apply(ap, dtype, st);
 }
 
+// conv3x3(GroupNorm32(cat(x0, x1)) [*(1 + scale) + shift] -> act) with the GroupNorm-apply FUSED into the convolution's halo fill
+// (conv3_halo_spec_kernel, IgemmParams::gn_coeff): statistics pass + coefficient kernel, then ONE convolution launch that reads the raw
+// tensors.  algo = 11 / 12 (the specialised kernels).  scratch: k22_groupnorm_scratch_bytes(B, C0 + C1).
+int k22_conv3x3_gn(const void* x0, const void* x1, int C0, int C1, const float* gamma, const float* beta, const float* film, long film_ld,
+                   float eps, int act, void* scratch, const void* Wp, const float* bias, const void* residual, void* out, void* partial,
+                   int B, int H, int W, int Cout, int Npad, int splitk, int bm, int algo, int dtype, void* stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int C = C0 + C1, HW = H * W;
+  const int sdt = k22_storage_dtype(dtype);
+  const int nsplit = gn_nsplit(B, HW);
+  float* part = reinterpret_cast<float*>(scratch);
+  float* coeff = part + (size_t)B * 128 * C * 2;
+  GnStatsParams sp;
+  sp.x0 = x0; sp.x1 = x1; sp.C0 = C0; sp.C1 = C1; sp.HW = HW; sp.B = B; sp.groups = 32; sp.nsplit = nsplit; sp.partial = part;
+  int rc = launch_gn_stats(sp, sdt, st);
+  if (rc) return rc;
+  GnCoeffParams cp = {};
+  cp.src[0].st = part; cp.src[0].rpi = nsplit; cp.src[0].C = C;
+  cp.HW = HW; cp.C = C; cp.groups = 32; cp.eps = eps; cp.gamma = gamma; cp.beta = beta; cp.film = film; cp.film_ld = film_ld; cp.coeff = coeff;
+  rc = launch_gn_coeff(cp, B, st);
+  if (rc) return rc;
+  IgemmParams p = {};
+  p.stages = -1;
+  p.Wp = Wp; p.bias = bias; p.residual = residual; p.out = out; p.partial = reinterpret_cast<float*>(partial);
+  p.M = B * H * W; p.N = Cout; p.Npad = Npad; p.Kc = C; p.K0 = C; p.taps = 9; p.H = H; p.W = W;
+  p.ldo = Cout; p.ldr = Cout; p.out_mode = IG_OUT_ROWMAJOR; p.act = K22_ACT_NONE; p.splitk = splitk > 0 ? splitk : 1; p.force_bm = bm; p.algo = algo;
+  p.gn_coeff = coeff; p.gn_x0 = x0; p.gn_x1 = x1; p.gn_C0 = C0; p.gn_act = act;
+  return launch_igemm(p, dtype, st);
+}
+
 int k22_groupnorm_from_group_sums(const void* x, int C, int B, int H, int W, const long long* group_sums, const float* gamma,
                                   const float* beta, const float* film, long film_ld, float eps, int act, int mode, int pad,
                                   void* out, int dtype, void* stream) {

@@ -69,11 +69,21 @@ template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float f) { return (
 template <> __device__ __forceinline__ float from_f32<float>(float f) { return f; }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// SiLU from the two native transcendentals, x * rcp(1 + exp2(-x * log2 e)): ~3 ulp of fp32 in 6 instructions.  The IEEE form above
+// (precise expf + a true division) compiles to ~55 instructions per element: it made gn_apply_kernel VALU-bound (round 4: 58 VALU
+// per element in the ISA) and is unaffordable inside an MFMA kernel.  Used wherever the result is rounded to a 16-bit type or
+// split into fp16 halves right away (bf16 / fp16 / split-precision engines); the plain fp32 engine keeps the IEEE form.
+__device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float apply_act(float x, int act) {
   if (act == K22_ACT_SILU) return silu_f(x);
   if (act == K22_ACT_GELU) return gelu_f(x);
   return x;
+}
+// FAST: SiLU through silu_fast (see above); everything else as apply_act
+template <bool FAST> __device__ __forceinline__ float apply_act_sel(float x, int act) {
+  if constexpr (FAST) { if (act == K22_ACT_SILU) return silu_fast(x); }
+  return apply_act(x, act);
 }
 
 // ---- split-precision operand format ("x3 chunk") ------------------------------------------------------------------------------

@@ -29,384 +29,13 @@
 //   * optional fused 1x1 skip_connection of the ResBlock (out += x . Ws^T): a second, plain-GEMM K loop over the
 //     block input's channels (A rows = the tile's own pixels, no halo) that accumulates into the same registers,
 //     so the skip tensor is never written, re-read or launched separately
-#include "kernels.h"
-#include <stdlib.h>
+#include "conv3_common.h"
 
-namespace {
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-__device__ __forceinline__ void ld_frag_at(Frag<bf16_t>& f, const char* rowp, int sw, int ks, int h) {
-  f.v = *reinterpret_cast<const u32x4_t*>(rowp + (((2 * ks + h) ^ sw) << 4));
-}
-__device__ __forceinline__ void ld_frag_at(Frag<f16_t>& f, const char* rowp, int sw, int ks, int h) {
-  f.v = *reinterpret_cast<const u32x4_t*>(rowp + (((2 * ks + h) ^ sw) << 4));
-}
-__device__ __forceinline__ void ld_frag_at(Frag<float>& f, const char* rowp, int sw, int ks, int h) {
-  const float4 a = *reinterpret_cast<const float4*>(rowp + (((4 * ks + 2 * h) ^ sw) << 4));
-  const float4 b = *reinterpret_cast<const float4*>(rowp + (((4 * ks + 2 * h + 1) ^ sw) << 4));
-  f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
-  f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
-}
-
-// split precision: the operand is in x3 chunks (weights; activations written by gn_apply / the attention epilogue)
-__device__ __forceinline__ void ld_frag_at(Frag<x3_t>& f, const char* rowp, int sw, int ks, int h) {
-  x3_frag_from_chunks(f, *reinterpret_cast<const u32x4_t*>(rowp + (((4 * ks + 2 * h) ^ sw) << 4)),
-                      *reinterpret_cast<const u32x4_t*>(rowp + (((4 * ks + 2 * h + 1) ^ sw) << 4)));
-}
-// RAW operands (x3 arithmetic only): plain fp32 rows in the LDS, split while they are read; every other type = ld_frag_at
-template <bool RAW, typename T> __device__ __forceinline__ void ld_frag_at_a(Frag<T>& f, const char* rowp, int sw, int ks, int h) {
-  if constexpr (RAW && is_x3<T>::value) {
-    x3_frag_from_f32(f, *reinterpret_cast<const float4*>(rowp + (((4 * ks + 2 * h) ^ sw) << 4)),
-                     *reinterpret_cast<const float4*>(rowp + (((4 * ks + 2 * h + 1) ^ sw) << 4)));
-  } else {
-    ld_frag_at(f, rowp, sw, ks, h);
-  }
-}
-
-template <typename T> __device__ __forceinline__ void store8(T* dst, const float* v);
-template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* dst, const float* v) {
-  uint4 w;
-  w.x = pack2_bf16(v[0], v[1]);
-  w.y = pack2_bf16(v[2], v[3]);
-  w.z = pack2_bf16(v[4], v[5]);
-  w.w = pack2_bf16(v[6], v[7]);
-  *reinterpret_cast<uint4*>(dst) = w;
-}
-template <> __device__ __forceinline__ void store8<f16_t>(f16_t* dst, const float* v) {
-  uint4 w;
-  w.x = pack2_f16(v[0], v[1]);
-  w.y = pack2_f16(v[2], v[3]);
-  w.z = pack2_f16(v[4], v[5]);
-  w.w = pack2_f16(v[6], v[7]);
-  *reinterpret_cast<uint4*>(dst) = w;
-}
-template <> __device__ __forceinline__ void store8<float>(float* dst, const float* v) {
-  *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-  *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
-}
-template <> __device__ __forceinline__ void store8<x3_t>(x3_t* dst, const float* v) { store8<float>(reinterpret_cast<float*>(dst), v); }
-template <typename T> __device__ __forceinline__ void load8f(const T* src, float* v);
-template <> __device__ __forceinline__ void load8f<bf16_t>(const bf16_t* src, float* v) {
-  const uint4 r = *reinterpret_cast<const uint4*>(src);
-  v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
-  v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
-  v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
-  v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
-}
-template <> __device__ __forceinline__ void load8f<f16_t>(const f16_t* src, float* v) {
-  const uint4 r = *reinterpret_cast<const uint4*>(src);
-  unpack2_f16(r.x, v[0], v[1]); unpack2_f16(r.y, v[2], v[3]); unpack2_f16(r.z, v[4], v[5]); unpack2_f16(r.w, v[6], v[7]);
-}
-template <> __device__ __forceinline__ void load8f<float>(const float* src, float* v) {
-  const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
-  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-}
-template <> __device__ __forceinline__ void load8f<x3_t>(const x3_t* src, float* v) { load8f<float>(reinterpret_cast<const float*>(src), v); }
-// value as it will be read back from memory (the GroupNorm statistics are those of the stored tensor)
-template <typename T> __device__ __forceinline__ float stored(float v);
-template <> __device__ __forceinline__ float stored<bf16_t>(float v) { return bf16_to_f32(f32_to_bf16(v)); }
-template <> __device__ __forceinline__ float stored<f16_t>(float v) { return (float)(f16_t)v; }
-template <> __device__ __forceinline__ float stored<float>(float v) { return v; }
-template <> __device__ __forceinline__ float stored<x3_t>(float v) { return v; }
-
-__device__ __forceinline__ int xcd_remap_h(int bid, int nblocks) {
-  const int q = nblocks >> 3, r = nblocks & 7, x = bid & 7;
-  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-}
-
-// LDS-DMA issued from inline asm: 16 bytes per lane from `g` to LDS byte address `lds_dst` (wave-uniform) + 16*lane.
-// hipcc books a __builtin_amdgcn_global_load_lds as a FLAT access pending on BOTH counters, and because the counted
-// vmcnt waits of this file are invisible to it, every later wait for a ds_read becomes lgkmcnt(0) - also for fragments
-// read a whole MFMA group ago, with younger reads still in flight.  An asm statement is absent from its bookkeeping:
-// the compiler then emits exact lgkmcnt(N) for the fragment reads; completion of the DMA is counted by hand anyway.
-__device__ __forceinline__ void glds16_asm(const void* g, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
-}
-
-constexpr int HALO_BN = 128;
-constexpr int HALO_NW = 8;        // waves per workgroup
-constexpr int HALO_MAXA = 8;      // halo LDS-DMA slots per wave per slab: taps 0 .. 9-NBST carry one each
-
-// Each iteration issues [weight tile NBST-1 taps ahead (2 loads)] THEN [one halo piece]: the halo piece is the
-// youngest entry of the VMEM queue, so the counted wait for the weight tile can leave it in flight — it gets two
-// taps (~1.6 us at 96x96) to come back from the Infinity Cache / HBM instead of one.  This is the number of halo
-// pieces issued in the NBST-1 iterations before tap T, i.e. younger than the weight tile tap T needs; taps are
-// unrolled, so it is a compile-time constant.
-template <int NBST> constexpr int halo_count_a(int t) {
-  int c = 0;
-  for (int k = 1; k <= NBST - 1; ++k) {
-    const int u = t - k;
-    if (u >= 0 && u <= 9 - NBST) ++c;
-  }
-  return c;
-}
-
-}  // namespace
-
-// Everything after the 3x3 K loop, shared by the halo kernels: optional fused 1x1 skip connection (a plain-GEMM K loop
-// on 128-byte rows), then the epilogue through LDS (bias, residual, one rounding, 16-byte stores, GroupNorm partials).
-// PLAIN = false: rows are positions v of the padded plane (3x3 convolution); PLAIN = true: rows are the pixels
-// v < H*W of image `img` themselves (gemm8_kernel), and the qkv-projection output mode is available.
-// SPEC = true (conv3_halo_spec_kernel): only waves 0-3 hold accumulators, 2 x 2 over the tile with (BM/2) x 64 each; waves 4-7
-// were the producers of the main loop.  All eight waves issue the skip loop's LDS-DMA and run the store / statistics epilogue.
-template <typename T, int BM, bool PLAIN = false, bool SPEC = false>
-__device__ __forceinline__ void halo_tail(const IgemmParams& p, f32x16_t (&acc)[SPEC ? BM / 64 : BM / 128][2], char* smem, int bx, int bz, int img, int v0, int n0) {
-  using TR = TT<T>;
-  constexpr int BK = TR::BK, EPC = TR::EPC, KSTEPS = TR::KSTEPS;
-  constexpr int BN = HALO_BN, NW = HALO_NW, WM = SPEC ? 2 : 4, WN = 2;
-  constexpr int MI = BM / (WM * 32), NI = BN / (WN * 32);
-  constexpr int B_SLOTS = BN / 8 / NW;
-  constexpr int B_BYTES = BN * 128;
-  constexpr int TS = BN * 4 + 16;       // epilogue tile row stride (bytes): conflict-free float4 writes
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const bool cw = !SPEC || wave < 4;      // this wave holds accumulators (wave-uniform)
-  const int h = lane >> 5, l31 = lane & 31;
-  const int W2 = PLAIN ? 1 : p.W + 2;
-  const int VR = PLAIN ? (p.H > 0 ? p.H * p.W : p.M) : p.H * W2;
-  const int abase = wm * (BM / WM) + l31;
-  int brow[NI];
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) brow[ni] = (wn * (BN / WN) + ni * 32 + l31) * 128;
-  const int bsw = (l31 >> 1) & 7;
-
-  // ---- fused 1x1 skip connection: acc += X[tile pixels][SK] . Ws[n][SK]^T, 2-stage LDS-DMA pipeline ----------
-  if (p.S0 != nullptr) {
-    const int SK = p.SK0 + p.SK1;
-    const int nss = SK / BK;
-    const int sp = p.splitk > 1 ? p.splitk : 1;
-    const int q0 = nss * bz / sp, q1 = nss * (bz + 1) / sp;
-    if (q0 < q1) {
-      constexpr int SA_SLOTS = BM / 8 / NW;             // input-tile LDS-DMA instructions per wave per slab
-      constexpr int SBUF = BM * 128 + B_BYTES;
-      wait_vmcnt<0>();
-      __syncthreads();                                   // main-loop buffers are free
-      int spix[SA_SLOTS], schunk[SA_SLOTS];
-#pragma unroll
-      for (int i = 0; i < SA_SLOTS; ++i) {
-        const int row = 8 * (wave + NW * i) + (lane >> 3);
-        int v = v0 + row;
-        if (v > VR - 1) v = VR - 1;
-        const int y = v / W2;
-        int x = v - y * W2;
-        if (x > p.W - 1) x = p.W - 1;                    // junk columns read a valid pixel; their rows are dropped
-        spix[i] = (img * p.H + y) * p.W + x;
-        schunk[i] = ((lane & 7) ^ ((row >> 1) & 7)) * EPC;
-      }
-      int wsoff[B_SLOTS];
-#pragma unroll
-      for (int i = 0; i < B_SLOTS; ++i) {
-        const int row = 8 * (wave + NW * i) + (lane >> 3);
-        int n = n0 + row;
-        if (n > p.Npad - 1) n = p.Npad - 1;
-        wsoff[i] = n * SK + ((lane & 7) ^ ((row >> 1) & 7)) * EPC;
-      }
-      const T* __restrict__ X0 = reinterpret_cast<const T*>(p.S0);
-      const T* __restrict__ X1 = reinterpret_cast<const T*>(p.S1);
-      const T* __restrict__ Ws = reinterpret_cast<const T*>(p.Ws);
-#define K22_ISSUE_SKIP(Q, BUFI)                                                                            \
-      {                                                                                                    \
-        const int k0_ = (Q) * BK;                                                                          \
-        const bool second_ = k0_ >= p.SK0;                                                                 \
-        const T* xs_ = second_ ? X1 : X0;                                                                  \
-        const int ldx_ = second_ ? p.SK1 : p.SK0;                                                          \
-        const int kk_ = second_ ? k0_ - p.SK0 : k0_;                                                       \
-        char* dA_ = smem + (BUFI) * SBUF + wave * 1024;                                                    \
-        _Pragma("unroll") for (int i = 0; i < SA_SLOTS; ++i)                                               \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs_ + (int64_t)spix[i] * ldx_ + kk_ + schunk[i]), \
-                                             (__attribute__((address_space(3))) void*)(dA_ + i * NW * 1024), 16, 0, 0); \
-        char* dB_ = smem + (BUFI) * SBUF + BM * 128 + wave * 1024;                                         \
-        _Pragma("unroll") for (int i = 0; i < B_SLOTS; ++i)                                                \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ws + wsoff[i] + k0_), \
-                                             (__attribute__((address_space(3))) void*)(dB_ + i * NW * 1024), 16, 0, 0); \
-      }
-      K22_ISSUE_SKIP(q0, 0);
-      int buf = 0;
-      for (int q = q0; q < q1; ++q) {
-        wait_vmcnt<0>();
-        raw_barrier();
-        if (q + 1 < q1) K22_ISSUE_SKIP(q + 1, buf ^ 1);
-        const char* sA = smem + buf * SBUF;
-        const char* sB = sA + BM * 128;
-        if (cw) {
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-          Frag<T> a[MI], b[NI];
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) ld_frag_at_a<true>(a[mi], sA + (abase + mi * 32) * 128, bsw, ks, h);   // S0 / S1: plain T rows
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) ld_frag_at(b[ni], sB + brow[ni], bsw, ks, h);
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], b[ni], a[mi]);
-        }
-        }
-        buf ^= 1;
-      }
-#undef K22_ISSUE_SKIP
-    }
-  }
-  wait_vmcnt<0>();
-  __syncthreads();  // every wave is done with the operand buffers: the LDS becomes the fp32 output tile
-
-  // ---- epilogue 1: accumulators -> LDS tile [BM][BN] fp32 (lane = pixel, 4 consecutive channels per quad) ----
-  if (cw)
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    const int row = wm * (BM / WM) + mi * 32 + l31;
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int col = wn * (BN / WN) + ni * 32 + 8 * j + 4 * h;
-        *reinterpret_cast<float4*>(smem + row * TS + col * 4) =
-            make_float4(acc_unscale<T>(acc[mi][ni][4 * j]), acc_unscale<T>(acc[mi][ni][4 * j + 1]), acc_unscale<T>(acc[mi][ni][4 * j + 2]),
-                        acc_unscale<T>(acc[mi][ni][4 * j + 3]));
-      }
-  }
-  __syncthreads();
-
-  // ---- qkv projection, n-tile inside v (an n-tile never straddles q / k / v): V^T_all wants the tile transposed.
-  // lane = token (consecutive lanes -> consecutive addresses of one V^T row), 4 channels per LDS read
-  if constexpr (PLAIN) {
-    if (p.out_mode == IG_OUT_QKV && n0 >= 2 * (p.N / 3)) {
-      const int C = p.N / 3, heads = C >> 6;
-      constexpr int CPG = BN / (512 / BM);   // channels per thread group
-      const int r = tid % BM, cg = tid / BM;
-      const int v = v0 + r;
-      if (v < VR) {
-#pragma unroll 4
-        for (int c4 = 0; c4 < CPG; c4 += 4) {
-          const int col = cg * CPG + c4, n = n0 + col;
-          if (n >= p.N) break;
-          const float4 t = *reinterpret_cast<const float4*>(smem + r * TS + col * 4);
-          float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (p.bias != nullptr) b = *reinterpret_cast<const float4*>(p.bias + n);
-          const int c = n - 2 * C, head = c >> 6, d = c & 63;
-          T* vt = reinterpret_cast<T*>(p.vtall) + ((int64_t)(img * heads + head) * 64 + d) * p.att_Tkp + p.att_S + v;
-          vt[0] = from_f32<T>(t.x + b.x);
-          vt[(int64_t)p.att_Tkp] = from_f32<T>(t.y + b.y);
-          vt[(int64_t)2 * p.att_Tkp] = from_f32<T>(t.z + b.z);
-          vt[(int64_t)3 * p.att_Tkp] = from_f32<T>(t.w + b.w);
-        }
-      }
-      return;
-    }
-  }
-
-  // ---- epilogue 2: thread = 8 channels x RPT consecutive rows -------------------------------------------
-  constexpr int SEGS = BN / 8;            // 16 column segments
-  constexpr int RGS = 512 / SEGS;         // 32 row groups
-  constexpr int RPT = BM / RGS;           // rows per thread
-  const int cs = tid % SEGS, rg = tid / SEGS;
-  const int n = n0 + cs * 8;
-  const bool n_ok = n < p.N;              // N % 8 == 0 (checked on the host)
-  float bias8[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
-  const bool finish = (p.splitk <= 1);
-  if (finish && n_ok && p.bias != nullptr) {
-    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
-    bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
-    bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
-  }
-  if (finish && n_ok && p.bias2 != nullptr) {
-    const float4 b0 = *reinterpret_cast<const float4*>(p.bias2 + n), b1 = *reinterpret_cast<const float4*>(p.bias2 + n + 4);
-    bias8[0] += b0.x; bias8[1] += b0.y; bias8[2] += b0.z; bias8[3] += b0.w;
-    bias8[4] += b1.x; bias8[5] += b1.y; bias8[6] += b1.z; bias8[7] += b1.w;
-  }
-  const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
-  float* part = finish ? nullptr : p.partial + (int64_t)bz * p.M * p.N;
-  float ssum[8], ssq[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
-#pragma unroll
-  for (int k = 0; k < RPT; ++k) {
-    const int row = rg * RPT + k;
-    const int v = v0 + row;
-    int64_t m;
-    if constexpr (PLAIN) {
-      if (!n_ok || v >= VR) continue;
-      m = (int64_t)img * VR + v;
-    } else {
-      const int y = v / W2, x = v - y * W2;
-      if (!n_ok || v >= VR || x >= p.W) continue;
-      m = ((int64_t)img * p.H + y) * p.W + x;
-    }
-    const float4 t0 = *reinterpret_cast<const float4*>(smem + row * TS + cs * 32);
-    const float4 t1 = *reinterpret_cast<const float4*>(smem + row * TS + cs * 32 + 16);
-    float val[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-    if (!finish) {
-      *reinterpret_cast<float4*>(part + m * p.N + n) = t0;
-      *reinterpret_cast<float4*>(part + m * p.N + n + 4) = t1;
-      continue;
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) val[e] += bias8[e];
-    if (res != nullptr) {
-      float rv[8];
-      load8f<T>(res + m * p.ldr + n, rv);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) val[e] += rv[e];
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) val[e] = apply_act(val[e], p.act);
-    if (PLAIN && p.out_mode == IG_OUT_QKV) {
-      // columns [q | k | v] x [heads][64]: q row-major, k behind the context keys of K_all, v transposed into V^T_all
-      const int C = p.N / 3, heads = C >> 6;
-      const int which = n / C, c = n - which * C;
-      const int head = c >> 6, d = c & 63;
-      if (which == 0) {
-        store8<T>(reinterpret_cast<T*>(p.out) + m * p.ldo + c, val);
-      } else if (which == 1) {
-        store8<T>(reinterpret_cast<T*>(p.kall) + ((int64_t)(img * heads + head) * p.att_Tkp + p.att_S + v) * 64 + d, val);
-      } else {
-        T* vt = reinterpret_cast<T*>(p.vtall) + ((int64_t)(img * heads + head) * 64 + d) * p.att_Tkp + p.att_S + v;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) vt[(int64_t)e * p.att_Tkp] = from_f32<T>(val[e]);
-      }
-      continue;
-    }
-    if (p.out_mode == IG_OUT_ROWMAJOR) store8<T>(reinterpret_cast<T*>(p.out) + m * p.ldo + n, val);
-    else store8<float>(reinterpret_cast<float*>(p.out) + m * p.ldo + n, val);
-    if (p.stats != nullptr || p.gsum != nullptr) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float sv = (p.out_mode == IG_OUT_ROWMAJOR) ? stored<T>(val[e]) : val[e];
-        ssum[e] += sv;
-        ssq[e] += sv * sv;
-      }
-    }
-  }
-  if (!finish || (p.stats == nullptr && p.gsum == nullptr)) return;
-
-  // ---- epilogue 3: per-channel (sum, sumsq) of this tile's stored values, fixed-order reduction ---------
-  __syncthreads();  // tile fully consumed
-  float* red = reinterpret_cast<float*>(smem);  // [RGS][BN][2]
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    *reinterpret_cast<float2*>(red + ((rg * BN) + cs * 8 + e) * 2) = make_float2(ssum[e], ssq[e]);
-  }
-  __syncthreads();
-  float* chs = reinterpret_cast<float*>(smem + 40 * 1024);   // [BN][2], past red[RGS][BN][2] (32 KB)
-  if (tid < BN * 2) {
-    const int ch = tid >> 1, which = tid & 1;
-    float a = 0.f;
-#pragma unroll 8
-    for (int r = 0; r < RGS; ++r) a += red[((r * BN) + ch) * 2 + which];
-    if (n0 + ch < p.N && p.stats != nullptr) p.stats[((int64_t)bx * p.N + n0 + ch) * 2 + which] = a;
-    chs[tid] = a;
-  }
-  if (p.gsum != nullptr) {
-    __syncthreads();
-    gn_add_group_sums(chs, p.gsum, img, p.N, n0, (p.N - n0 < BN ? p.N - n0 : BN));
-  }
-}
+// conv3_spec.hip
+int launch_conv3_halo_spec(const IgemmParams& p, int dtype, int bm, int nbst, int splitk, hipStream_t stream);
+#ifdef K22_DEBUG_VARIANTS
+int launch_conv3_halo_spec_debug(const IgemmParams& p, int nbst, int splitk, hipStream_t stream);
+#endif
 
 // LW = number of waves that issue the LDS-DMA (the "loader" waves 0 .. LW-1):
 //   LW = 8: every wave loads its share right after the barrier (3 pieces per wave per tap);
@@ -652,247 +281,6 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const IgemmParams p) {
       for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], pb[ni], pa[mi]);
   }
   halo_tail<T, BM>(p, acc, smem, bx, bz, img, v0, n0);
-}
-
-// ================================================================================================================
-// conv3_halo_spec_kernel (p.algo == 11 / 12): the same tile, LDS images and epilogue with the eight waves SPECIALISED.
-//   waves 0-3 ("consumers", one per SIMD): 2 x 2 over the BM x 128 tile, (BM/2) x 64 per wave (BM = 256: 128 x 64 = 8
-//              accumulators, 6 fragment reads per 8 MFMAs instead of 4 per 4); per tap they do nothing but read fragments and
-//              issue MFMAs - no LDS-DMA instruction, no vmcnt wait;
-//   waves 4-7 ("producers", the second wave of every SIMD): issue all the LDS-DMA of a tap (4 weight pieces + 2 halo pieces
-//              each) right after its barrier and sit in the counted vmcnt wait for the next tap's tile.
-// Producers and consumers execute the same barriers (one per tap): the ring-slot / halo-buffer reuse argument of
-// conv3_halo_kernel holds unchanged.
-// PIPE (p.algo == 12): explicit fragment pipeline in the consumers.  The fragments of k-step ks+1 are read while the MFMAs of
-// k-step ks are issued (two register sets), and the last k-step of a tap is multiplied after the next tap's barrier, where
-// its eight MFMAs cover the latency of that tap's first fragment reads.  Within a block the reads and the MFMAs are
-// INTERLEAVED one read behind every MFMA (sched_group_barrier): issued as a read burst and an MFMA burst, the matrix pipe
-// idles while the one wave that owns it spends its issue slots on ds_read_b128s.  Measured (bench_kernels, all 3x3
-// convolutions of one step): 4.09 ms against 4.51 ms for the best lock-step variant at BM = 256, 4.43 against 4.77 at
-// BM = 128; the specialisation alone (algo 11, compiler-scheduled consumers) is +-0 - it is the interleaved pipeline that the
-// one-owner matrix pipe makes worthwhile.
-// DBG (measurement only, wrong results): 1 (p.algo == 13) = the producers issue nothing inside the tap loop - what is left is
-// the consumers' speed limit under the same barriers; 2 (p.algo == 14) = the LDS-DMA is issued but never waited for.  At 96x96
-// 768->768, same box: 1.08 PFLOP/s complete, 1.22 without the waits, 1.39 without the loads - half of what the loads cost
-// there is the ONE tap a tile has to land in (2-slot ring: the LDS holds the double-buffered halo), half is contention;
-// where four slots fit (48x48) the waits cost nothing and the contention is the same 12-14 %.  Staging the weight tiles
-// through producer registers (global_load two taps ahead, ds_write_b128 into the 2-slot ring) was built and measured equal
-// to the LDS-DMA form at 96x96 and slower elsewhere; removed.  So was a four-block form of the consumer pipeline that reads the
-// weight fragments of the last k-step one block early (only halo reads in flight at the barrier, no full read wait with the
-// 2-slot ring): same-box A/B/A/B 1.718-1.740 ms for all three forms on the 96x96 / 48x48 shapes.
-// ================================================================================================================
-template <typename T, int BM, int NBST, bool PIPE = false, int DBG = 0>
-__global__ __launch_bounds__(512) void conv3_halo_spec_kernel(const IgemmParams p) {
-  using TR = TT<T>;
-  constexpr int BK = TR::BK, EPC = TR::EPC, KSTEPS = TR::KSTEPS;
-  constexpr int BN = HALO_BN, NWL = 4, WM = 2, WN = 2;
-  constexpr int MI = BM / (WM * 32), NI = BN / (WN * 32);
-  constexpr int B_SLOTS = BN / 8 / NWL;        // 4 weight LDS-DMA instructions per producer per tap
-  constexpr int B_BYTES = BN * 128;
-  constexpr int APT = 2;                       // halo pieces per producer per tap (taps 0 .. 9-NBST)
-  constexpr int A_SLOTS = (10 - NBST) * APT;
-  constexpr int GM = 8;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool producer = wave >= 4;             // wave-uniform
-  const int h = lane >> 5, l31 = lane & 31;
-
-  const int W2 = p.W + 2;
-  const int VR = p.H * W2;
-  const int TPI = (VR + BM - 1) / BM;
-  const int HRp = (BM + 2 * W2 + 2 + 7) & ~7;
-  const int NP = HRp >> 3;
-  const int A_BYTES = HRp * 128;
-  const int PR_MAX = (p.H + 2) * W2 - 1;
-  const int B = p.M / (p.H * p.W);
-
-  const int gx = B * TPI, gy = (p.N + BN - 1) / BN;
-  int L = p.xcd_remap ? xcd_remap_h(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int per_z = gx * gy;
-  const int bz = L / per_z;
-  L -= bz * per_z;
-  const int grp = L / (GM * gy);
-  const int first_m = grp * GM;
-  const int gsz = gx - first_m < GM ? gx - first_m : GM;
-  const int lin = L - grp * GM * gy;
-  const int bx = first_m + lin % gsz, by = lin / gsz;
-  const int img = bx / TPI, v0 = (bx - img * TPI) * BM;
-  const int n0 = by * BN;
-
-  const int nslab = p.Kc / BK;
-  int s0 = 0, s1 = nslab;
-  if (p.splitk > 1) {
-    const int per = (nslab + p.splitk - 1) / p.splitk;
-    s0 = bz * per;
-    s1 = s0 + per < nslab ? s0 + per : nslab;
-  }
-
-  f32x16_t acc[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-  char* const Bst = smem + 2 * A_BYTES;
-  if (s0 < s1) {
-    if (producer) {
-      // ---------------------------------------- producers: LDS-DMA only -----------------------------------------------
-      const int lw = wave - 4;
-      const T* __restrict__ Aimg = reinterpret_cast<const T*>(p.A0) + (int64_t)img * (p.H + 2) * W2 * p.Kc;
-      const T* __restrict__ Wp = reinterpret_cast<const T*>(p.Wp);
-      int aoff[A_SLOTS];
-#pragma unroll
-      for (int q = 0; q < A_SLOTS; ++q) {
-        int j = q * NWL + lw;
-        if (j > NP - 1) j = NP - 1;   // surplus slots re-load the last piece (same bytes, same place): uniform counting
-        const int hr = 8 * j + (lane >> 3);
-        int pr = v0 + hr;
-        if (pr > PR_MAX) pr = PR_MAX;
-        aoff[q] = pr * p.Kc + ((lane & 7) ^ ((hr >> 1) & 7)) * EPC;
-      }
-      int boff[B_SLOTS];
-#pragma unroll
-      for (int i = 0; i < B_SLOTS; ++i) {
-        const int row = 8 * (lw + NWL * i) + (lane >> 3);
-        int n = n0 + row;
-        if (n > p.Npad - 1) n = p.Npad - 1;
-        boff[i] = n * 9 * p.Kc + ((lane & 7) ^ ((row >> 1) & 7)) * EPC;
-      }
-      const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
-#define K22_SP_A(Q, SLAB, DSTOFF)                                                                          \
-      {                                                                                                    \
-        int j_ = (Q) * NWL + lw;                                                                           \
-        if (j_ > NP - 1) j_ = NP - 1;                                                                      \
-        glds16_asm(Aimg + aoff[Q] + (SLAB) * BK, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(DSTOFF) + j_ * 1024)); \
-      }
-#define K22_SP_B(SLAB, TAP, STAGE)                                                                         \
-      {                                                                                                    \
-        const int kofs_ = (TAP) * p.Kc + (SLAB) * BK;                                                      \
-        const unsigned d_ = lds0 + 2 * A_BYTES + (STAGE) * B_BYTES + lw * 1024;                            \
-        _Pragma("unroll") for (int i = 0; i < B_SLOTS; ++i)                                                \
-            glds16_asm(Wp + boff[i] + kofs_, __builtin_amdgcn_readfirstlane(d_ + i * NWL * 1024));         \
-      }
-#pragma unroll
-      for (int q = 0; q < A_SLOTS; ++q) K22_SP_A(q, s0, 0);
-#pragma unroll
-      for (int t = 0; t < NBST - 1; ++t) K22_SP_B(s0, t, t);
-      int fill = NBST - 1;
-      for (int s = s0; s < s1; ++s) {
-        const int anext_off = (((s - s0) & 1) ^ 1) * A_BYTES;
-        const int sn = s + 1 < s1 ? s + 1 : s1 - 1;   // past-the-end loads re-read the last slab (uniform counting)
-#define K22_SP_PTAP(TAP)                                                                                   \
-        {                                                                                                  \
-          if constexpr (DBG == 0) wait_vmcnt<B_SLOTS * (NBST - 2) + APT * halo_count_a<NBST>(TAP)>();      \
-          raw_barrier();                                                                                   \
-          constexpr int ta_ = ((TAP) + NBST - 1) % 9;                                                      \
-          const int sa_ = ((TAP) + NBST - 1 >= 9) ? sn : s;                                                \
-          if constexpr (DBG != 1) K22_SP_B(sa_, ta_, fill);                                                \
-          if constexpr ((TAP) <= 9 - NBST && DBG != 1) {                                                   \
-            _Pragma("unroll") for (int a_ = 0; a_ < APT; ++a_) {                                           \
-              constexpr int qb_ = ((TAP) <= 9 - NBST ? (TAP) : 0) * APT;                                   \
-              K22_SP_A(qb_ + a_, sn, anext_off);                                                           \
-            }                                                                                              \
-          }                                                                                                \
-          fill = (fill + 1 == NBST) ? 0 : fill + 1;                                                        \
-        }
-        K22_SP_PTAP(0) K22_SP_PTAP(1) K22_SP_PTAP(2) K22_SP_PTAP(3) K22_SP_PTAP(4) K22_SP_PTAP(5) K22_SP_PTAP(6) K22_SP_PTAP(7) K22_SP_PTAP(8)
-#undef K22_SP_PTAP
-      }
-#undef K22_SP_A
-#undef K22_SP_B
-    } else {
-      // ---------------------------------------- consumers: fragments + MFMA only --------------------------------------
-      const int wm = wave >> 1, wn = wave & 1;
-      const int abase = wm * (BM / WM) + l31;
-      int brow[NI];
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) brow[ni] = (wn * (BN / WN) + ni * 32 + l31) * 128;
-      const int bsw = (l31 >> 1) & 7;
-      int cur = 0;
-      // (s_setprio 3 in the consumers, so that they win issue arbitration against the producer on their SIMD: measured +-1 %)
-      Frag<T> pa[MI], pb[NI];   // PIPE: fragments read but not yet multiplied (zero = a no-op group before the first tap)
-      if constexpr (PIPE) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) pa[mi] = Frag<T>{};
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) pb[ni] = Frag<T>{};
-      }
-      // One block of the pipeline = NRD fragment reads (of the NEXT group) + NMF MFMAs (of the group read one block ago), which
-      // are independent of each other: one read is scheduled behind every MPR MFMAs (0x008 = MFMA, 0x100 = DS read), so that
-      // each ds_read_b128 issues under the 32 cycles the MFMA before it occupies the pipe.
-      constexpr int NRD = (MI + NI) * FragCost<T>::READS;
-      constexpr int NMF = MI * NI * FragCost<T>::MFMAS;
-      constexpr int MPR = NMF / NRD;
-#define K22_SP_INTERLEAVE()                                                                                \
-      {                                                                                                    \
-        _Pragma("unroll") for (int i_ = 0; i_ < NRD; ++i_) {                                               \
-          __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);                                             \
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                               \
-        }                                                                                                  \
-        if constexpr (NMF - MPR * NRD > 0) __builtin_amdgcn_sched_group_barrier(0x008, NMF - MPR * NRD, 0); \
-        __builtin_amdgcn_sched_barrier(0);                                                                 \
-      }
-      for (int s = s0; s < s1; ++s) {
-        const char* const Acur = smem + ((s - s0) & 1) * A_BYTES;
-#define K22_SP_CTAP(TAP)                                                                                   \
-        {                                                                                                  \
-          raw_barrier();                                                                                   \
-          const char* Bcur = Bst + cur * B_BYTES;                                                          \
-          const int shift = ((TAP) / 3) * W2 + ((TAP) % 3);                                                \
-          const char* arow[MI];                                                                            \
-          int asw[MI];                                                                                     \
-          _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                              \
-            const int ar = abase + mi * 32 + shift;                                                        \
-            arow[mi] = Acur + ar * 128;                                                                    \
-            asw[mi] = (ar >> 1) & 7;                                                                       \
-          }                                                                                                \
-          if constexpr (PIPE) {                                                                            \
-            Frag<T> ca[MI], cb[NI];                                                                        \
-            _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ks += 2) {                                     \
-              _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) ld_frag_at(ca[mi], arow[mi], asw[mi], ks, h); \
-              _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) ld_frag_at(cb[ni], Bcur + brow[ni], bsw, ks, h); \
-              _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                            \
-                _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], pb[ni], pa[mi]);   \
-              K22_SP_INTERLEAVE();                                                                         \
-              _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) ld_frag_at(pa[mi], arow[mi], asw[mi], ks + 1, h); \
-              _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) ld_frag_at(pb[ni], Bcur + brow[ni], bsw, ks + 1, h); \
-              _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                            \
-                _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], cb[ni], ca[mi]);   \
-              K22_SP_INTERLEAVE();                                                                         \
-            }                                                                                              \
-          } else {                                                                                         \
-          _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks) {                                          \
-            Frag<T> a[MI], b[NI];                                                                          \
-            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) ld_frag_at(a[mi], arow[mi], asw[mi], ks, h); \
-            _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) ld_frag_at(b[ni], Bcur + brow[ni], bsw, ks, h); \
-            _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                              \
-              _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], b[ni], a[mi]);       \
-          }                                                                                                \
-          }                                                                                                \
-          /* Fragment reads may not stay in flight across the next barrier: right after barrier TAP+1 the producers refill    \
-             slot (TAP + NBST) % NBST = the weight slot THIS tap read, whatever the ring depth (and after tap 8 the halo buffer \
-             of the slab before).  Only the DMA's latency kept the NBST >= 3 forms correct in round 2; now nothing is left to   \
-             timing.  (The MFMAs that use the fragments can still sink below the barrier - registers only - in both forms.) */  \
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
-          cur = (cur + 1 == NBST) ? 0 : cur + 1;                                                           \
-        }
-        K22_SP_CTAP(0) K22_SP_CTAP(1) K22_SP_CTAP(2) K22_SP_CTAP(3) K22_SP_CTAP(4) K22_SP_CTAP(5) K22_SP_CTAP(6) K22_SP_CTAP(7) K22_SP_CTAP(8)
-#undef K22_SP_CTAP
-      }
-#undef K22_SP_INTERLEAVE
-      if constexpr (PIPE) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], pb[ni], pa[mi]);
-      }
-    }
-  }
-  halo_tail<T, BM, false, true>(p, acc, smem, bx, bz, img, v0, n0);
 }
 
 // ================================================================================================================
@@ -1418,32 +806,6 @@ __global__ __launch_bounds__(512) void conv3_halo4_kernel(const IgemmParams p) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-static int halo_rows(const IgemmParams& p, int bm) { return (bm + 2 * (p.W + 2) + 2 + 7) & ~7; }
-
-static size_t halo_smem_bytes(const IgemmParams& p, int bm, int nbst) {
-  const size_t main_loop = (size_t)2 * halo_rows(p, bm) * 128 + (size_t)nbst * HALO_BN * 128;
-  const size_t epi = (size_t)bm * (HALO_BN * 4 + 16);
-  const size_t red = (size_t)32 * HALO_BN * 2 * 4;
-  const size_t skip = p.S0 ? (size_t)2 * (bm * 128 + HALO_BN * 128) : 0;
-  size_t m = main_loop > epi ? main_loop : epi;
-  m = m > skip ? m : skip;
-  return m > red ? m : red;
-}
-
-// deepest weight ring (2, 3, 4 or 6 tiles) that fits the LDS next to the double-buffered halo and still leaves
-// enough halo slots (taps 0 .. 9-NBST, one 8-row piece per wave each); 0 = the problem does not fit at all.
-// Depth matters at the low-resolution levels: their weights stream from HBM (~2 us away) while a tap is
-// 0.2-0.4 us of MFMA work, so a workgroup must keep ~64+ KB of weight tiles in flight (Little's law).
-static int halo_pick_nbst(const IgemmParams& p, int bm) {
-  const int np = halo_rows(p, bm) / 8;
-  for (int nbst : {6, 4, 3, 2}) {
-    if (np > (10 - nbst) * HALO_NW) continue;
-    if (halo_smem_bytes(p, bm, nbst) > 160 * 1024) continue;
-    return nbst;
-  }
-  return 0;
-}
-
 static int halo3_rows(const IgemmParams& p, int bm) { return (bm + 2 * (p.W + 2) + 2 + 15) & ~15; }
 static size_t halo3_smem_bytes(const IgemmParams& p, int bm, int rb) {
   const size_t main_loop = (size_t)2 * halo3_rows(p, bm) * 64 + (size_t)rb * 3 * HALO_BN * 64;
@@ -1532,6 +894,10 @@ bool conv3_halo_supported(const IgemmParams& p, int dtype, int bm) {
   // split precision: the input is read in x3 chunks; instantiated forms = the lock-step kernel with asm LDS-DMA (algo 2 / 5 / 6 / 7 all
   // run it) and the specialised kernel (11 / 12)
   if (dtype == K22_F16X3 && (p.a_raw || p.algo == 3 || p.algo == 4)) return false;
+  if (p.gn_coeff != nullptr) {   // fused GroupNorm-apply: the specialised kernels only; slabs never straddle the two raw sources
+    if (!conv3_algo_fuses_gn(p.algo) || !p.gn_x0 || p.gn_C0 <= 0 || p.gn_C0 > p.Kc || p.gn_C0 % BK || (p.gn_C0 < p.Kc && !p.gn_x1)) return false;
+    if ((int64_t)p.H * p.W * p.Kc >= (1ll << 31)) return false;
+  }
   if (p.out_mode != IG_OUT_ROWMAJOR && p.out_mode != IG_OUT_ROWMAJOR_F32) return false;
   if (p.N % 8 || p.ldo % 8 || (p.residual && p.ldr % 8) || p.Kc % BK) return false;
   if (p.H <= 0 || p.W <= 0 || p.M % (p.H * p.W)) return false;
@@ -1566,27 +932,6 @@ static int launch_halo_nbst(const IgemmParams& p, int nbst, int splitk, hipStrea
   if (nbst == 3) return launch_halo_cfg<T, BM, 3, LW, MODE>(p, splitk, stream);
   if (nbst <= 5) return launch_halo_cfg<T, BM, 4, LW, MODE>(p, splitk, stream);
   return launch_halo_cfg<T, BM, 6, LW, MODE>(p, splitk, stream);
-}
-
-template <typename T, int BM, int NBST, bool PIPE, int DBG = 0>
-static int launch_halo_spec_cfg(const IgemmParams& p, int splitk, hipStream_t stream) {
-  const size_t smem = halo_smem_bytes(p, BM, NBST);
-  static LdsAttrGuard attr_guard;
-  if (int rc_ = k22_ensure_lds_attr(attr_guard, reinterpret_cast<const void*>(&conv3_halo_spec_kernel<T, BM, NBST, PIPE, DBG>), 160 * 1024, __FILE__, __LINE__)) return rc_;
-  IgemmParams q = p;
-  q.splitk = splitk;
-  const int B = p.M / (p.H * p.W);
-  const int nblocks = B * conv3_halo_tiles_per_image(p, BM) * ((p.N + HALO_BN - 1) / HALO_BN) * splitk;
-  hipLaunchKernelGGL((conv3_halo_spec_kernel<T, BM, NBST, PIPE, DBG>), dim3(nblocks), dim3(512), smem, stream, q);
-  K22_CHECK_LAUNCH();
-  return K22_OK;
-}
-template <typename T, int BM, bool PIPE>
-static int launch_halo_spec_nbst(const IgemmParams& p, int nbst, int splitk, hipStream_t stream) {
-  if (nbst == 2) return launch_halo_spec_cfg<T, BM, 2, PIPE>(p, splitk, stream);
-  if (nbst == 3) return launch_halo_spec_cfg<T, BM, 3, PIPE>(p, splitk, stream);
-  if (nbst <= 5) return launch_halo_spec_cfg<T, BM, 4, PIPE>(p, splitk, stream);
-  return launch_halo_spec_cfg<T, BM, 6, PIPE>(p, splitk, stream);
 }
 
 template <typename T, int BM, int RB>
@@ -1658,9 +1003,7 @@ int launch_conv3_halo(const IgemmParams& p, int dtype, int bm, int splitk, hipSt
   if (dtype == K22_F16X3) {
     int nb = halo_pick_nbst(p, bm);
     if (p.stages >= 2 && p.stages < nb) nb = p.stages == 5 ? 4 : p.stages;
-    if (p.algo == 11) return bm == 256 ? launch_halo_spec_nbst<x3_t, 256, false>(p, nb, splitk, stream) : launch_halo_spec_nbst<x3_t, 128, false>(p, nb, splitk, stream);
-    // BM = 256: two fragment sets of 8 registers per fragment do not fit beside 128 accumulators (as for fp32): compiler-scheduled consumers
-    if (p.algo == 12) return bm == 256 ? launch_halo_spec_nbst<x3_t, 256, false>(p, nb, splitk, stream) : launch_halo_spec_nbst<x3_t, 128, true>(p, nb, splitk, stream);
+    if (p.algo == 11 || p.algo == 12) return launch_conv3_halo_spec(p, dtype, bm, nb, splitk, stream);
     if (p.algo == 13 || p.algo == 14 || p.algo == 8 || p.algo == 9) return k22_set_error(K22_EINVAL, "conv3_halo: no measurement-only variants in split precision");
     return bm == 256 ? launch_halo_nbst<x3_t, 256, 8, 2>(p, nb, splitk, stream) : launch_halo_nbst<x3_t, 128, 8, 2>(p, nb, splitk, stream);
   }
@@ -1679,23 +1022,12 @@ int launch_conv3_halo(const IgemmParams& p, int dtype, int bm, int splitk, hipSt
   }
   int nbst = halo_pick_nbst(p, bm);
   if (p.stages >= 2 && p.stages < nbst) nbst = p.stages == 5 ? 4 : p.stages;  // tuning knob: shallower ring on request
-  if (p.algo == 11) {  // producer / consumer wave specialisation (conv3_halo_spec_kernel), compiler-scheduled consumers
-    if (dtype == K22_BF16) return bm == 256 ? launch_halo_spec_nbst<bf16_t, 256, false>(p, nbst, splitk, stream) : launch_halo_spec_nbst<bf16_t, 128, false>(p, nbst, splitk, stream);
-    else if (dtype == K22_F16) return bm == 256 ? launch_halo_spec_nbst<f16_t, 256, false>(p, nbst, splitk, stream) : launch_halo_spec_nbst<f16_t, 128, false>(p, nbst, splitk, stream);
-    return bm == 256 ? launch_halo_spec_nbst<float, 256, false>(p, nbst, splitk, stream) : launch_halo_spec_nbst<float, 128, false>(p, nbst, splitk, stream);
-  }
-  if (p.algo == 12) {  // the same with the explicit, interleaved fragment pipeline in the consumers
-    if (dtype == K22_BF16) return bm == 256 ? launch_halo_spec_nbst<bf16_t, 256, true>(p, nbst, splitk, stream) : launch_halo_spec_nbst<bf16_t, 128, true>(p, nbst, splitk, stream);
-    else if (dtype == K22_F16) return bm == 256 ? launch_halo_spec_nbst<f16_t, 256, true>(p, nbst, splitk, stream) : launch_halo_spec_nbst<f16_t, 128, true>(p, nbst, splitk, stream);
-    // fp32, BM = 256: two fragment sets of 8 registers per fragment do not fit beside 128 accumulators (the pipelined form spills):
-    // the compiler-scheduled consumer is used there
-    return bm == 256 ? launch_halo_spec_nbst<float, 256, false>(p, nbst, splitk, stream) : launch_halo_spec_nbst<float, 128, true>(p, nbst, splitk, stream);
-  }
+  // producer / consumer wave specialisation (conv3_spec.hip): 11 = compiler-scheduled consumers, 12 = explicit, interleaved fragment pipeline
+  if (p.algo == 11 || p.algo == 12) return launch_conv3_halo_spec(p, dtype, bm, nbst, splitk, stream);
 #ifdef K22_DEBUG_VARIANTS   // measurement-only kernels (wrong results) are compiled only into a developer build: make CXXFLAGS+=-DK22_DEBUG_VARIANTS
   if (p.algo == 13 || p.algo == 14) {  // measurement-only forms of algo 12 (wrong results): 13 = no LDS-DMA inside the tap loop, 14 = LDS-DMA issued but never waited for
     if (dtype != K22_BF16 || bm != 256) return k22_set_error(K22_EINVAL, "conv3_halo: the debug variants are bf16, BM = 256 only");
-    if (p.algo == 13) return nbst == 2 ? launch_halo_spec_cfg<bf16_t, 256, 2, true, 1>(p, splitk, stream) : launch_halo_spec_cfg<bf16_t, 256, 4, true, 1>(p, splitk, stream);
-    return nbst == 2 ? launch_halo_spec_cfg<bf16_t, 256, 2, true, 2>(p, splitk, stream) : launch_halo_spec_cfg<bf16_t, 256, 4, true, 2>(p, splitk, stream);
+    return launch_conv3_halo_spec_debug(p, nbst, splitk, stream);
   }
 #else
   if (p.algo == 13 || p.algo == 14 || p.algo == 8 || p.algo == 9) return k22_set_error(K22_EINVAL, "conv3_halo: measurement-only variants need a -DK22_DEBUG_VARIANTS build");

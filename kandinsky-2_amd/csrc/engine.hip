@@ -79,6 +79,15 @@ struct K22UNet {
   bool tuned_done = false;
   int autotune = 1;
   int fuse_skip = 1;
+  // GroupNorm-apply (+FiLM, +SiLU, zero border) fused into the consuming 3x3 convolution's halo fill (conv3_halo_spec_kernel producers)
+  // wherever the convolution's tile configuration is one of the specialised kernels; the stand-alone gn_apply stays for the rest.
+  // OFF by default (K22_FUSE_GN=1 turns it on): parity-green and bit-identical to the two-kernel path, but measured SLOWER on MI355X -
+  // bf16 C2 step 143.5 -> 112.9 steps/s (conv class 4.30 -> 6.48 ms for 0.26 ms of gn_apply removed), f16x3 66.5 -> 59.4: the matrix
+  // pipe's owner shares its SIMD's issue port with the producer wave, every n-tile of an m-tile re-normalises the same pixels (6-12x
+  // the work of one stand-alone pass), and the rewrite pins each halo piece to land within ONE tap (profiles/r04_gn_fused_negative.txt).
+  int fuse_gn = 0;
+  struct GnLink { const Tuned* consumer = nullptr; };   // GroupNorm op -> the convolution that reads its output (set after both exist)
+  std::deque<GnLink> gn_links;
   int gn_onepass = 0;
   int gn_fused = 0;
   // weight-streaming kernel (stream_gemm.hip) for the small-M 3x3 convolutions: fragment-major copies of their weights live in the
@@ -153,7 +162,7 @@ struct K22UNet {
 
   // ------------------------------------------------------------------------------------------
   void op_gn(OpList& L, const Act& in, const std::string& pfx, int64_t film_off,
-             int act, int mode, int pad, Slot* dst) {
+             int act, int mode, int pad, Slot* dst, const GnLink* link = nullptr) {
     const int Bn = B, C = in.C(), HW = in.H * in.W;
     const int nsplit = gn_nsplit(Bn, HW);
     // producer-side partial sums for every part of the input?  Otherwise the stand-alone stats pass.
@@ -184,7 +193,7 @@ struct K22UNet {
       }, OP_GN, 0.0, (double)Bn * HW * C * esz + (double)Bn * (Ho + 2 * pad) * (Wo + 2 * pad) * C * esz, 1));
         return;
     }
-    const bool one_launch = gn_fused && !x3 && gn_fused_supported(C, a.C0, dtype);
+    const bool one_launch = gn_fused && !x3 && link == nullptr && gn_fused_supported(C, a.C0, dtype);
     L.push_back(Op([=](hipStream_t st) {
       const void* x0 = ptr(a.s0);
       const void* x1 = a.s1 ? ptr(a.s1) : nullptr;
@@ -211,6 +220,8 @@ struct K22UNet {
       if (one_launch) return launch_gn_fused(cp, ap, dt, st);   // coefficients + apply in one launch (elementwise.hip: gn_fused_kernel)
       int rc = launch_gn_coeff(cp, Bn, st);
       if (rc) return rc;
+      // the consuming convolution applies the coefficients itself while it fills its LDS halo (fused GroupNorm-apply): nothing to write
+      if (link != nullptr && link->consumer != nullptr && conv3_algo_fuses_gn(link->consumer->cfg.algo)) return K22_OK;
       return launch_gn_apply(ap, dt, st);
     }, OP_GN, 0.0, gn_bytes, (fused ? 2 : 3) - (one_launch ? 1 : 0)));
   }
@@ -224,9 +235,11 @@ struct K22UNet {
 
   // conv3x3 over a zero-bordered slot `src` [B][Hc+2][Wc+2][Cin].  `stats` (optional) receives the GroupNorm
   // partial sums of the output; returns the launch descriptor (null when the output is not a tunable T tensor).
+  // gn_in (optional): the raw tensor(s) whose GroupNorm (coefficients in s_coeff, written by the op_gn just before) `src` holds: with a
+  // specialised-kernel configuration the convolution reads gn_in and applies the coefficients in its halo fill instead of reading `src`
   Tuned* op_conv(OpList& L, Slot* src, int Hc, int Wc, int Cin, int Cout,
                  const std::string& pfx, const Act* residual, Slot* dst, int out_mode, Slot* stats = nullptr,
-                 const Act* skip_in = nullptr, const std::string& skip_pfx = std::string()) {
+                 const Act* skip_in = nullptr, const std::string& skip_pfx = std::string(), const Act* gn_in = nullptr, int gn_act = K22_ACT_NONE) {
     tuned.emplace_back();
     Tuned* t = &tuned.back();
     IgemmParams& p = t->p;
@@ -277,10 +290,16 @@ struct K22UNet {
     need(dst, out_mode == IG_OUT_ROWMAJOR ? (size_t)p.M * Cout * esz : (size_t)p.M * Cout * sizeof(float));
     Slot* rs = residual ? residual->s0 : nullptr;
     const int dt = dtype;
+    const bool gnf = gn_in != nullptr && fuse_gn;
+    Act ga;
+    if (gnf) ga = *gn_in;
     t->run = [=](hipStream_t st) {
       IgemmParams q = t->p;
       apply_cfg(q, t->cfg);
       q.A0 = ptr(src); q.residual = rs ? ptr(rs) : nullptr; q.out = ptr(dst); q.partial = ptr<float>(s_splitk);
+      if (gnf && conv3_algo_fuses_gn(t->cfg.algo)) {
+        q.gn_coeff = ptr<float>(s_coeff); q.gn_x0 = ptr(ga.s0); q.gn_x1 = ga.s1 ? ptr(ga.s1) : nullptr; q.gn_C0 = ga.C0; q.gn_act = gn_act;
+      }
       q.stats = t->want_stats ? ptr<float>(stats) : nullptr;
       q.gsum = gs >= 0 ? gsum_at(gs) : nullptr;
       if (q.S0) { q.S0 = ptr(sk.s0); q.S1 = sk.s1 ? ptr(sk.s1) : nullptr; }
@@ -344,14 +363,20 @@ struct K22UNet {
     const int Ho = updown == 1 ? in.H / 2 : (updown == 2 ? in.H * 2 : in.H);
     const int Wo = updown == 1 ? in.W / 2 : (updown == 2 ? in.W * 2 : in.W);
     // in_layers: GN + SiLU (+ resample) -> conv3x3
-    op_gn(ops, in, pfx + ".in_layers.0", -1, K22_ACT_SILU, updown, 1, s_P1);
-    Tuned* t1 = op_conv(ops, s_P1, Ho, Wo, Cin, Cout, pfx + ".in_layers.2", nullptr, s_U1, IG_OUT_ROWMAJOR, s_U1st);
+    GnLink* l1 = nullptr;
+    if (fuse_gn && updown == 0) { gn_links.emplace_back(); l1 = &gn_links.back(); }   // (the resampling GroupNorms keep gn_apply)
+    op_gn(ops, in, pfx + ".in_layers.0", -1, K22_ACT_SILU, updown, 1, s_P1, l1);
+    Tuned* t1 = op_conv(ops, s_P1, Ho, Wo, Cin, Cout, pfx + ".in_layers.2", nullptr, s_U1, IG_OUT_ROWMAJOR, s_U1st, nullptr, std::string(),
+                        l1 ? &in : nullptr, K22_ACT_SILU);
+    if (l1) l1->consumer = t1;
     // out_layers: GN * (1+scale) + shift -> SiLU -> conv3x3 (+ skip)
     Act u1; u1.s0 = s_U1; u1.C0 = Cout; u1.H = Ho; u1.W = Wo;
     if (t1->want_stats) { u1.p0 = t1; u1.st0 = s_U1st; u1.gs0 = t1->gsum_off; }
     const int64_t film_off = film_cursor;
     film_cursor += 2 * Cout;
-    op_gn(ops, u1, pfx + ".out_layers.0", film_off, K22_ACT_SILU, 0, 1, s_P2);
+    GnLink* l2 = nullptr;
+    if (fuse_gn) { gn_links.emplace_back(); l2 = &gn_links.back(); }
+    op_gn(ops, u1, pfx + ".out_layers.0", film_off, K22_ACT_SILU, 0, 1, s_P2, l2);
     Act skip;
     skip.H = Ho; skip.W = Wo; skip.C0 = Cout;
     if (updown) {
@@ -369,7 +394,8 @@ struct K22UNet {
       probe.SK0 = in.C0; probe.SK1 = in.C1; probe.Ws = reinterpret_cast<const void*>(1);
       if (fuse_skip && Cout >= 128 && (conv3_halo_supported(probe, dtype, 256) || conv3_halo_supported(probe, dtype, 128))) {
         Tuned* t2 = op_conv(ops, s_P2, Ho, Wo, Cout, Cout, pfx + ".out_layers.3", nullptr, dst, IG_OUT_ROWMAJOR, dst_stats,
-                            &in, pfx + ".skip_connection");
+                            &in, pfx + ".skip_connection", l2 ? &u1 : nullptr, K22_ACT_SILU);
+        if (l2) l2->consumer = t2;
         Act out; out.s0 = dst; out.C0 = Cout; out.H = Ho; out.W = Wo;
         if (t2->want_stats) { out.p0 = t2; out.st0 = dst_stats; out.gs0 = t2->gsum_off; }
         return out;
@@ -380,7 +406,9 @@ struct K22UNet {
       if (in.s1) { if (err.empty()) err = "identity skip over a concat input"; }
       skip.s0 = in.s0;
     }
-    Tuned* t2 = op_conv(ops, s_P2, Ho, Wo, Cout, Cout, pfx + ".out_layers.3", &skip, dst, IG_OUT_ROWMAJOR, dst_stats);
+    Tuned* t2 = op_conv(ops, s_P2, Ho, Wo, Cout, Cout, pfx + ".out_layers.3", &skip, dst, IG_OUT_ROWMAJOR, dst_stats, nullptr, std::string(),
+                        l2 ? &u1 : nullptr, K22_ACT_SILU);
+    if (l2) l2->consumer = t2;
     Act out; out.s0 = dst; out.C0 = Cout; out.H = Ho; out.W = Wo;
     if (t2->want_stats) { out.p0 = t2; out.st0 = dst_stats; out.gs0 = t2->gsum_off; }
     return out;
@@ -446,6 +474,7 @@ struct K22UNet {
     if (nH % (1 << n_down) || nW % (1 << n_down)) return k22_set_error(K22_EINVAL, "unet: H, W must be divisible by 2^(levels-1)");
     if (nB > 8) return k22_set_error(K22_EINVAL, "unet: batch (2*bs) must be <= 8 per engine call");
     B = nB; H = nH; W = nW;
+    gn_links.clear();
     slots.clear(); ops.clear(); cond_ops.clear(); hint_ops.clear(); s_ctxkv.clear(); gsum_bytes = 0; frag_jobs.clear(); frag_done = false; n_attn = 0; err.clear();
     tuned.clear(); tuned_done = false; warmed = false;
     ws = nullptr; cond_set = false; hint_set = false;
@@ -767,6 +796,8 @@ int k22_unet_create(const K22UNetConfig* cfg, const K22Weight* weights, int n_we
     u->gn_fused = g1 ? (atoi(g1) != 0) : 0;
     const char* sf = getenv("K22_STREAM");   // 0 = no fragment-major weight copies, no weight-streaming kernel
     u->stream_frag = sf ? (atoi(sf) != 0) : 1;
+    const char* fg = getenv("K22_FUSE_GN");   // 0 = every GroupNorm through the stand-alone gn_apply kernel
+    u->fuse_gn = fg ? (atoi(fg) != 0) : 0;
     const char* f = getenv("K22_FUSE_SKIP");  // 0 = 1x1 skip connections as separate GEMMs
     u->fuse_skip = f ? (atoi(f) != 0) : 1;
   }

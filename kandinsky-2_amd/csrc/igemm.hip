@@ -696,6 +696,8 @@ int launch_igemm(const IgemmParams& p, int dtype, hipStream_t stream) {
   }
   if (pl.splitk > 1 && p.partial == nullptr) pl.splitk = 1;
   if (p.res_f32 && pl.halo) return k22_set_error(K22_EINVAL, "igemm: fp32 residual is not supported by the halo kernel");
+  if (p.gn_coeff != nullptr && !conv3_algo_fuses_gn(pl.halo))
+    return k22_set_error(K22_EINVAL, "igemm: the fused GroupNorm-apply input needs the specialised halo kernel (algo 11 / 12)");
   if (p.S0 != nullptr && !pl.halo) return k22_set_error(K22_EINVAL, "igemm: the fused 1x1 skip connection needs the halo kernel");
   if ((p.stats != nullptr || p.gsum != nullptr) && pl.splitk == 1 && !pl.halo)
     return k22_set_error(K22_EINVAL, "igemm: GroupNorm partial sums requested from a configuration that cannot produce them");

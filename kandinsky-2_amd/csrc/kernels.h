@@ -81,6 +81,12 @@ struct IgemmParams {
   int a_raw;             // K22_F16X3 only: 1 = the A operand (A0 / A1) is plain fp32 rows, converted to split halves at fragment-read
                          // time (generic kernel and gemm8 only); 0 = A is in x3 chunks (common.h), written so by its producer.
                          // The fused-skip operands S0 / S1 are always plain fp32 rows; weights are always x3 chunks.
+  // Fused GroupNorm-apply (conv3_halo_spec_kernel, taps == 9): the input is NOT the zero-bordered, normalised tensor A0 but the raw
+  // UNPADDED NHWC tensor(s) gn_x0 [B][H][W][gn_C0] (+ gn_x1 [B][H][W][Kc - gn_C0]: virtual concat); the producer waves read them
+  // into the LDS halo image, and rewrite it in place as  act(x * A[c] + Bc[c])  from gn_coeff [B][Kc][2] (gn_coeff_kernel's table:
+  // mean / rstd, gamma / beta and FiLM folded), zero at the border positions - GroupNorm32 + FiLM + SiLU of nn.py:26-37,
+  // unet.py:150-152, 174-180, 212-216 without the stand-alone apply pass.  gn_coeff == null: off (A0 is read).
+  const float* gn_coeff; const void* gn_x0; const void* gn_x1; int gn_C0, gn_act;
   unsigned long long* st_trace;          // K22_STREAM_DEBUG builds only: 16 stamps per workgroup
   int st_tm, st_rb, st_mtiles, st_buf;   // set by launch_stream (stream_gemm.hip): rows per m-tile, image rows per band, m-tiles, bytes of one LDS A buffer
 };
@@ -94,6 +100,8 @@ int igemm_stats_rows_per_image(const IgemmParams& p, int dtype);
 int launch_igemm(const IgemmParams& p, int dtype, hipStream_t stream);
 // conv3_halo.hip: 3x3 convolution with the input tile (+halo) resident in LDS across the 9 taps.
 bool conv3_halo_supported(const IgemmParams& p, int dtype, int bm);
+// the kernel variants that can take the fused GroupNorm-apply input (IgemmParams::gn_coeff): the specialised halo kernels
+inline bool conv3_algo_fuses_gn(int algo) { return algo == 11 || algo == 12; }
 int conv3_halo_tiles_per_image(const IgemmParams& p, int bm);
 int launch_conv3_halo(const IgemmParams& p, int dtype, int bm, int splitk, hipStream_t stream);
 int launch_conv3_halo_trace(const IgemmParams& p, int dtype, hipStream_t stream);
