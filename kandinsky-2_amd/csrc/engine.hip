@@ -144,10 +144,125 @@ struct K22UNet {
   }
   const float* Wf(const std::string& name) { return reinterpret_cast<const float*>(W_(name)); }
 
+  // ---- two half-batch chains (round 4) ------------------------------------------------------------------------------------------
+  // A forward is a chain of ~400 DEPENDENT launches of which about a third (GroupNorm coefficients / apply, the 20-us GEMMs of the
+  // AttentionBlocks, split-K finishes) move little data and leave most of the 256 CUs idle.  Images never interact inside the UNet
+  // (GroupNorm and attention are per sample; the CFG pair [cond | uncond] is two samples), so an even batch runs as TWO independent
+  // half-batch engines ("kids": same weights, own workspace) on two streams forked from and joined into the caller's - in the captured
+  // graph two parallel branches - and one chain's latency-bound stretches overlap the other's MFMA-bound ones.  Measured at C2 (bf16,
+  // tools/two_stream_probe.py, two separately launched graphs on two streams): 8.20 ms for one B = 2 chain, 5.89 ms for one B = 1 chain
+  // alone, 7.31 ms for two B = 1 chains overlapped (-11 %).  EXPERIMENTAL, OFF by default (K22_CHAINS=2 enables it), for two measured
+  // reasons (profiles/r04_two_chains.txt): (1) as two branches of ONE captured graph - the form the whole-loop graph needs - hipGraph
+  // gave no overlap at all: 139.5 steps/s against 139.8 for the single chain; (2) the split-precision engine is NOT reproducible under
+  // it: with the kids' kernels overlapping over a whole forward (never within a 22-op window) the first image of the second chain came
+  // out 2e-2 off in ~70 % of the forwards while bf16 / fp16 / fp32 stayed bit-stable and the serial order of the same kids is exact - an
+  // interaction that is not understood yet, so nothing that must hold parity runs on it.  The parent engine then owns no ops of its own:
+  // only the fork / join, the graph(s), and the workspace layout [kid 0 | kid 1 | combined model output].
+  K22UNet* kid[2] = {nullptr, nullptr};
+  bool chained = false;
+  hipStream_t side = nullptr, side0 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join0 = nullptr;
+  size_t kid_off[2] = {0, 0}, comb_off = 0;
+  int nparts() const { return chained ? 2 : 1; }
+  K22UNet* part(int i) { return chained ? kid[i] : this; }
+  const K22UNet* part(int i) const { return chained ? kid[i] : this; }
+  int partB() const { return chained ? B / 2 : B; }
+  // the [B][out_channels][HW] model output as one tensor (chained: gathered from the kids by fetch_out)
+  float* model_out() { return chained ? reinterpret_cast<float*>(ws + comb_off) : ptr<float>(s_out); }
+  int fetch_out(hipStream_t st) {
+    if (!chained) return K22_OK;
+    const size_t n = (size_t)(B / 2) * cfg.out_channels * H * W * 4;
+    for (int i = 0; i < 2; ++i) {
+      hipError_t e = hipMemcpyAsync(ws + comb_off + i * n, kid[i]->ptr(kid[i]->s_out), n, hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+    }
+    return K22_OK;
+  }
+  // one forward of the whole batch on `st` (inputs staged, conditioning set): the op list, or the two kids' op lists in parallel
+  int exec(hipStream_t st) {
+    if (!chained) return run_ops(st);
+    static const bool serial = getenv("K22_CHAINS_SERIAL") && atoi(getenv("K22_CHAINS_SERIAL")) != 0;   // debug: both kids on the caller's stream
+    if (serial) { int rc0 = kid[0]->run_ops(st); return rc0 ? rc0 : kid[1]->run_ops(st); }
+    // debug: ops [lo, hi) of both kids run concurrently, the rest serially on the caller's stream
+    static const int dbg_lo = getenv("K22_CHAINS_LO") ? atoi(getenv("K22_CHAINS_LO")) : 0;
+    static const int dbg_hi = getenv("K22_CHAINS_HI") ? atoi(getenv("K22_CHAINS_HI")) : (1 << 30);
+    const int nops = (int)kid[0]->ops.size();
+    const int lo = dbg_lo < nops ? dbg_lo : nops, hi = dbg_hi < nops ? dbg_hi : nops;
+    for (int kk = 0; kk < 2; ++kk) for (int i = 0; i < lo; ++i) { int r_ = kid[kk]->ops[i](st); if (r_) return r_; }
+    // debug K22_CHAINS_OWN=1: BOTH kids on private non-blocking streams (the caller's stream may be the legacy NULL stream)
+    static const bool own = getenv("K22_CHAINS_OWN") && atoi(getenv("K22_CHAINS_OWN")) != 0;
+    if (own && !side0) {
+      hipError_t e0 = hipStreamCreateWithFlags(&side0, hipStreamNonBlocking);
+      if (e0 == hipSuccess) e0 = hipEventCreateWithFlags(&ev_join0, hipEventDisableTiming);
+      if (e0 != hipSuccess) return k22_set_error_hip(e0, __FILE__, __LINE__);
+    }
+    hipStream_t s0 = own ? side0 : st;
+    hipError_t e = hipEventRecord(ev_fork, st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(side, ev_fork, 0);
+    if (e == hipSuccess && own) e = hipStreamWaitEvent(side0, ev_fork, 0);
+    if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+    int rc = K22_OK;
+    for (int i = lo; i < hi && !rc; ++i) rc = kid[0]->ops[i](s0);
+    int rc1 = rc;
+    for (int i = lo; i < hi && !rc1; ++i) rc1 = kid[1]->ops[i](side);
+    e = hipEventRecord(ev_join, side);
+    if (e == hipSuccess) e = hipStreamWaitEvent(st, ev_join, 0);
+    if (e == hipSuccess && own) { e = hipEventRecord(ev_join0, side0); if (e == hipSuccess) e = hipStreamWaitEvent(st, ev_join0, 0); }
+    if (rc1) return rc1;
+    if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+    for (int kk = 0; kk < 2; ++kk) for (int i = hi; i < nops; ++i) { int r_ = kid[kk]->ops[i](st); if (r_) return r_; }
+    return K22_OK;
+  }
+  int exec_eager(hipStream_t st) { const int rc = exec(st); if (rc == K22_OK) warmed = true; return rc; }
+  // first forward of a plan / binding: fragment-major weight copies, tile configurations the table does not know
+  int prepare_run(hipStream_t st) {
+    for (int i = 0; i < nparts(); ++i) {
+      K22UNet* k = part(i);
+      if (!k->frag_done) { int rc = k->repack_frags(st); if (rc) return rc; }
+      if (k->autotune && !k->tuned_done) {
+        int rc = k->tune_all(st);
+        if (rc) return rc;
+        k->tuned_done = true;
+      }
+    }
+    return K22_OK;
+  }
+  void drop_graphs() {
+    if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+    if (loop_exec) { (void)hipGraphExecDestroy(loop_exec); loop_exec = nullptr; }
+  }
+  // plan for batch nB: two kids of nB / 2 when the batch is even and chains are on, else this engine's own op list
+  int plan_top(int nB, int nH, int nW) {
+    if (kid[0] == nullptr || nB < 2 || nB % 2) { chained = false; return plan(nB, nH, nW); }
+    if (nB > 8) return k22_set_error(K22_EINVAL, "unet: batch (2*bs) must be <= 8 per engine call");
+    for (int i = 0; i < 2; ++i) { int rc = kid[i]->plan(nB / 2, nH, nW); if (rc) return rc; }
+    chained = true;
+    B = nB; H = nH; W = nW;
+    ops.clear(); cond_ops.clear(); hint_ops.clear(); tuned.clear();
+    drop_graphs();
+    ws = nullptr; cond_set = false; hint_set = false; warmed = false;
+    kid_off[0] = 0;
+    kid_off[1] = (kid[0]->ws_bytes + 255) / 256 * 256 + (getenv("K22_CHAINS_PAD") ? (size_t)atol(getenv("K22_CHAINS_PAD")) : 0);
+    comb_off = kid_off[1] + (kid[1]->ws_bytes + 255) / 256 * 256;
+    ws_bytes = comb_off + (size_t)nB * cfg.out_channels * nH * nW * 4 + 256;
+    if (!side) {
+      hipError_t e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_join, hipEventDisableTiming);
+      if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+    }
+    return K22_OK;
+  }
+
   ~K22UNet() {
     if (loop_exec) (void)hipGraphExecDestroy(loop_exec);
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (side) (void)hipStreamDestroy(side);
+    delete kid[0];
+    delete kid[1];
   }
 
   // One forward on `st`: the op list in order.  (A variant that forked the time-embedding / FiLM GEMV onto a second stream,
@@ -802,6 +917,19 @@ int k22_unet_create(const K22UNetConfig* cfg, const K22Weight* weights, int n_we
     u->fuse_skip = f ? (atoi(f) != 0) : 1;
   }
   for (int i = 0; i < n_weights; ++i) u->w[weights[i].name] = weights[i].ptr;
+  {
+    const char* ch = getenv("K22_CHAINS");   // 2 = an even batch as two half-batch chains (experimental, see K22UNet::kid); default 1
+    if (ch && atoi(ch) == 2) {
+      for (int i = 0; i < 2; ++i) {
+        K22UNet* k = new K22UNet();
+        k->cfg = u->cfg; k->dtype = u->dtype; k->sdt = u->sdt; k->esz = u->esz;
+        k->autotune = u->autotune; k->gn_onepass = u->gn_onepass; k->gn_fused = u->gn_fused; k->stream_frag = u->stream_frag;
+        k->fuse_gn = u->fuse_gn; k->fuse_skip = u->fuse_skip;
+        k->w = u->w;
+        u->kid[i] = k;
+      }
+    }
+  }
   *out = u;
   return K22_OK;
 }
@@ -810,7 +938,7 @@ void k22_unet_destroy(K22UNet* u) { delete u; }
 
 int k22_unet_plan(K22UNet* u, int B, int H, int W, size_t* workspace_bytes) {
   if (!u || !workspace_bytes) return k22_set_error(K22_EINVAL, "unet_plan: null argument");
-  int rc = u->plan(B, H, W);
+  int rc = u->plan_top(B, H, W);
   if (rc) return rc;
   *workspace_bytes = u->ws_bytes;
   return K22_OK;
@@ -818,13 +946,19 @@ int k22_unet_plan(K22UNet* u, int B, int H, int W, size_t* workspace_bytes) {
 
 int k22_unet_bind(K22UNet* u, void* workspace, size_t workspace_bytes) {
   if (!u || !workspace) return k22_set_error(K22_EINVAL, "unet_bind: null argument");
-  if (u->ops.empty()) return k22_set_error(K22_EINVAL, "unet_bind: plan first");
+  if (u->ops.empty() && !u->chained) return k22_set_error(K22_EINVAL, "unet_bind: plan first");
   if (workspace_bytes < u->ws_bytes) return k22_set_error(K22_ENOMEM, "unet_bind: workspace too small");
   if ((uintptr_t)workspace % 256) return k22_set_error(K22_EINVAL, "unet_bind: workspace must be 256-byte aligned");
   u->ws = reinterpret_cast<char*>(workspace);
   u->cond_set = false; u->hint_set = false; u->frag_done = false;
-  if (u->graph_exec) { (void)hipGraphExecDestroy(u->graph_exec); u->graph_exec = nullptr; }
-  if (u->loop_exec) { (void)hipGraphExecDestroy(u->loop_exec); u->loop_exec = nullptr; }
+  u->drop_graphs();
+  if (u->chained)
+    for (int i = 0; i < 2; ++i) {
+      K22UNet* k = u->kid[i];
+      k->ws = u->ws + u->kid_off[i];
+      k->cond_set = false; k->hint_set = false; k->frag_done = false;
+      k->drop_graphs();
+    }
   return K22_OK;
 }
 
@@ -836,15 +970,20 @@ int k22_unet_set_condition(K22UNet* u, const float* full_emb, const float* poole
   if (!image_emb) return k22_set_error(K22_EINVAL, "unet_set_condition: image_emb is required");
   if (c.head_type == 0 && (!full_emb || !pooled_emb)) return k22_set_error(K22_EINVAL, "unet_set_condition: the 2.1 head needs full_emb and pooled_emb");
   hipError_t e;
-  if (c.head_type == 0) {
-    e = hipMemcpyAsync(u->ptr(u->s_full), full_emb, (size_t)u->B * ntext * c.text_dim1 * 4, hipMemcpyDeviceToDevice, st);
+  const size_t pb = (size_t)u->partB();
+  for (int i = 0; i < u->nparts(); ++i) {
+    K22UNet* k = u->part(i);
+    if (c.head_type == 0) {
+      e = hipMemcpyAsync(k->ptr(k->s_full), full_emb + i * pb * ntext * c.text_dim1, pb * ntext * c.text_dim1 * 4, hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+      e = hipMemcpyAsync(k->ptr(k->s_pool), pooled_emb + i * pb * c.text_dim2, pb * c.text_dim2 * 4, hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+    }
+    e = hipMemcpyAsync(k->ptr(k->s_imgemb), image_emb + i * pb * c.image_dim, pb * c.image_dim * 4, hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-    e = hipMemcpyAsync(u->ptr(u->s_pool), pooled_emb, (size_t)u->B * c.text_dim2 * 4, hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+    for (auto& op : k->cond_ops) { int rc = op(st); if (rc) return rc; }
+    k->cond_set = true;
   }
-  e = hipMemcpyAsync(u->ptr(u->s_imgemb), image_emb, (size_t)u->B * c.image_dim * 4, hipMemcpyDeviceToDevice, st);
-  if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-  for (auto& op : u->cond_ops) { int rc = op(st); if (rc) return rc; }
   u->cond_set = true;
   return K22_OK;
 }
@@ -854,9 +993,14 @@ int k22_unet_set_hint(K22UNet* u, const float* hint, void* stream) {
   if (!u->cfg.hint_channels) return k22_set_error(K22_EINVAL, "unet_set_hint: this UNet has no hint input (hint_channels == 0)");
   if (!hint) return k22_set_error(K22_EINVAL, "unet_set_hint: null hint");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipError_t e = hipMemcpyAsync(u->ptr(u->s_hintin), hint, (size_t)u->B * u->cfg.hint_channels * 64 * u->H * u->W * 4, hipMemcpyDeviceToDevice, st);
-  if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-  for (auto& op : u->hint_ops) { int rc = op(st); if (rc) return rc; }
+  const size_t per = (size_t)u->partB() * u->cfg.hint_channels * 64 * u->H * u->W;
+  for (int i = 0; i < u->nparts(); ++i) {
+    K22UNet* k = u->part(i);
+    hipError_t e = hipMemcpyAsync(k->ptr(k->s_hintin), hint + i * per, per * 4, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+    for (auto& op : k->hint_ops) { int rc = op(st); if (rc) return rc; }
+    k->hint_set = true;
+  }
   u->hint_set = true;
   return K22_OK;
 }
@@ -873,23 +1017,22 @@ int k22_unet_forward(K22UNet* u, const float* x, const float* timesteps, const f
 #define K22_CPY(dst, src, bytes)                                                   \
   e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);                \
   if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-  K22_CPY(u->ptr(u->s_xin), x, (size_t)u->B * 4 * hw * 4);
-  K22_CPY(u->ptr(u->s_t), timesteps, (size_t)u->B * 4);
-  if (u->cfg.in_channels == 9) {
-    K22_CPY(u->ptr(u->s_img), inpaint_image, (size_t)u->B * 4 * hw * 4);
-    K22_CPY(u->ptr(u->s_mask), inpaint_mask, (size_t)u->B * hw * 4);
+  const size_t pb = (size_t)u->partB();
+  for (int i = 0; i < u->nparts(); ++i) {
+    K22UNet* k = u->part(i);
+    K22_CPY(k->ptr(k->s_xin), x + i * pb * 4 * hw, pb * 4 * hw * 4);
+    K22_CPY(k->ptr(k->s_t), timesteps + i * pb, pb * 4);
+    if (u->cfg.in_channels == 9) {
+      K22_CPY(k->ptr(k->s_img), inpaint_image + i * pb * 4 * hw, pb * 4 * hw * 4);
+      K22_CPY(k->ptr(k->s_mask), inpaint_mask + i * pb * hw, pb * hw * 4);
+    }
   }
-  if (!u->frag_done) { int rc = u->repack_frags(st); if (rc) return rc; }
-  if (u->autotune && !u->tuned_done) {
-    // first forward on this plan: conv / GEMM problems the tile table does not know are measured on the device
-    int rc = u->tune_all(st);
-    if (rc) return rc;
-    u->tuned_done = true;
-  }
+  // first forward on this plan: fragment-major weight copies; conv / GEMM problems the tile table does not know are measured on the device
+  { int rc = u->prepare_run(st); if (rc) return rc; }
   if (use_graph) {
     if (!u->graph_exec) {
       // warm-up eagerly once (sets function attributes), then capture
-      if (!u->warmed) { int rc = u->run_ops_eager(st); if (rc) return rc; }
+      if (!u->warmed) { int rc = u->exec_eager(st); if (rc) return rc; }
       hipGraph_t g = nullptr;
       if (!u->cap_stream) {
         e = hipStreamCreateWithFlags(&u->cap_stream, hipStreamNonBlocking);
@@ -897,7 +1040,7 @@ int k22_unet_forward(K22UNet* u, const float* x, const float* timesteps, const f
       }
       e = hipStreamBeginCapture(u->cap_stream, hipStreamCaptureModeThreadLocal);
       if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-      const int rc = u->run_ops(u->cap_stream);
+      const int rc = u->exec(u->cap_stream);
       e = hipStreamEndCapture(u->cap_stream, &g);
       if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
       if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
@@ -908,10 +1051,13 @@ int k22_unet_forward(K22UNet* u, const float* x, const float* timesteps, const f
     e = hipGraphLaunch(u->graph_exec, st);
     if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
   } else {
-    int rc = u->run_ops_eager(st);
+    int rc = u->exec_eager(st);
     if (rc) return rc;
   }
-  K22_CPY(out, u->ptr(u->s_out), (size_t)u->B * u->cfg.out_channels * hw * 4);
+  for (int i = 0; i < u->nparts(); ++i) {
+    K22UNet* k = u->part(i);
+    K22_CPY(out + i * pb * u->cfg.out_channels * hw, k->ptr(k->s_out), pb * u->cfg.out_channels * hw * 4);
+  }
 #undef K22_CPY
   return K22_OK;
 }
@@ -939,35 +1085,45 @@ int k22_unet_sample_loop(K22UNet* u, float* x, float* x_tmp, const float* timest
   if (pct_index >= 4 * HW) return k22_set_error(K22_EINVAL, "unet_sample_loop: percentile index out of range");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipError_t e;
-  if (!u->frag_done) { int rc = u->repack_frags(st); if (rc) return rc; }
-  if (u->autotune && !u->tuned_done) {
-    int rc = u->tune_all(st);
-    if (rc) return rc;
-    u->tuned_done = true;
-  }
+  { int rc = u->prepare_run(st); if (rc) return rc; }
   const size_t half = (size_t)(B / 2) * 4 * HW * sizeof(float);
+  const size_t pb = (size_t)u->partB();   // chained: each kid runs one half of the CFG batch ([cond] / [uncond]): pb == B / 2
   // one pass over the loop on `s`: what is captured is exactly what an eager call runs
   auto run_loop = [&](hipStream_t s) -> int {
     hipError_t er;
     if (u->cfg.in_channels == 9) {
-      er = hipMemcpyAsync(u->ptr(u->s_img), inpaint_image, (size_t)B * 4 * HW * 4, hipMemcpyDeviceToDevice, s);
-      if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
-      er = hipMemcpyAsync(u->ptr(u->s_mask), inpaint_mask, (size_t)B * HW * 4, hipMemcpyDeviceToDevice, s);
-      if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
+      for (int i = 0; i < u->nparts(); ++i) {
+        K22UNet* kk = u->part(i);
+        er = hipMemcpyAsync(kk->ptr(kk->s_img), inpaint_image + i * pb * 4 * HW, pb * 4 * HW * 4, hipMemcpyDeviceToDevice, s);
+        if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
+        er = hipMemcpyAsync(kk->ptr(kk->s_mask), inpaint_mask + i * pb * HW, pb * HW * 4, hipMemcpyDeviceToDevice, s);
+        if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
+      }
     }
     float* cur = x; float* nxt = x_tmp;
     for (int k = 0; k < n_steps; ++k) {
       // model_fn: the UNet sees the first half twice (kandinsky2_1_model.py:223-225)
+      if (u->chained) {
+        for (int i = 0; i < 2; ++i) {
+          er = hipMemcpyAsync(u->kid[i]->ptr(u->kid[i]->s_xin), cur, half, hipMemcpyDeviceToDevice, s);
+          if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
+          er = hipMemcpyAsync(u->kid[i]->ptr(u->kid[i]->s_t), timesteps + (size_t)k * B + i * pb, pb * 4, hipMemcpyDeviceToDevice, s);
+          if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
+        }
+      } else {
       er = hipMemcpyAsync(u->ptr(u->s_xin), cur, half, hipMemcpyDeviceToDevice, s);
       if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
       er = hipMemcpyAsync(u->ptr(u->s_xin) + half, cur, half, hipMemcpyDeviceToDevice, s);
       if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
       er = hipMemcpyAsync(u->ptr(u->s_t), timesteps + (size_t)k * B, (size_t)B * 4, hipMemcpyDeviceToDevice, s);
       if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
-      int rc = u->run_ops(s);
+      }
+      int rc = u->exec(s);
+      if (rc) return rc;
+      rc = u->fetch_out(s);
       if (rc) return rc;
       SamplerParams p = {};
-      p.x = cur; p.model_out = u->ptr<float>(u->s_out); p.noise = noise_seq + (size_t)k * B * 4 * HW; p.init_img = init_img; p.mask = mask;
+      p.x = cur; p.model_out = u->model_out(); p.noise = noise_seq + (size_t)k * B * 4 * HW; p.init_img = init_img; p.mask = mask;
       p.table = table; p.step = nullptr; p.step_host = table_rows[k]; p.guidance = guidance; p.clamp_lo = clamp_lo; p.clamp_hi = clamp_hi;
       p.use_cfg = 1; p.n_lo = pct_index; p.gamma = pct_gamma;
       p.s_buf = reinterpret_cast<float*>(scratch); p.x0_buf = reinterpret_cast<float*>(scratch) + 64;
@@ -995,17 +1151,20 @@ int k22_unet_sample_loop(K22UNet* u, float* x, float* x_tmp, const float* timest
     if (u->loop_exec) { (void)hipGraphExecDestroy(u->loop_exec); u->loop_exec = nullptr; }
     if (!u->warmed) {   // first forward of this plan: run one step's ops eagerly (function attributes, code load) on a scratch input; a re-capture
                         // for other scalars / buffers (guidance, step count: they are baked into the graph's nodes) does not repeat it
-      e = hipMemsetAsync(u->ptr(u->s_xin), 0, (size_t)B * 4 * HW * 4, st);
-      if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-      e = hipMemcpyAsync(u->ptr(u->s_t), timesteps, (size_t)B * 4, hipMemcpyDeviceToDevice, st);
-      if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-      if (u->cfg.in_channels == 9) {
-        e = hipMemcpyAsync(u->ptr(u->s_img), inpaint_image, (size_t)B * 4 * HW * 4, hipMemcpyDeviceToDevice, st);
+      for (int i = 0; i < u->nparts(); ++i) {
+        K22UNet* kk = u->part(i);
+        e = hipMemsetAsync(kk->ptr(kk->s_xin), 0, pb * 4 * HW * 4, st);
         if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-        e = hipMemcpyAsync(u->ptr(u->s_mask), inpaint_mask, (size_t)B * HW * 4, hipMemcpyDeviceToDevice, st);
+        e = hipMemcpyAsync(kk->ptr(kk->s_t), timesteps + i * pb, pb * 4, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+        if (u->cfg.in_channels == 9) {
+          e = hipMemcpyAsync(kk->ptr(kk->s_img), inpaint_image + i * pb * 4 * HW, pb * 4 * HW * 4, hipMemcpyDeviceToDevice, st);
+          if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+          e = hipMemcpyAsync(kk->ptr(kk->s_mask), inpaint_mask + i * pb * HW, pb * HW * 4, hipMemcpyDeviceToDevice, st);
+          if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+        }
       }
-      int rc = u->run_ops_eager(st);
+      int rc = u->exec_eager(st);
       if (rc) return rc;
       e = hipStreamSynchronize(st);
       if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
@@ -1031,19 +1190,25 @@ int k22_unet_sample_loop(K22UNet* u, float* x, float* x_tmp, const float* timest
   return K22_OK;
 }
 
-int k22_unet_num_ops(const K22UNet* u) { return u ? (int)u->ops.size() : 0; }
+int k22_unet_num_ops(const K22UNet* u) {
+  if (!u) return 0;
+  int n = 0;
+  for (int i = 0; i < u->nparts(); ++i) n += (int)u->part(i)->ops.size();
+  return n;
+}
 
 int k22_unet_set_autotune(K22UNet* u, int on) {
   if (!u) return k22_set_error(K22_EINVAL, "unet_set_autotune: null handle");
-  if (!u->ops.empty() && (on != 0) != (u->autotune != 0)) return k22_set_error(K22_EINVAL, "unet_set_autotune: call before k22_unet_plan");
+  if ((!u->ops.empty() || u->chained) && (on != 0) != (u->autotune != 0)) return k22_set_error(K22_EINVAL, "unet_set_autotune: call before k22_unet_plan");
   u->autotune = on ? 1 : 0;
+  for (int i = 0; i < 2; ++i) if (u->kid[i]) u->kid[i]->autotune = u->autotune;
   return K22_OK;
 }
 
 // Text table of the chosen tile configurations (one line per distinct conv / GEMM problem of the plan).
 int k22_unet_tuning_report(const K22UNet* u, char* buf, size_t cap) {
   if (!u || !buf || cap == 0) return k22_set_error(K22_EINVAL, "unet_tuning_report: null argument");
-  const std::string out = tuning_report_text(u->tuned);
+  const std::string out = tuning_report_text(u->part(0)->tuned);   // (two chains: both kids run the same problems)
   snprintf(buf, cap, "%s", out.c_str());
   return K22_OK;
 }
@@ -1052,33 +1217,38 @@ int k22_unet_profile(K22UNet* u, int reps, double* ms, double* flops, double* by
   if (!u || !u->ws || !u->cond_set) return k22_set_error(K22_EINVAL, "unet_profile: run k22_unet_forward once first");
   if (reps < 1) reps = 1;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (!u->frag_done) { int rc0 = u->repack_frags(st); if (rc0) return rc0; }   // a profile before the first forward of this binding
-  const size_t n = u->ops.size();
-  std::vector<hipEvent_t> ev(2 * n);
-  for (auto& e : ev) { hipError_t r = hipEventCreate(&e); if (r != hipSuccess) return k22_set_error_hip(r, __FILE__, __LINE__); }
   for (int k = 0; k < OP_NKINDS; ++k) { ms[k] = 0.0; flops[k] = 0.0; bytes[k] = 0.0; launches[k] = 0; }
-  for (size_t i = 0; i < n; ++i) {
-    flops[u->ops[i].kind] += u->ops[i].flops + u->ops[i].flops2;  // a fused 1x1 skip is work of the conv launch
-    bytes[u->ops[i].kind] += u->ops[i].bytes;
-    launches[u->ops[i].kind] += u->ops[i].kernels;
-  }
   int rc = K22_OK;
-  for (int r = 0; r < reps && rc == K22_OK; ++r) {
+  // two chains: the kids are timed one after the other, op by op - ISOLATED device times of both halves, summed (the step itself
+  // overlaps them: the class times then add up to more than the step)
+  for (int part = 0; part < u->nparts() && rc == K22_OK; ++part) {
+    K22UNet* q = u->part(part);
+    if (!q->frag_done) { int rc0 = q->repack_frags(st); if (rc0) return rc0; }   // a profile before the first forward of this binding
+    const size_t n = q->ops.size();
+    std::vector<hipEvent_t> ev(2 * n);
+    for (auto& e : ev) { hipError_t r = hipEventCreate(&e); if (r != hipSuccess) return k22_set_error_hip(r, __FILE__, __LINE__); }
     for (size_t i = 0; i < n; ++i) {
-      (void)hipEventRecord(ev[2 * i], st);
-      rc = u->ops[i](st);
-      (void)hipEventRecord(ev[2 * i + 1], st);
-      if (rc) break;
+      flops[q->ops[i].kind] += q->ops[i].flops + q->ops[i].flops2;  // a fused 1x1 skip is work of the conv launch
+      bytes[q->ops[i].kind] += q->ops[i].bytes;
+      launches[q->ops[i].kind] += q->ops[i].kernels;
     }
-    hipError_t e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { rc = k22_set_error_hip(e, __FILE__, __LINE__); break; }
-    for (size_t i = 0; i < n; ++i) {
-      float t = 0.f;
-      (void)hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]);
-      ms[u->ops[i].kind] += (double)t / reps;
+    for (int r = 0; r < reps && rc == K22_OK; ++r) {
+      for (size_t i = 0; i < n; ++i) {
+        (void)hipEventRecord(ev[2 * i], st);
+        rc = q->ops[i](st);
+        (void)hipEventRecord(ev[2 * i + 1], st);
+        if (rc) break;
+      }
+      hipError_t e = hipStreamSynchronize(st);
+      if (e != hipSuccess) { rc = k22_set_error_hip(e, __FILE__, __LINE__); break; }
+      for (size_t i = 0; i < n; ++i) {
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]);
+        ms[q->ops[i].kind] += (double)t / reps;
+      }
     }
+    for (auto& e : ev) (void)hipEventDestroy(e);
   }
-  for (auto& e : ev) (void)hipEventDestroy(e);
   return rc;
 }
 
