@@ -151,17 +151,17 @@ struct K22UNet {
   // half-batch engines ("kids": same weights, own workspace) on two streams forked from and joined into the caller's - in the captured
   // graph two parallel branches - and one chain's latency-bound stretches overlap the other's MFMA-bound ones.  Measured at C2 (bf16,
   // tools/two_stream_probe.py, two separately launched graphs on two streams): 8.20 ms for one B = 2 chain, 5.89 ms for one B = 1 chain
-  // alone, 7.31 ms for two B = 1 chains overlapped (-11 %).  EXPERIMENTAL, OFF by default (K22_CHAINS=2 enables it), for two measured
-  // reasons (profiles/r04_two_chains.txt): (1) as two branches of ONE captured graph - the form the whole-loop graph needs - hipGraph
-  // gave no overlap at all: 139.5 steps/s against 139.8 for the single chain; (2) the split-precision engine is NOT reproducible under
-  // it: with the kids' kernels overlapping over a whole forward (never within a 22-op window) the first image of the second chain came
-  // out 2e-2 off in ~70 % of the forwards while bf16 / fp16 / fp32 stayed bit-stable and the serial order of the same kids is exact - an
-  // interaction that is not understood yet, so nothing that must hold parity runs on it.  The parent engine then owns no ops of its own:
-  // only the fork / join, the graph(s), and the workspace layout [kid 0 | kid 1 | combined model output].
+  // alone, 7.31 ms for two B = 1 chains overlapped.  In the engine: one captured graph PER KID launched side by side, the step loop driven
+  // from the host: bf16 C2 152.5 steps/s against 146.9 (+3.9 %), C4 -5 %, bit-reproducible for bf16 / fp16 / fp32 (as two branches of ONE
+  // captured graph hipGraph gave no overlap at all).  OPT-IN (K22_CHAINS=2), off by default and never used by the split-precision engine:
+  // with both kids' kernels launched eagerly and drifting apart over a whole forward the FIRST image of the second chain came out 2e-2 off
+  // in ~70 % of the f16x3 forwards (never with bf16 / fp16 / fp32, never with the kids on one stream, never within a 22-op window) - an
+  // interaction that is not understood yet (profiles/r04_two_chains.txt), so nothing that must hold parity runs on it by default.  The
+  // parent engine owns no ops of its own: only the fork / join and the workspace layout [kid 0 | kid 1 | combined model output].
   K22UNet* kid[2] = {nullptr, nullptr};
   bool chained = false;
-  hipStream_t side = nullptr, side0 = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join0 = nullptr;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   size_t kid_off[2] = {0, 0}, comb_off = 0;
   int nparts() const { return chained ? 2 : 1; }
   K22UNet* part(int i) { return chained ? kid[i] : this; }
@@ -179,39 +179,58 @@ struct K22UNet {
     return K22_OK;
   }
   // one forward of the whole batch on `st` (inputs staged, conditioning set): the op list, or the two kids' op lists in parallel
+  int fork_side(hipStream_t st) {
+    hipError_t e = hipEventRecord(ev_fork, st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(side, ev_fork, 0);
+    return e == hipSuccess ? (int)K22_OK : k22_set_error_hip(e, __FILE__, __LINE__);
+  }
+  int join_side(hipStream_t st) {
+    hipError_t e = hipEventRecord(ev_join, side);
+    if (e == hipSuccess) e = hipStreamWaitEvent(st, ev_join, 0);
+    return e == hipSuccess ? (int)K22_OK : k22_set_error_hip(e, __FILE__, __LINE__);
+  }
   int exec(hipStream_t st) {
     if (!chained) return run_ops(st);
     static const bool serial = getenv("K22_CHAINS_SERIAL") && atoi(getenv("K22_CHAINS_SERIAL")) != 0;   // debug: both kids on the caller's stream
     if (serial) { int rc0 = kid[0]->run_ops(st); return rc0 ? rc0 : kid[1]->run_ops(st); }
-    // debug: ops [lo, hi) of both kids run concurrently, the rest serially on the caller's stream
-    static const int dbg_lo = getenv("K22_CHAINS_LO") ? atoi(getenv("K22_CHAINS_LO")) : 0;
-    static const int dbg_hi = getenv("K22_CHAINS_HI") ? atoi(getenv("K22_CHAINS_HI")) : (1 << 30);
-    const int nops = (int)kid[0]->ops.size();
-    const int lo = dbg_lo < nops ? dbg_lo : nops, hi = dbg_hi < nops ? dbg_hi : nops;
-    for (int kk = 0; kk < 2; ++kk) for (int i = 0; i < lo; ++i) { int r_ = kid[kk]->ops[i](st); if (r_) return r_; }
-    // debug K22_CHAINS_OWN=1: BOTH kids on private non-blocking streams (the caller's stream may be the legacy NULL stream)
-    static const bool own = getenv("K22_CHAINS_OWN") && atoi(getenv("K22_CHAINS_OWN")) != 0;
-    if (own && !side0) {
-      hipError_t e0 = hipStreamCreateWithFlags(&side0, hipStreamNonBlocking);
-      if (e0 == hipSuccess) e0 = hipEventCreateWithFlags(&ev_join0, hipEventDisableTiming);
-      if (e0 != hipSuccess) return k22_set_error_hip(e0, __FILE__, __LINE__);
+    int rc = fork_side(st);
+    if (rc) return rc;
+    rc = kid[0]->run_ops(st);
+    const int rc1 = rc ? rc : kid[1]->run_ops(side);
+    rc = join_side(st);
+    return rc1 ? rc1 : rc;
+  }
+  // Two chains, graph form: ONE captured graph per kid, launched side by side on the caller's stream and the side stream.  (As two branches
+  // of one captured graph hipGraph ran the chains back to back - measured, profiles/r04_two_chains.txt - so the parent captures nothing.)
+  int capture_own_graph(hipStream_t st) {
+    if (graph_exec) return K22_OK;
+    if (!warmed) { int rc = run_ops_eager(st); if (rc) return rc; }
+    hipError_t e;
+    if (!cap_stream) {
+      e = hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking);
+      if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
     }
-    hipStream_t s0 = own ? side0 : st;
-    hipError_t e = hipEventRecord(ev_fork, st);
-    if (e == hipSuccess) e = hipStreamWaitEvent(side, ev_fork, 0);
-    if (e == hipSuccess && own) e = hipStreamWaitEvent(side0, ev_fork, 0);
+    hipGraph_t g = nullptr;
+    e = hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-    int rc = K22_OK;
-    for (int i = lo; i < hi && !rc; ++i) rc = kid[0]->ops[i](s0);
-    int rc1 = rc;
-    for (int i = lo; i < hi && !rc1; ++i) rc1 = kid[1]->ops[i](side);
-    e = hipEventRecord(ev_join, side);
-    if (e == hipSuccess) e = hipStreamWaitEvent(st, ev_join, 0);
-    if (e == hipSuccess && own) { e = hipEventRecord(ev_join0, side0); if (e == hipSuccess) e = hipStreamWaitEvent(st, ev_join0, 0); }
-    if (rc1) return rc1;
+    const int rc = run_ops(cap_stream);
+    e = hipStreamEndCapture(cap_stream, &g);
+    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
     if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-    for (int kk = 0; kk < 2; ++kk) for (int i = hi; i < nops; ++i) { int r_ = kid[kk]->ops[i](st); if (r_) return r_; }
+    e = hipGraphInstantiate(&graph_exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) { graph_exec = nullptr; return k22_set_error_hip(e, __FILE__, __LINE__); }
     return K22_OK;
+  }
+  int exec_kid_graphs(hipStream_t st) {
+    for (int i = 0; i < 2; ++i) { int rc = kid[i]->capture_own_graph(st); if (rc) return rc; }
+    int rc = fork_side(st);
+    if (rc) return rc;
+    hipError_t e = hipGraphLaunch(kid[0]->graph_exec, st);
+    if (e == hipSuccess) e = hipGraphLaunch(kid[1]->graph_exec, side);
+    rc = join_side(st);
+    if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+    return rc;
   }
   int exec_eager(hipStream_t st) { const int rc = exec(st); if (rc == K22_OK) warmed = true; return rc; }
   // first forward of a plan / binding: fragment-major weight copies, tile configurations the table does not know
@@ -242,7 +261,7 @@ struct K22UNet {
     drop_graphs();
     ws = nullptr; cond_set = false; hint_set = false; warmed = false;
     kid_off[0] = 0;
-    kid_off[1] = (kid[0]->ws_bytes + 255) / 256 * 256 + (getenv("K22_CHAINS_PAD") ? (size_t)atol(getenv("K22_CHAINS_PAD")) : 0);
+    kid_off[1] = (kid[0]->ws_bytes + 255) / 256 * 256;
     comb_off = kid_off[1] + (kid[1]->ws_bytes + 255) / 256 * 256;
     ws_bytes = comb_off + (size_t)nB * cfg.out_channels * nH * nW * 4 + 256;
     if (!side) {
@@ -919,7 +938,7 @@ int k22_unet_create(const K22UNetConfig* cfg, const K22Weight* weights, int n_we
   for (int i = 0; i < n_weights; ++i) u->w[weights[i].name] = weights[i].ptr;
   {
     const char* ch = getenv("K22_CHAINS");   // 2 = an even batch as two half-batch chains (experimental, see K22UNet::kid); default 1
-    if (ch && atoi(ch) == 2) {
+    if (ch && atoi(ch) == 2 && cfg->dtype != K22_F16X3) {   // (never for the split-precision engine: see K22UNet::kid)
       for (int i = 0; i < 2; ++i) {
         K22UNet* k = new K22UNet();
         k->cfg = u->cfg; k->dtype = u->dtype; k->sdt = u->sdt; k->esz = u->esz;
@@ -1029,7 +1048,10 @@ int k22_unet_forward(K22UNet* u, const float* x, const float* timesteps, const f
   }
   // first forward on this plan: fragment-major weight copies; conv / GEMM problems the tile table does not know are measured on the device
   { int rc = u->prepare_run(st); if (rc) return rc; }
-  if (use_graph) {
+  if (use_graph && u->chained) {
+    int rc = u->exec_kid_graphs(st);
+    if (rc) return rc;
+  } else if (use_graph) {
     if (!u->graph_exec) {
       // warm-up eagerly once (sets function attributes), then capture
       if (!u->warmed) { int rc = u->exec_eager(st); if (rc) return rc; }
@@ -1118,7 +1140,7 @@ int k22_unet_sample_loop(K22UNet* u, float* x, float* x_tmp, const float* timest
       er = hipMemcpyAsync(u->ptr(u->s_t), timesteps + (size_t)k * B, (size_t)B * 4, hipMemcpyDeviceToDevice, s);
       if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
       }
-      int rc = u->exec(s);
+      int rc = (u->chained && use_graph) ? u->exec_kid_graphs(s) : u->exec(s);
       if (rc) return rc;
       rc = u->fetch_out(s);
       if (rc) return rc;
@@ -1138,7 +1160,9 @@ int k22_unet_sample_loop(K22UNet* u, float* x, float* x_tmp, const float* timest
     }
     return K22_OK;
   };
-  if (!use_graph) return run_loop(st);
+  // two chains: the loop is driven from the host (per step: stage, two graph launches side by side, join, sampler kernels) - the
+  // whole-loop graph would put both chains into ONE graph, whose branches hipGraph runs back to back
+  if (!use_graph || u->chained) return run_loop(st);
   // key of the captured loop: every pointer and scalar baked into its nodes
   std::vector<unsigned long long> key = {(unsigned long long)(uintptr_t)x, (unsigned long long)(uintptr_t)x_tmp, (unsigned long long)(uintptr_t)timesteps,
       (unsigned long long)(uintptr_t)noise_seq, (unsigned long long)(uintptr_t)init_img, (unsigned long long)(uintptr_t)mask,

@@ -4,6 +4,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     import kandinsky2_amd as k22
+    from kandinsky2_amd import _lib
+    if os.environ.get("CONV_ALGO"): _lib.check(_lib.lib().k22_set_option(b"conv_algo", int(os.environ["CONV_ALGO"])))
+    if os.environ.get("GEMM_ALGO"): _lib.check(_lib.lib().k22_set_option(b"gemm_algo", int(os.environ["GEMM_ALGO"])))
     fx = torch.load(os.path.join(ROOT, "tests", "golden", "c4_inpaint.pt"), weights_only=False)
     arch = k22.make_arch(k22.MODEL_CONFIG_2_1, inpainting=True)
     sd = k22.init_unet_state_dict(arch, seed=0)
@@ -29,9 +32,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print("DETAIL", os.environ.get("TAG"), "vs golden:", ["%.2e" % v for v in d], "repeat equal:", [torch.equal(outs[0], o) for o in outs[1:]])
     torch.save(outs[0], f"/tmp/out_{os.environ.get('TAG')}.pt")
 else:
-    cfgs = {}
-    for lo in range(0, 242, 22):
-        cfgs[f"w{lo}"] = dict(K22_CHAINS="2", USE_GRAPH="0", K22_CHAINS_LO=str(lo), K22_CHAINS_HI=str(lo + 22), REPS="14")
+    cfgs = {"heur_default": dict(K22_CHAINS="2", K22_AUTOTUNE="0", REPS="12"),
+            "heur_generic_conv": dict(K22_CHAINS="2", K22_AUTOTUNE="0", REPS="12", CONV_ALGO="1"),
+            "heur_gemm8": dict(K22_CHAINS="2", K22_AUTOTUNE="0", REPS="12", GEMM_ALGO="10"),
+            "heur_generic_conv_fp32attn": dict(K22_CHAINS="2", K22_AUTOTUNE="0", REPS="12", CONV_ALGO="1", K22_X3_ATTN_F32="1")}
     for tag, env in cfgs.items():
         e = dict(os.environ, TAG=tag, **env)
         r = subprocess.run([sys.executable, __file__, "child"], env=e, capture_output=True, text=True)
