@@ -69,11 +69,18 @@ template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float f) { return (
 template <> __device__ __forceinline__ float from_f32<float>(float f) { return f; }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-// SiLU from the two native transcendentals, x * rcp(1 + exp2(-x * log2 e)): ~3 ulp of fp32 in 6 instructions.  The IEEE form above
-// (precise expf + a true division) compiles to ~55 instructions per element: it made gn_apply_kernel VALU-bound (round 4: 58 VALU
-// per element in the ISA) and is unaffordable inside an MFMA kernel.  Used wherever the result is rounded to a 16-bit type or
-// split into fp16 halves right away (bf16 / fp16 / split-precision engines); the plain fp32 engine keeps the IEEE form.
+// SiLU from the two native transcendentals, x * rcp(1 + exp2(-x * log2 e)): a few ulp of fp32 in 6 instructions, where the IEEE form
+// above (precise expf + a true division) compiles to ~55.  Used ONLY by the split-precision engine's GroupNorm store (gn_apply's
+// out_x3, gn_rewrite16<x3_t>), whose parity gates were measured with it (C2 final latent 3.6e-6).  The bf16 / fp16 engines keep the
+// IEEE form: round 4 tried silu_fast there and measured (a) no speed-up of the bf16 step (GroupNorm class 1.16 -> 1.18 ms: those
+// launches are latency-, not VALU-bound) and (b) a WORSE fp16 / bf16 MoVQ decode against the reference goldens in 9 of 10 fp16
+// cases (768 px fp16: uint8 max diff 3 -> 6, 11.5 % -> 12.6 % of the bytes differ; bf16: 24 -> 36 grey levels), reproduced as an
+// A/B of two builds on one box (tools/gpu_silu_ab.sh, profiles/r04_silu_ab.txt); the IEEE form restores round 3's bits exactly.
+#ifdef K22_SILU_IEEE_EVERYWHERE   // measurement-only build: tools/gpu_silu_ab.sh
+__device__ __forceinline__ float silu_fast(float x) { return silu_f(x); }
+#else
 __device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }
+#endif
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float apply_act(float x, int act) {
   if (act == K22_ACT_SILU) return silu_f(x);

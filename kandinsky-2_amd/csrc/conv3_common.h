@@ -108,7 +108,7 @@ __device__ __forceinline__ u32x4_t gn_rewrite16(bf16_t, u32x4_t raw, const float
   float v[8];
   unpack2_bf16(raw.x, v[0], v[1]); unpack2_bf16(raw.y, v[2], v[3]); unpack2_bf16(raw.z, v[4], v[5]); unpack2_bf16(raw.w, v[6], v[7]);
 #pragma unroll
-  for (int k = 0; k < 8; ++k) v[k] = apply_act_sel<true>(v[k] * cf[2 * k] + cf[2 * k + 1], act);
+  for (int k = 0; k < 8; ++k) v[k] = apply_act(v[k] * cf[2 * k] + cf[2 * k + 1], act);
   const u32x4_t o = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7])};
   return border ? u32x4_t{0u, 0u, 0u, 0u} : o;
 }
@@ -116,7 +116,7 @@ __device__ __forceinline__ u32x4_t gn_rewrite16(f16_t, u32x4_t raw, const float*
   float v[8];
   unpack2_f16(raw.x, v[0], v[1]); unpack2_f16(raw.y, v[2], v[3]); unpack2_f16(raw.z, v[4], v[5]); unpack2_f16(raw.w, v[6], v[7]);
 #pragma unroll
-  for (int k = 0; k < 8; ++k) v[k] = apply_act_sel<true>(v[k] * cf[2 * k] + cf[2 * k + 1], act);
+  for (int k = 0; k < 8; ++k) v[k] = apply_act(v[k] * cf[2 * k] + cf[2 * k + 1], act);
   const u32x4_t o = {pack2_f16(v[0], v[1]), pack2_f16(v[2], v[3]), pack2_f16(v[4], v[5]), pack2_f16(v[6], v[7])};
   return border ? u32x4_t{0u, 0u, 0u, 0u} : o;
 }

@@ -194,9 +194,9 @@ __global__ __launch_bounds__(256) void gn_coeff_kernel(GnCoeffParams p) {
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyParams p) {
   constexpr int EPV = Vec16<T>::N;
-  // SiLU through the native exp2 / rcp wherever the result is rounded to 16 bits or split into fp16 halves right away (common.h:
-  // silu_fast; the same choice as the fused form of this pass in conv3_common.h: gn_rewrite16 - the two give the same bits)
-  const bool fast = sizeof(T) == 2 || p.out_x3 != 0;
+  // split-precision store: SiLU through the native exp2 / rcp (common.h: silu_fast; the same choice as the fused form of this pass in
+  // conv3_common.h: gn_rewrite16 - the two give the same bits).  The 16-bit engines keep the IEEE form: see common.h
+  const bool fast = p.out_x3 != 0;
   const int C = p.C0 + p.C1, CV = C / EPV;
   const int Ho = p.mode == 1 ? p.H / 2 : (p.mode == 2 ? p.H * 2 : p.H);
   const int Wo = p.mode == 1 ? p.W / 2 : (p.mode == 2 ? p.W * 2 : p.W);
@@ -385,12 +385,12 @@ __global__ __launch_bounds__(256) void gn_apply3_kernel(GnApply3Params q) {
         for (int k = 0; k < EPV; ++k) {
           float acc = 0.f;
 #pragma unroll
-          for (int u = 0; u < 4; ++u) acc += apply_act_sel<sizeof(T) == 2>(v[i][u].get(k) * A[k] + Bc[k], p.act);
+          for (int u = 0; u < 4; ++u) acc += apply_act(v[i][u].get(k) * A[k] + Bc[k], p.act);
           rr[k] = acc * 0.25f;
         }
       } else {
 #pragma unroll
-        for (int k = 0; k < EPV; ++k) rr[k] = apply_act_sel<sizeof(T) == 2>(v[i][0].get(k) * A[k] + Bc[k], p.act);
+        for (int k = 0; k < EPV; ++k) rr[k] = apply_act(v[i][0].get(k) * A[k] + Bc[k], p.act);
       }
 #pragma unroll
       for (int k = 0; k < NPL; ++k) o.set2(k, rr[2 * k], rr[2 * k + 1]);
@@ -560,12 +560,12 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(GnFusedParams q) {
           for (int k = 0; k < EPV; ++k) {
             float acc = 0.f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc += apply_act_sel<sizeof(T) == 2>(v[u][t].get(k) * A[k] + Bc[k], p.act);
+            for (int t = 0; t < 4; ++t) acc += apply_act(v[u][t].get(k) * A[k] + Bc[k], p.act);
             rr[k] = acc * 0.25f;
           }
         } else {
 #pragma unroll
-          for (int k = 0; k < EPV; ++k) rr[k] = apply_act_sel<sizeof(T) == 2>(v[u][0].get(k) * A[k] + Bc[k], p.act);
+          for (int k = 0; k < EPV; ++k) rr[k] = apply_act(v[u][0].get(k) * A[k] + Bc[k], p.act);
         }
 #pragma unroll
         for (int k = 0; k < EPV / 2; ++k) o.set2(k, rr[2 * k], rr[2 * k + 1]);

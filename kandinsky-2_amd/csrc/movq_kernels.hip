@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void spatialnorm_apply_kernel(SpatialNormParam
 #pragma unroll
     for (int k = 0; k < EPV; ++k) {
       const float norm = v.get(k) * A[k] + Bc[k];
-      r[k] = apply_act_sel<sizeof(T) == 2>(norm * sy[k] + sb[k], p.act);   // 16-bit decodes: SiLU from the native exp2 / rcp (common.h)
+      r[k] = apply_act(norm * sy[k] + sb[k], p.act);
     }
 #pragma unroll
     for (int k = 0; k < EPV / 2; ++k) o.set2(k, r[2 * k], r[2 * k + 1]);

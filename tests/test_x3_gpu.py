@@ -209,8 +209,13 @@ def test_groupnorm_writes_x3_chunks(C0, C1, H, W, act, mode, pad, film):
     want = outs[0].double()
     got = x3_unpack(outs[1])
     err = (got - want).abs()
-    assert (err <= torch.maximum(want.abs() * 2.0 ** -22, torch.full_like(err, 2.0 ** -24))).all()
-    assert torch.equal(outs[1].view(torch.int32), to_x3(outs[0], 1.0).view(torch.int32))   # exactly the chunks of the fp32 kernel's values
+    if act == 0:
+        assert (err <= torch.maximum(want.abs() * 2.0 ** -22, torch.full_like(err, 2.0 ** -24))).all()
+        assert torch.equal(outs[1].view(torch.int32), to_x3(outs[0], 1.0).view(torch.int32))   # exactly the chunks of the fp32 kernel's values
+    else:
+        # the x3 store computes SiLU from the native exp2 / rcp (common.h: silu_fast, ~3 ulp of fp32), the fp32 kernel the IEEE form:
+        # same value to a few fp32 ulps, then the same split
+        assert (err <= torch.maximum(want.abs() * 2.0 ** -20, torch.full_like(err, 2.0 ** -22))).all()
 
 
 @pytest.mark.parametrize("B,H,T,S", [(2, 2, 64, 87), (1, 3, 144, 87), (2, 4, 576, 87), (2, 1, 100, 5), (1, 12, 2304, 87)])
