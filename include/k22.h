@@ -41,7 +41,12 @@ extern "C" {
 
 int k22_version(void);
 const char* k22_last_error(void);
-/* Tuning knobs (process-wide): "igemm_stages" = 2..4 LDS-DMA pipeline depth (-1 default);
+/* Tuning knobs.  PROCESS-WIDE MUTABLE STATE, NOT RE-ENTRANT: these exist for the kernel-level test / measurement surface (k22_gemm,
+ * k22_conv3x3*, k22_groupnorm) and must not be changed while another thread is inside any k22_* call.  Leave them at their defaults
+ * in a process that runs engines (k22_unet_*, k22_prior_*, k22_movq_*, k22_encoder_*): engine launches carry the configuration of their
+ * tile-table line, but a line that says "generic kernel" (algo 0) is dispatched through the same switch these knobs override.
+ * Everything else in this header is re-entrant per handle (one handle = one stream at a time).
+ * Knobs: "igemm_stages" = 2..4 LDS-DMA pipeline depth (-1 default);
  * "igemm_xcd_remap" = 0/1 XCD-aware workgroup renumbering; "conv_algo" = 0 auto, 1 generic implicit GEMM,
  * 2 LDS-resident halo kernel for the 3x3 convolutions (3-7: its variants, see conv3_halo.hip; 8-9: measurement only);
  * "gemm_algo" = 0 generic implicit-GEMM kernel, 10 = 8-wave BM x 128 tile kernel where it applies;

@@ -396,3 +396,30 @@ int k22_sampler_step(const float* x, const float* model_out, const float* noise,
 }
 
 }  // extern "C"
+
+// ---- debug: LDS sentinel (tools/lds_victim_probe.py) -------------------------------------------------------------
+// Every workgroup fills `bytes` of dynamic LDS with a pattern, then re-reads it `spins` times and reports words that changed under it:
+// rec[0] = number of changed words seen, rec[1 + 4 * i ...] = (workgroup, byte offset, value found, spin) of the first 255 of them.
+// Nothing in the product launches it; it exists to find out which kernel on ANOTHER stream writes into LDS it does not own.
+__global__ __launch_bounds__(256) void lds_sentinel_kernel(int words, int spins, unsigned* rec) {
+  extern __shared__ unsigned sent_lds[];
+  for (int i = threadIdx.x; i < words; i += 256) sent_lds[i] = 0xA5000000u | (unsigned)i;
+  __syncthreads();
+  for (int s = 0; s < spins; ++s) {
+    for (int i = threadIdx.x; i < words; i += 256) {
+      const unsigned v = reinterpret_cast<volatile unsigned*>(sent_lds)[i];
+      if (v != (0xA5000000u | (unsigned)i)) {
+        const unsigned k = atomicAdd(rec, 1u);
+        if (k < 255u) { rec[1 + 4 * k] = blockIdx.x; rec[2 + 4 * k] = 4u * i; rec[3 + 4 * k] = v; rec[4 + 4 * k] = (unsigned)s; }
+        sent_lds[i] = 0xA5000000u | (unsigned)i;
+      }
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+extern "C" int k22_debug_lds_sentinel(int bytes, int workgroups, int spins, unsigned* rec, void* stream) {
+  if (bytes <= 0 || bytes > 64 * 1024 || (bytes & 3) || !rec) return k22_set_error(K22_EINVAL, "lds_sentinel: bytes in 4..65536, multiple of 4");
+  hipLaunchKernelGGL(lds_sentinel_kernel, dim3(workgroups), dim3(256), (size_t)bytes, reinterpret_cast<hipStream_t>(stream), bytes / 4, spins, rec);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}

@@ -195,8 +195,11 @@ struct K22UNet {
     if (serial) { int rc0 = kid[0]->run_ops(st); return rc0 ? rc0 : kid[1]->run_ops(st); }
     int rc = fork_side(st);
     if (rc) return rc;
-    rc = kid[0]->run_ops(st);
-    const int rc1 = rc ? rc : kid[1]->run_ops(side);
+    static const int dbg_swap = getenv("K22_CHAINS_SWAP") ? atoi(getenv("K22_CHAINS_SWAP")) : 0;   // debug (tools/chains_gap_probe.py):
+    int rc1;                                                                                           // 1 = kid 0 on the side stream, 2 = kid 1 enqueued first
+    if (dbg_swap == 1) { rc = kid[0]->run_ops(side); rc1 = rc ? rc : kid[1]->run_ops(st); }
+    else if (dbg_swap == 2) { rc = kid[1]->run_ops(side); rc1 = rc ? rc : kid[0]->run_ops(st); }
+    else { rc = kid[0]->run_ops(st); rc1 = rc ? rc : kid[1]->run_ops(side); }
     rc = join_side(st);
     return rc1 ? rc1 : rc;
   }
@@ -262,6 +265,7 @@ struct K22UNet {
     ws = nullptr; cond_set = false; hint_set = false; warmed = false;
     kid_off[0] = 0;
     kid_off[1] = (kid[0]->ws_bytes + 255) / 256 * 256;
+    if (const char* g = getenv("K22_KID_GAP_MB")) kid_off[1] += (size_t)atoi(g) << 20;   // debug: a guard region between the kids (tools/chains_gap_probe.py)
     comb_off = kid_off[1] + (kid[1]->ws_bytes + 255) / 256 * 256;
     ws_bytes = comb_off + (size_t)nB * cfg.out_channels * nH * nW * 4 + 256;
     if (!side) {
@@ -783,6 +787,10 @@ struct K22UNet {
     size_t off = 0;
     for (auto& s : slots) { s.off = off; off += (s.bytes + 255) / 256 * 256; }
     ws_bytes = off + 256;
+    if (getenv("K22_DBG_SLOTS")) {   // debug: the workspace map (tools/chains_gap_probe.py diffs workspaces of two forwards)
+      int i = 0;
+      for (auto& s : slots) { if (s.bytes) fprintf(stderr, "k22 slot %3d off %12zu bytes %12zu\n", i, s.off, s.bytes); ++i; }
+    }
     return K22_OK;
   }
 
@@ -938,7 +946,8 @@ int k22_unet_create(const K22UNetConfig* cfg, const K22Weight* weights, int n_we
   for (int i = 0; i < n_weights; ++i) u->w[weights[i].name] = weights[i].ptr;
   {
     const char* ch = getenv("K22_CHAINS");   // 2 = an even batch as two half-batch chains (experimental, see K22UNet::kid); default 1
-    if (ch && atoi(ch) == 2 && cfg->dtype != K22_F16X3) {   // (never for the split-precision engine: see K22UNet::kid)
+    const bool x3_kids = getenv("K22_CHAINS_X3") && atoi(getenv("K22_CHAINS_X3")) != 0;   // debug only (tools/chains_gap_probe.py)
+    if (ch && atoi(ch) == 2 && (cfg->dtype != K22_F16X3 || x3_kids)) {   // (never for the split-precision engine: see K22UNet::kid)
       for (int i = 0; i < 2; ++i) {
         K22UNet* k = new K22UNet();
         k->cfg = u->cfg; k->dtype = u->dtype; k->sdt = u->sdt; k->esz = u->esz;

@@ -623,7 +623,9 @@ static int launch_reduce(const IgemmParams& q, hipStream_t stream) {
 
 template <typename T, int BM, int BN, int STAGES, bool ARAW = false>
 static int launch_cfg(const IgemmParams& p, int splitk, hipStream_t stream) {
-  constexpr int smem = STAGES * (BM + BN) * 128;
+  constexpr int smem0 = STAGES * (BM + BN) * 128;
+  static const int dbg_pad = getenv("K22_DBG_LDS_PAD") ? atoi(getenv("K22_DBG_LDS_PAD")) : 0;   // debug (tools/lds_victim_probe.py)
+  const int smem = dbg_pad == 1 ? (smem0 + 1279) / 1280 * 1280 : (dbg_pad == 2 ? smem0 + 4096 : smem0);
   static LdsAttrGuard attr_guard;
   if (int rc_ = k22_ensure_lds_attr(attr_guard, reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, STAGES, ARAW>), smem, __FILE__, __LINE__)) return rc_;
   IgemmParams q = p;

@@ -28,6 +28,11 @@ Round 4 - SPLIT-PRECISION candidates.  The tensors stay fp32 in 
     :bf16x3  hi + lo with bf16 halves (16 mantissa bits)
 A mode may join several 'kinds:type' parts with '/', e.g. 'w:x3w/g+a+s:x3' = weights split, every activation operand split (three
 MFMAs); 'w:x3w/g+a+s:fp16' = weights split, activations rounded to fp16 as operands (two MFMAs).
+Round 4 - WINOGRAD F(2x2, 3x3) numerics (VERDICT r3 #5a, the go / no-go half that needs no GPU):
+    wino:T   every stride-1 3x3 convolution of the ResBlocks is evaluated as the engine would evaluate it on 16-bit MFMAs: the filter
+             transform U = G g G^T in fp32 from the fp32 weights, THEN rounded to T (pack time); the input transform V = B^T d B in fp32
+             from the operand as stored (kind g), THEN rounded to T (what the LDS fill would write); 16 products sum_c U V in fp32 (MFMA
+             accumulate); the output transform A^T M A in fp32.  The 3x3 weights are not pre-rounded by kind w in this mode.
 Nothing here is product code; bench.py / tests only read the committed result (tests/golden/drift_ablation.json).
 """
 import argparse
@@ -90,7 +95,9 @@ W_SUFFIXES = (".in_layers.2.weight", ".out_layers.3.weight", ".skip_connection.w
 def round_weights(sd, r):
     out = {}
     for k, v in sd.items():
-        if "w" in r.kinds and (k.endswith(W_SUFFIXES) or k == "to_model_dim_n.weight") and k.split(".")[0] in (
+        if "wino" in r.kinds and k.endswith((".in_layers.2.weight", ".out_layers.3.weight")):
+            out[k] = v                       # transformed in fp32 first, rounded after (conv3)
+        elif "w" in r.kinds and (k.endswith(W_SUFFIXES) or k == "to_model_dim_n.weight") and k.split(".")[0] in (
                 "input_blocks", "middle_block", "output_blocks", "to_model_dim_n"):
             out[k] = r(v, "w")
         else:
@@ -103,6 +110,31 @@ def gn(x, w, b, swish):
     return F.silu(y) if swish else y
 
 
+_BT = torch.tensor([[1., 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]])
+_G = torch.tensor([[1., 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]])
+_AT = torch.tensor([[1., 1, 1, 0], [0, 1, -1, -1]])
+_UCACHE = {}
+
+
+def conv3(x, w, b, r):
+    """3x3 'same' convolution; under kind 'wino' as Winograd F(2x2, 3x3) with the operand roundings of a 16-bit MFMA kernel."""
+    if "wino" not in r.kinds:
+        return F.conv2d(x, w, b, padding=1)
+    B, C, H, W = x.shape
+    O = w.shape[0]
+    assert H % 2 == 0 and W % 2 == 0
+    key = (w.data_ptr(), r.fn["wino"])
+    if key not in _UCACHE:
+        _UCACHE[key] = r(torch.einsum("ij,ocjk,lk->iloc", _G.to(w), w, _G.to(w)), "wino").reshape(16, O, C).contiguous()
+    U = _UCACHE[key]
+    th, tw = H // 2, W // 2
+    d = F.unfold(F.pad(x, (1, 1, 1, 1)), kernel_size=4, stride=2).view(B, C, 4, 4, th * tw)
+    V = r(torch.einsum("ij,bcjkt,lk->ilcbt", _BT.to(x), d, _BT.to(x)), "wino").reshape(16, C, B * th * tw)
+    M = torch.bmm(U, V).view(4, 4, O, B, th, tw)
+    Y = torch.einsum("pi,ilobyx,ql->boypxq", _AT.to(x), M, _AT.to(x)).reshape(B, O, H, W)
+    return Y + b.view(1, -1, 1, 1)
+
+
 def res_block(sd, pfx, x, emb, updown, r):
     h = gn(x, sd[pfx + ".in_layers.0.weight"], sd[pfx + ".in_layers.0.bias"], True)
     if updown == 1:
@@ -110,11 +142,11 @@ def res_block(sd, pfx, x, emb, updown, r):
     elif updown == 2:
         h, x = F.interpolate(h, scale_factor=2, mode="nearest"), F.interpolate(x, scale_factor=2, mode="nearest")
     h = r(h, "g")
-    h = r(F.conv2d(h, sd[pfx + ".in_layers.2.weight"], sd[pfx + ".in_layers.2.bias"], padding=1), "u")
+    h = r(conv3(h, sd[pfx + ".in_layers.2.weight"], sd[pfx + ".in_layers.2.bias"], r), "u")
     e = F.linear(F.silu(emb), sd[pfx + ".emb_layers.1.weight"], sd[pfx + ".emb_layers.1.bias"])[..., None, None]
     scale, shift = torch.chunk(e, 2, dim=1)
     h = gn(h, sd[pfx + ".out_layers.0.weight"], sd[pfx + ".out_layers.0.bias"], False) * (1 + scale) + shift
-    h = F.conv2d(r(F.silu(h), "g"), sd[pfx + ".out_layers.3.weight"], sd[pfx + ".out_layers.3.bias"], padding=1)
+    h = conv3(r(F.silu(h), "g"), sd[pfx + ".out_layers.3.weight"], sd[pfx + ".out_layers.3.bias"], r)
     if (pfx + ".skip_connection.weight") in sd:   # fused into the second convolution's accumulator by the engine: no rounding
         x = F.conv2d(r(x, "s"), sd[pfx + ".skip_connection.weight"], sd[pfx + ".skip_connection.bias"])
     return r(x + h, "h")
