@@ -561,3 +561,37 @@ def test_split_precision_emulation_meets_the_gate_on_the_oracle(golden_dir):
     assert runs["w:x3w/g+a+s:x3"]["final_max_abs"] <= 5e-6
     assert 5e-4 < runs["w:x3w/g+a+s:fp16"]["final_max_abs"] < 1e-3       # the two-MFMA candidate: inside the gate by 12 % only
     assert runs["w:bf16x3/g+a+s:bf16x3"]["final_max_abs"] <= 5e-5
+
+
+def test_winograd_emulation_matches_direct_convolution_and_its_recorded_drift(golden_dir):
+    """oracle/drift_ablation.py's Winograd F(2x2, 3x3) path (the CPU half of the go / no-go of DESIGN.md 9 R4-7): exact against F.conv2d
+    without rounding, and the recorded C2 numbers (tests/golden/drift_ablation_wino.json) say what 16-bit Winograd costs: the first bf16
+    forward stays under the reference's own bf16 mode (1.09e-2 of scale), the 50-step final latent under its 2.9e-2."""
+    import json
+    import os
+    import torch.nn.functional as F
+    from oracle import drift_ablation as da
+
+    class NoRound:
+        kinds = {"wino"}
+        fn = {"wino": None}
+
+        def __call__(self, x, kind):
+            return x
+
+    g = torch.Generator().manual_seed(0)
+    x, w, b = torch.randn(2, 24, 12, 8, generator=g), torch.randn(40, 24, 3, 3, generator=g) * 0.1, torch.randn(40, generator=g)
+    da._UCACHE.clear()
+    ref = F.conv2d(x, w, b, padding=1)
+    assert (da.conv3(x, w, b, NoRound()) - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    da._UCACHE.clear()
+    r = da.Rounder("wino:bf16")
+    xb = x.bfloat16().float()
+    e_w = (da.conv3(xb, w, b, r) - ref).abs().max().item()
+    e_d = (F.conv2d(xb, w.bfloat16().float(), b, padding=1) - ref).abs().max().item()
+    assert e_d < e_w < 4 * e_d        # Winograd in bf16 is worse than direct bf16, by a small factor
+    da._UCACHE.clear()
+    runs = {r_["mode"]: r_ for r_ in json.load(open(os.path.join(golden_dir, "drift_ablation_wino.json")))["runs"]}
+    bw, fw = runs["all:bf16/wino:bf16"], runs["all:fp16/wino:fp16"]
+    assert bw["first_forward_rel"] < 1.09e-2 and bw["final_max_abs"] < 2.9e-2 and bw["final_rms"] < 6.1e-3
+    assert fw["first_forward_rel"] < 2e-3 and fw["final_max_abs"] < 4.7e-3
