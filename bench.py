@@ -252,6 +252,15 @@ def run(a):
     if not a.no_e2e and default_21:
         try:
             e2e = e2e_pass(a, arch, sd, dev, tdt, dist_on, world)
+            if e2e is not None and a.dtype == "bf16" and not dist_on:
+                # the same chain on the other engines: fp16 = the reference's own precision; f16x3 = the engine that holds
+                # the 1e-3 gate (its prior and MoVQ run in fp32); one untimed + one timed image each
+                e2e["other_engines"] = {}
+                for name, dt in (("fp16", torch.float16), ("f16x3", k22.F16X3)):
+                    try:
+                        e2e["other_engines"][name] = e2e_short(a, arch, sd, dev, dt)
+                    except Exception as e:
+                        print(f"bench: e2e pass ({name}) failed: {e}", file=sys.stderr)
         except Exception as e:  # the bench line must come out whatever happens in the side measurements
             print(f"bench: e2e pass failed on rank {rank}: {e}", file=sys.stderr)
             if dist_on:
@@ -369,6 +378,26 @@ def e2e_pass(a, arch, sd, dev, tdt, dist_on, world):
             "what": f"Kandinsky2_1HIP.generate_text2img, {a.size}x{a.size}, bs {a.bs}/GPU, prior_steps 25, num_steps {a.sched_steps}, p_sampler, "
                     f"{a.dtype} engines, MoVQ decode in {str(pipe.movq_dtype).replace('torch.', '')}{' (the reference under use_fp16 decodes in half too)' if pipe.movq_dtype != torch.float32 else ''}, "
                     f"seeded random weights + stand-in conditioning embeddings (tokenizers / text encoders are not in the timed chain)"}
+
+
+def e2e_short(a, arch, sd, dev, dt):
+    """images/sec of generate_text2img on another engine type: one untimed call (plans, graph captures), one timed."""
+    pipe = _seeded_pipeline(a, arch, sd, dev, dt)
+
+    def gen():
+        return pipe.generate_text2img("a red cat, 4k photo", num_steps=a.sched_steps, batch_size=a.bs, guidance_scale=4, h=a.size, w=a.size,
+                                      sampler="p_sampler", prior_cf_scale=4, prior_steps="25", output_type="tensor")
+    gen()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    img = gen()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out = {"images_per_sec": round(a.bs / el, 4), "ms_per_call": round(el * 1e3, 2), "movq_dtype": str(pipe.movq_dtype).replace("torch.", ""),
+           "ok": bool(tuple(img.shape) == (a.bs, a.size, a.size, 3))}
+    del pipe
+    torch.cuda.empty_cache()
+    return out
 
 
 def parity_paths(m_timed, arch, sd, a, dev):
