@@ -595,3 +595,17 @@ def test_winograd_emulation_matches_direct_convolution_and_its_recorded_drift(go
     bw, fw = runs["all:bf16/wino:bf16"], runs["all:fp16/wino:fp16"]
     assert bw["first_forward_rel"] < 1.09e-2 and bw["final_max_abs"] < 2.9e-2 and bw["final_rms"] < 6.1e-3
     assert fw["first_forward_rel"] < 2e-3 and fw["final_max_abs"] < 4.7e-3
+
+
+def test_shipped_tile_table_covers_the_split_precision_engine():
+    """Round 4: the split-precision engine (dtype code 3) resolves its C2 / C3 / C4 problems from the shipped table like the other engines
+    (bench: tile_configs_measured_in_this_process = 0), only through algorithms its kernels exist for (csrc/tuning.h: no algos 2 / 6 / 20,
+    i.e. no first-generation halo variants and no weight-streaming kernel, which needs 16-bit fragment-major weights)."""
+    rows = [l.split() for l in open(_lib.TILE_TABLE_PATH) if l.strip() and not l.startswith("#")]
+    x3 = [r for r in rows if int(r[0]) == _lib.K22_F16X3]
+    assert len(x3) >= 280
+    algos = {int(r[r.index("|") + 1]) if "|" in r else int(r[10]) for r in x3}
+    assert algos <= {0, 1, 3, 4, 5, 7, 10, 11, 12} and not (algos & {2, 6, 20})
+    # the C2 shapes: 3x3 convolutions at 96 / 48 / 24 / 12 pixels, batch 2
+    c2 = {(int(r[6]), int(r[7])) for r in x3 if int(r[1]) == 9 and int(r[2]) == 2 * int(r[6]) * int(r[7])}
+    assert {(96, 96), (48, 48), (24, 24), (12, 12)} <= c2
