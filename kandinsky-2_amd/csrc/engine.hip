@@ -105,6 +105,7 @@ struct K22UNet {
     return K22_OK;
   }
   size_t ws_bytes = 0;
+  int n_pre = 0;   // leading ops of `ops` that form the prologue of a forward (run_pre / run_body)
   char* ws = nullptr;
   bool cond_set = false;
   bool warmed = false;   // one eager pass of the op list has run on this plan (function attributes set, code loaded): capture may start
@@ -152,11 +153,13 @@ struct K22UNet {
   // graph two parallel branches - and one chain's latency-bound stretches overlap the other's MFMA-bound ones.  Measured at C2 (bf16,
   // tools/two_stream_probe.py, two separately launched graphs on two streams): 8.20 ms for one B = 2 chain, 5.89 ms for one B = 1 chain
   // alone, 7.31 ms for two B = 1 chains overlapped.  In the engine: one captured graph PER KID launched side by side, the step loop driven
-  // from the host: bf16 C2 152.5 steps/s against 146.9 (+3.9 %), C4 -5 %, bit-reproducible for bf16 / fp16 / fp32 (as two branches of ONE
-  // captured graph hipGraph gave no overlap at all).  OPT-IN (K22_CHAINS=2), off by default and never used by the split-precision engine:
-  // with both kids' kernels launched eagerly and drifting apart over a whole forward the FIRST image of the second chain came out 2e-2 off
-  // in ~70 % of the f16x3 forwards (never with bf16 / fp16 / fp32, never with the kids on one stream, never within a 22-op window) - an
-  // interaction that is not understood yet (profiles/r04_two_chains.txt), so nothing that must hold parity runs on it by default.  The
+  // from the host: bf16 C2 152.5 steps/s against 146.9 (+3.9 %), C4 -5 %, split precision +3.7 %, bit-reproducible for all four engine types
+  // (as two branches of ONE captured graph hipGraph gave no overlap at all).  OPT-IN (K22_CHAINS=2), off by default.  Round 4's first,
+  // eager form put the whole op lists inside the fork and the FIRST image of the lagging chain came out 2e-2 off in ~70 % of the f16x3
+  // forwards; that was traced (profiles/r04_chains_root_cause.txt) to ONE kernel pair - linear_smallm_kernel (the time-embedding MLP, the
+  // first op of a forward) returns wrong elements while igemm_kernel<16-bit, 128x64> workgroups of the other chain are resident on its
+  // SIMD - and is avoided BY CONSTRUCTION since: both kids' prologues (run_pre) run on the caller's stream before the fork, only the
+  // bodies overlap (eager: 0 of 11 forwards wrong where the first form had 6 of 6).  The
   // parent engine owns no ops of its own: only the fork / join and the workspace layout [kid 0 | kid 1 | combined model output].
   K22UNet* kid[2] = {nullptr, nullptr};
   bool chained = false;
@@ -193,13 +196,19 @@ struct K22UNet {
     if (!chained) return run_ops(st);
     static const bool serial = getenv("K22_CHAINS_SERIAL") && atoi(getenv("K22_CHAINS_SERIAL")) != 0;   // debug: both kids on the caller's stream
     if (serial) { int rc0 = kid[0]->run_ops(st); return rc0 ? rc0 : kid[1]->run_ops(st); }
+    // Both prologues first, on the caller's stream: linear_smallm_kernel (the time-embedding MLP) is the one kernel of a forward that was
+    // found to return wrong elements while igemm_kernel<16-bit, 128x64> workgroups of the OTHER chain are resident on its SIMD
+    // (profiles/r04_chains_root_cause.txt); before the fork nothing of the other chain runs.
+    static const int dbg_swap0 = getenv("K22_CHAINS_SWAP") ? atoi(getenv("K22_CHAINS_SWAP")) : 0;
+    if (dbg_swap0 == 0) { for (int i = 0; i < 2; ++i) { int rcp = kid[i]->run_pre(st); if (rcp) return rcp; } }
     int rc = fork_side(st);
     if (rc) return rc;
     static const int dbg_swap = getenv("K22_CHAINS_SWAP") ? atoi(getenv("K22_CHAINS_SWAP")) : 0;   // debug (tools/chains_gap_probe.py):
-    int rc1;                                                                                           // 1 = kid 0 on the side stream, 2 = kid 1 enqueued first
-    if (dbg_swap == 1) { rc = kid[0]->run_ops(side); rc1 = rc ? rc : kid[1]->run_ops(st); }
+    int rc1;                                                                                           // 1 = kid 0 on the side stream, 2 = kid 1 enqueued first,
+    if (dbg_swap == 1) { rc = kid[0]->run_ops(side); rc1 = rc ? rc : kid[1]->run_ops(st); }          // 3 = round 4's first form (prologues inside the fork)
     else if (dbg_swap == 2) { rc = kid[1]->run_ops(side); rc1 = rc ? rc : kid[0]->run_ops(st); }
-    else { rc = kid[0]->run_ops(st); rc1 = rc ? rc : kid[1]->run_ops(side); }
+    else if (dbg_swap == 3) { rc = kid[0]->run_ops(st); rc1 = rc ? rc : kid[1]->run_ops(side); }
+    else { rc = kid[0]->run_body(st); rc1 = rc ? rc : kid[1]->run_body(side); }
     rc = join_side(st);
     return rc1 ? rc1 : rc;
   }
@@ -216,7 +225,7 @@ struct K22UNet {
     hipGraph_t g = nullptr;
     e = hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-    const int rc = run_ops(cap_stream);
+    const int rc = run_body(cap_stream);   // (kids only: the prologue is launched by the parent before the fork)
     e = hipStreamEndCapture(cap_stream, &g);
     if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
     if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
@@ -227,6 +236,7 @@ struct K22UNet {
   }
   int exec_kid_graphs(hipStream_t st) {
     for (int i = 0; i < 2; ++i) { int rc = kid[i]->capture_own_graph(st); if (rc) return rc; }
+    for (int i = 0; i < 2; ++i) { int rc = kid[i]->run_pre(st); if (rc) return rc; }   // both prologues before the fork: see exec()
     int rc = fork_side(st);
     if (rc) return rc;
     hipError_t e = hipGraphLaunch(kid[0]->graph_exec, st);
@@ -292,10 +302,15 @@ struct K22UNet {
   // i.e. a parallel branch of the captured graph joined by the first FiLM consumer, was measured on one box, alternating
   // runs: 116.9 / 117.2 steps/s with the branch against 119.4 / 119.1 without - the 231 MB weight stream slows the
   // convolutions it runs beside by more than the 80 us it hides.  Removed.)
-  int run_ops(hipStream_t st) {
-    for (auto& op : ops) { int rc = op(st); if (rc) return rc; }
+  int run_ops_range(hipStream_t st, size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi && i < ops.size(); ++i) { int rc = ops[i](st); if (rc) return rc; }
     return K22_OK;
   }
+  int run_ops(hipStream_t st) { return run_ops_range(st, 0, ops.size()); }
+  // two chains: the PROLOGUE of a forward (group-sum clear + timestep embedding + the FiLM GEMV: n_pre ops, four small kernels) runs on the
+  // caller's stream before the fork, the BODY on the kid's own stream - see exec()
+  int run_pre(hipStream_t st) { return run_ops_range(st, 0, (size_t)n_pre); }
+  int run_body(hipStream_t st) { return run_ops_range(st, (size_t)n_pre, ops.size()); }
   int run_ops_eager(hipStream_t st) { const int rc = run_ops(st); if (rc == K22_OK) warmed = true; return rc; }
 
   // ------------------------------------------------------------------------------------------
@@ -787,6 +802,7 @@ struct K22UNet {
     size_t off = 0;
     for (auto& s : slots) { s.off = off; off += (s.bytes + 255) / 256 * 256; }
     ws_bytes = off + 256;
+    n_pre = gsum_bytes ? 2 : 1;   // [group-sum clear,] time embedding + FiLM vectors
     if (getenv("K22_DBG_SLOTS")) {   // debug: the workspace map (tools/chains_gap_probe.py diffs workspaces of two forwards)
       int i = 0;
       for (auto& s : slots) { if (s.bytes) fprintf(stderr, "k22 slot %3d off %12zu bytes %12zu\n", i, s.off, s.bytes); ++i; }
@@ -946,8 +962,7 @@ int k22_unet_create(const K22UNetConfig* cfg, const K22Weight* weights, int n_we
   for (int i = 0; i < n_weights; ++i) u->w[weights[i].name] = weights[i].ptr;
   {
     const char* ch = getenv("K22_CHAINS");   // 2 = an even batch as two half-batch chains (experimental, see K22UNet::kid); default 1
-    const bool x3_kids = getenv("K22_CHAINS_X3") && atoi(getenv("K22_CHAINS_X3")) != 0;   // debug only (tools/chains_gap_probe.py)
-    if (ch && atoi(ch) == 2 && (cfg->dtype != K22_F16X3 || x3_kids)) {   // (never for the split-precision engine: see K22UNet::kid)
+    if (ch && atoi(ch) == 2) {
       for (int i = 0; i < 2; ++i) {
         K22UNet* k = new K22UNet();
         k->cfg = u->cfg; k->dtype = u->dtype; k->sdt = u->sdt; k->esz = u->esz;

@@ -1,6 +1,6 @@
 """Round-4 debug probe for the split-precision nondeterminism under two chains: puts a guard region between the two
 kids' workspaces (K22_KID_GAP_MB), fills it with a pattern before every forward and reports which bytes a forward changed.
-    K22_CHAINS=2 K22_CHAINS_X3=1 K22_KID_GAP_MB=64 python tools/chains_gap_probe.py [f16x3|bf16|fp32] [reps] [graph 0/1]"""
+    K22_CHAINS=2 K22_KID_GAP_MB=64 python tools/chains_gap_probe.py [f16x3|bf16|fp32] [reps] [graph 0/1]"""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
