@@ -15,10 +15,15 @@ LIB_PATH = os.path.join(_HERE, "libk22hip.so")
 # K22_TILE_TABLE=<file> substitutes another table, K22_TILE_TABLE=0 starts with an empty one.
 TILE_TABLE_PATH = os.path.join(_HERE, "tiles_gfx950.txt")
 
-K22_BF16, K22_F32, K22_F16, K22_F16X3 = 0, 1, 2, 3
+K22_BF16, K22_F32, K22_F16, K22_F16X3, K22_F16X2 = 0, 1, 2, 3, 4
 # backend_dtype of the split-precision UNet engine (no torch dtype names it): fp32 tensors, MFMA operands as fp16 (hi, lo) pairs, three
 # fp16 MFMAs per product - the arithmetic that meets the 1e-3 final-latent gate at 16-bit MFMA rate (include/k22.h: K22_F16X3)
 F16X3 = "f16x3"
+# backend_dtype of the ASYMMETRIC split engine (round 5; include/k22.h: K22_F16X2): the same tensors, arena and operand formats, with the
+# precision of every MFMA op a property of the plan - weights always as (hi, lo) pairs, the activation operand at fp16 precision where
+# the operand-rounding ablation says it is cheap (two MFMAs per product; attention one), all three MFMAs where it is not
+F16X2 = "f16x2"
+SPLIT_DTYPES = (F16X3, F16X2)
 X3_WSCALE = 256.0   # csrc/common.h: K22_X3_WSCALE
 
 
@@ -27,9 +32,9 @@ def dtype_code(backend_dtype) -> int:
     use_fp16 mode: same speed, 3 more mantissa bits), float32 (parity path, exact-fp32 MFMA)."""
     import torch
     try:
-        return {torch.bfloat16: K22_BF16, torch.float32: K22_F32, torch.float16: K22_F16, F16X3: K22_F16X3}[backend_dtype]
+        return {torch.bfloat16: K22_BF16, torch.float32: K22_F32, torch.float16: K22_F16, F16X3: K22_F16X3, F16X2: K22_F16X2}[backend_dtype]
     except KeyError:
-        raise ValueError('backend_dtype must be torch.bfloat16, torch.float16, torch.float32 or "f16x3"') from None
+        raise ValueError('backend_dtype must be torch.bfloat16, torch.float16, torch.float32 "f16x3" or "f16x2"') from None
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 OUT_ROWMAJOR, OUT_ROWMAJOR_F32, OUT_NCHW_F32 = 0, 1, 2
 

@@ -13,6 +13,7 @@
 // K_all / V^T_all are produced by kv_pack_kernel (elementwise.hip), zero padded to 64 keys.
 #include "kernels.h"
 #include "elementwise.h"
+#include <type_traits>
 
 // V^T fragment whose K (= key) order matches the S^T accumulator registers:
 // element j<4 -> key 16a + 4h + j ; j>=4 -> key 16a + 8 + 4h + (j-4).
@@ -69,6 +70,21 @@ __device__ __forceinline__ void ld_qfrag(Frag<float>& f, const float* p) {
   f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
   f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
 }
+// xh_t (round 5): the attention of the ASYMMETRIC split engine (K22_F16X2).  q / K_all / V^T_all are the fp32 tensors the split engines'
+// qkv GEMM writes; they are rounded to fp16 while the tiles are staged (Q: at fragment load) and the kernel runs the fp16 engine's body:
+// ONE MFMA per product, fp32 online softmax, native exp2.  The operand rounding of the attention is 1.5 % of the error budget of that
+// engine (tests/golden/drift_ablation_x2.json, kind `a`); the output is written as x3 chunks for the proj_out GEMM, which keeps all
+// three MFMAs.
+struct xh_t { float f; };
+template <typename T> struct AttC { using type = T; static constexpr bool MIX = false; };
+template <> struct AttC<xh_t> { using type = f16_t; static constexpr bool MIX = true; };
+__device__ __forceinline__ u32x4_t f16x8_from_f32(const u32x4_t a, const u32x4_t b) {
+  const float4 x = __builtin_bit_cast(float4, a), y = __builtin_bit_cast(float4, b);
+  return u32x4_t{pack2_f16(x.x, x.y), pack2_f16(x.z, x.w), pack2_f16(y.x, y.y), pack2_f16(y.z, y.w)};
+}
+__device__ __forceinline__ void ld_qfrag(Frag<f16_t>& f, const float* p) {
+  f.v = f16x8_from_f32(*reinterpret_cast<const u32x4_t*>(p), *reinterpret_cast<const u32x4_t*>(p + 4));
+}
 // 2^x: the bf16 path uses the raw v_exp_f32 (inputs here are <= 0; results below 2^-126 flush, which is
 // far below bf16 resolution of the probabilities), the fp32 parity path the accurate exp2f.
 template <typename T> __device__ __forceinline__ float exp2_t(float x);
@@ -96,13 +112,17 @@ __device__ __forceinline__ float max2f(float a, float b) {
   return r;
 }
 
-template <typename T>
+template <typename TS>
 __global__ __launch_bounds__(256, 2) void attention_kernel(AttentionParams p) {
+  using T = typename AttC<TS>::type;          // arithmetic / LDS type
+  constexpr bool MIX = AttC<TS>::MIX;         // fp32 tensors in memory, fp16 tiles and MFMAs (xh_t)
+  using TG = typename std::conditional<MIX, float, T>::type;   // element type of q / K_all / V^T_all / out in memory
   using TR = TT<T>;
   constexpr int EPC = TR::EPC, BK = TR::BK, KSTEPS = TR::KSTEPS;
   constexpr int NSUB = 64 / BK;   // 128-byte sub-tiles per 64-element row (1 bf16, 2 fp32)
   constexpr int CPR = 64 / EPC;   // 16-byte chunks per 64-element row
   constexpr int LCH = CPR / 4;    // chunks per thread per 64x64 tile
+  constexpr int GCH = MIX ? 2 * LCH : LCH;   // 16-byte global loads per thread per tile and tensor
   __shared__ __attribute__((aligned(16))) char smem[2 * NSUB * 8192];
   char* Ks = smem;
   char* Vs = smem + NSUB * 8192;
@@ -113,24 +133,31 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttentionParams p) {
   const int t = blockIdx.x * 128 + wave * 32 + l31;
   const int tq = t < p.T ? t : p.T - 1;
 
-  const T* qrow = reinterpret_cast<const T*>(p.q) + (int64_t)(b * p.T + tq) * p.ldq + hd * 64;
+  const TG* qrow = reinterpret_cast<const TG*>(p.q) + (int64_t)(b * p.T + tq) * p.ldq + hd * 64;
   Frag<T> qf[4];
 #pragma unroll
   for (int a = 0; a < 4; ++a) ld_qfrag(qf[a], qrow + 16 * a + 8 * h);
 
-  const T* Kg = reinterpret_cast<const T*>(p.kall) + (int64_t)(b * p.H + hd) * p.Tkp * 64;
-  const T* Vg = reinterpret_cast<const T*>(p.vtall) + (int64_t)(b * p.H + hd) * 64 * p.Tkp;
+  const TG* Kg = reinterpret_cast<const TG*>(p.kall) + (int64_t)(b * p.H + hd) * p.Tkp * 64;
+  const TG* Vg = reinterpret_cast<const TG*>(p.vtall) + (int64_t)(b * p.H + hd) * 64 * p.Tkp;
   const int nkt = (p.Tk + 63) / 64;
 
   // unconditional, native-vector staging (conditional staging ends up in scratch memory)
-  u32x4_t kreg[LCH], vreg[LCH];
+  u32x4_t kreg[GCH], vreg[GCH];
 #define K22_ATT_GLOAD(KT)                                                                                \
   {                                                                                                      \
     const int kt_ = (KT);                                                                                \
     _Pragma("unroll") for (int i = 0; i < LCH; ++i) {                                                    \
       const int q = tid + i * 256, row = q / CPR, cc = q - row * CPR;                                    \
+      if constexpr (MIX) {   /* one fp16 chunk of the tile = two consecutive fp32 chunks in memory */    \
+        const float* kp_ = Kg + (int64_t)(kt_ * 64 + row) * 64 + cc * EPC;                               \
+        const float* vp_ = Vg + (int64_t)row * p.Tkp + kt_ * 64 + cc * EPC;                              \
+        kreg[2 * i] = *reinterpret_cast<const u32x4_t*>(kp_); kreg[2 * i + 1] = *reinterpret_cast<const u32x4_t*>(kp_ + 4); \
+        vreg[2 * i] = *reinterpret_cast<const u32x4_t*>(vp_); vreg[2 * i + 1] = *reinterpret_cast<const u32x4_t*>(vp_ + 4); \
+      } else {                                                                                           \
       kreg[i] = *reinterpret_cast<const u32x4_t*>(Kg + (int64_t)(kt_ * 64 + row) * 64 + cc * EPC);       \
       vreg[i] = *reinterpret_cast<const u32x4_t*>(Vg + (int64_t)row * p.Tkp + kt_ * 64 + cc * EPC);      \
+      }                                                                                                  \
     }                                                                                                    \
   }
 #define K22_ATT_LSTORE()                                                                                 \
@@ -138,7 +165,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttentionParams p) {
     _Pragma("unroll") for (int i = 0; i < LCH; ++i) {                                                    \
       const int q = tid + i * 256, row = q / CPR, cc = q - row * CPR;                                    \
       const int off = (cc >> 3) * 8192 + lds_chunk_off(row, cc & 7);                                     \
-      if constexpr (is_x3<T>::value) {   /* fp32 K / V^T rows -> x3 chunks, once per workgroup */           \
+      if constexpr (MIX) {                                                                               \
+        *reinterpret_cast<u32x4_t*>(Ks + off) = f16x8_from_f32(kreg[2 * i], kreg[2 * i + 1]);            \
+        *reinterpret_cast<u32x4_t*>(Vs + off) = f16x8_from_f32(vreg[2 * i], vreg[2 * i + 1]);            \
+      } else if constexpr (is_x3<T>::value) {   /* fp32 K / V^T rows -> x3 chunks, once per workgroup */    \
         *reinterpret_cast<u32x4_t*>(Ks + off) = x3_split4(__builtin_bit_cast(float4, kreg[i]));           \
         *reinterpret_cast<u32x4_t*>(Vs + off) = x3_split4(__builtin_bit_cast(float4, vreg[i]));           \
       } else {                                                                                           \
@@ -235,13 +265,16 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttentionParams p) {
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l_tot;
   if (t < p.T) {
-    T* orow = reinterpret_cast<T*>(p.out) + (int64_t)(b * p.T + t) * p.ldo + hd * 64;
+    TG* orow = reinterpret_cast<TG*>(p.out) + (int64_t)(b * p.T + t) * p.ldo + hd * 64;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d = db * 32 + 8 * g + 4 * h;
-        if constexpr (sizeof(T) == 2) {
+        if constexpr (MIX) {
+          if (p.out_x3) *reinterpret_cast<u32x4_t*>(orow + d) = x3_split4(o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+          else *reinterpret_cast<float4*>(orow + d) = make_float4(o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+        } else if constexpr (sizeof(T) == 2) {
           uint2 w;
           w.x = pack2<T>(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
           w.y = pack2<T>(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
@@ -263,6 +296,7 @@ int launch_attention(const AttentionParams& p, int dtype, hipStream_t s) {
   else if (dtype == K22_F16) hipLaunchKernelGGL(attention_kernel<f16_t>, grid, dim3(256), 0, s, p);
   else if (dtype == K22_F32) hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(256), 0, s, p);
   else if (dtype == K22_F16X3) hipLaunchKernelGGL(attention_kernel<x3_t>, grid, dim3(256), 0, s, p);
+  else if (dtype == K22_F16X2) hipLaunchKernelGGL(attention_kernel<xh_t>, grid, dim3(256), 0, s, p);
   else return k22_set_error(K22_EINVAL, "attention: bad dtype");
   K22_CHECK_LAUNCH();
   return K22_OK;

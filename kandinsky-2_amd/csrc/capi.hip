@@ -148,7 +148,7 @@ int k22_gemm(const void* A0, const void* A1, const void* Wp, const float* bias, 
   p.M = M; p.N = N; p.Npad = Npad; p.Kc = K0 + K1; p.K0 = K0; p.taps = 1; p.lda0 = lda0; p.lda1 = lda1;
   p.ldo = ldo; p.ldr = ldr; p.out_mode = out_f32 ? IG_OUT_ROWMAJOR_F32 : IG_OUT_ROWMAJOR; p.act = act;
   p.splitk = splitk; p.force_bm = bm; p.force_bn = bn;
-  p.a_raw = dtype == K22_F16X3 ? 1 : 0;   // unit entry: A0 / A1 are plain fp32 rows (the engine feeds x3 chunks where its own kernels produce A)
+  p.a_raw = k22_is_split(dtype) ? 1 : 0;   // unit entry: A0 / A1 are plain fp32 rows (the engine feeds x3 chunks where its own kernels produce A)
   if (p.splitk == 0) p.splitk = partial ? igemm_choose_splitk(p, dtype) : 1;
   K22_DBG_FRAG(p);
   return launch_igemm(p, dtype, reinterpret_cast<hipStream_t>(stream));
@@ -202,7 +202,7 @@ int k22_gemm_gnstats(const void* A, const void* Wp, const float* bias, const voi
   p.M = B * H * W; p.N = N; p.Npad = Npad; p.Kc = K; p.K0 = K; p.taps = 1; p.H = H; p.W = W; p.lda0 = K;
   p.ldo = N; p.ldr = N; p.out_mode = IG_OUT_ROWMAJOR; p.act = K22_ACT_NONE; p.splitk = splitk > 0 ? splitk : 1;
   p.force_bm = bm; p.algo = (bm == 160 || bm == 288) ? 20 : 10;
-  p.a_raw = dtype == K22_F16X3 ? 1 : 0;
+  p.a_raw = k22_is_split(dtype) ? 1 : 0;
   const int rpi = igemm_stats_rows_per_image(p, dtype);
   if (rows_per_image) *rows_per_image = rpi;
   if (rpi <= 0) return k22_set_error(K22_EINVAL, "gemm_gnstats: this configuration cannot produce GroupNorm partial sums");
@@ -246,7 +246,7 @@ int k22_groupnorm(const void* x0, const void* x1, int C0, int C1, int B, int H, 
                   void* scratch, void* out, int dtype, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int C = C0 + C1, HW = H * W;
-  const int out_x3 = dtype == K22_F16X3 ? 1 : 0;   // split-precision engine: fp32 in, x3 chunks out (what its convolutions read)
+  const int out_x3 = k22_is_split(dtype) ? 1 : 0;   // split-precision engine: fp32 in, x3 chunks out (what its convolutions read)
   dtype = k22_storage_dtype(dtype);
   const int nsplit = gn_nsplit(B, HW);
   float* partial = reinterpret_cast<float*>(scratch);
@@ -333,7 +333,7 @@ int k22_qkv_project(const void* x, const void* Wp, const float* bias, void* q_ou
   p.M = B * T; p.N = 3 * C; p.Npad = 3 * C; p.Kc = K; p.K0 = K; p.taps = 1; p.lda0 = K; p.lda1 = 0;
   p.ldo = C; p.ldr = 3 * C; p.out_mode = IG_OUT_QKV; p.act = K22_ACT_NONE; p.splitk = 1; p.force_bm = bm; p.force_bn = bn;
   p.att_T = T; p.att_S = S; p.att_Tkp = Tkp; p.H = 1; p.W = T;   /* rows per image */
-  p.a_raw = dtype == K22_F16X3 ? 1 : 0;
+  p.a_raw = k22_is_split(dtype) ? 1 : 0;
   K22_DBG_FRAG(p);
   return launch_igemm(p, dtype, reinterpret_cast<hipStream_t>(stream));
 }

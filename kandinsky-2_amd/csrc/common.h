@@ -22,13 +22,19 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 // K22_F16X3 (round 4, UNet engine only) = the SPLIT-PRECISION arithmetic: fp32 tensors, every MFMA operand x carried as the fp16 pair
 // hi = rne(x), lo = rne(x - hi) and every product as THREE v_mfma_f32_32x32x16_f16 (hi.hi + hi.lo + lo.hi, one fp32 accumulator):
 // ~23 significand bits per operand at 3/16 of the exact-fp32 MFMA cost.  See x3_t below.
-enum K22DType { K22_BF16 = 0, K22_F32 = 1, K22_F16 = 2, K22_F16X3 = 3 };
+// K22_F16X2 (round 5) = the ASYMMETRIC split: the same tensors and operand formats as K22_F16X3 (so one op of a plan can run either), but
+// a conv / GEMM product is TWO MFMAs - w_hi.a_hi + w_lo.a_hi: the weights keep ~22 bits (their rounding is the SYSTEMATIC error of a
+// 16-bit engine: the same delta at every pixel and step), the activation operand is taken at fp16 precision (its rounding is random
+// per pixel and step).  See x2_t below and DESIGN.md (precision plan).
+enum K22DType { K22_BF16 = 0, K22_F32 = 1, K22_F16 = 2, K22_F16X3 = 3, K22_F16X2 = 4 };
+// the two split-precision arithmetics: fp32 tensors in HBM, x3-chunk MFMA operands
+inline bool k22_is_split(int dtype) { return dtype == K22_F16X3 || dtype == K22_F16X2; }
 // bytes per element / elements per 128-byte LDS row of a storage type code
-inline int k22_esz(int dtype) { return (dtype == K22_F32 || dtype == K22_F16X3) ? 4 : 2; }
-inline int k22_bk(int dtype) { return (dtype == K22_F32 || dtype == K22_F16X3) ? 32 : 64; }
+inline int k22_esz(int dtype) { return (dtype == K22_F32 || k22_is_split(dtype)) ? 4 : 2; }
+inline int k22_bk(int dtype) { return (dtype == K22_F32 || k22_is_split(dtype)) ? 32 : 64; }
 inline bool k22_dtype_ok(int dtype) { return dtype == K22_BF16 || dtype == K22_F32 || dtype == K22_F16; }
 // what the kernels that only move / normalise data are instantiated on for an engine of arithmetic type `dtype`
-inline int k22_storage_dtype(int dtype) { return dtype == K22_F16X3 ? (int)K22_F32 : dtype; }
+inline int k22_storage_dtype(int dtype) { return k22_is_split(dtype) ? (int)K22_F32 : dtype; }
 enum K22Act { K22_ACT_NONE = 0, K22_ACT_SILU = 1, K22_ACT_GELU = 2 };
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
@@ -113,8 +119,19 @@ __device__ __forceinline__ u32x4_t x3_split4(float x0, float x1, float x2, float
 __device__ __forceinline__ u32x4_t x3_split4(const float4 v) { return x3_split4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ float to_f32(x3_t v) { return v.f; }
 template <> __device__ __forceinline__ x3_t from_f32<x3_t>(float f) { return x3_t{f}; }
+// K22_F16X2: the same storage and operand formats (is_x3 is true for it: everything that concerns the FORMAT is shared), two MFMAs per
+// product - the activation fragment carries only its hi halves (FragA below: two 8-byte LDS reads, 4 registers).
+struct x2_t { float f; };
+__device__ __forceinline__ float to_f32(x2_t v) { return v.f; }
+template <> __device__ __forceinline__ x2_t from_f32<x2_t>(float f) { return x2_t{f}; }
 template <typename T> struct is_x3 { static constexpr bool value = false; };
 template <> struct is_x3<x3_t> { static constexpr bool value = true; };
+template <> struct is_x3<x2_t> { static constexpr bool value = true; };
+// arithmetic of the fused 1x1 skip connection inside a conv kernel of type T (the full split for the asymmetric one: see halo_tail)
+template <typename T> struct SkipT { using type = T; };
+template <> struct SkipT<x2_t> { using type = x3_t; };
+template <typename T> struct is_x2 { static constexpr bool value = false; };
+template <> struct is_x2<x2_t> { static constexpr bool value = true; };
 
 // ---- per-type tile traits ------------------------------------------------------------
 template <typename T> struct TT;
@@ -130,9 +147,11 @@ template <> struct TT<float> {
   static constexpr int KSTEPS = 2;
 };
 template <> struct TT<x3_t> : TT<float> {};
-// ds_read_b128s per fragment / MFMA instructions per 32x32x16 atom (the consumers' interleave of conv3_halo_spec_kernel)
+template <> struct TT<x2_t> : TT<float> {};
+// LDS reads per fragment / MFMA instructions per 32x32x16 atom (the consumers' interleave of conv3_halo_spec_kernel)
 template <typename T> struct FragCost { static constexpr int READS = sizeof(T) == 2 ? 1 : 2, MFMAS = sizeof(T) == 2 ? 1 : 8; };
 template <> struct FragCost<x3_t> { static constexpr int READS = 2, MFMAS = 3; };
+template <> struct FragCost<x2_t> { static constexpr int READS = 2, MFMAS = 2; };
 
 // A/B fragment of one 32x32x16 atom: 8 consecutive K elements of one row.
 template <typename T> struct Frag;
@@ -140,6 +159,13 @@ template <> struct Frag<bf16_t> { u32x4_t v; };
 template <> struct Frag<f16_t> { u32x4_t v; };
 template <> struct Frag<float> { float v[8]; };
 template <> struct Frag<x3_t> { u32x4_t hi, lo; };
+template <> struct Frag<x2_t> { u32x4_t hi, lo; };   // the WEIGHT fragment of the asymmetric split
+struct FragHi { u32x4_t hi; };                       // its ACTIVATION fragment: hi halves only
+// FragA<T>: the fragment type of the activation operand of a conv / GEMM atom (Frag<T> itself except for x2_t)
+template <typename T> struct FragAT { using type = Frag<T>; };
+template <> struct FragAT<x2_t> { using type = FragHi; };
+template <typename T> using FragA = typename FragAT<T>::type;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 // two x3 chunks (K elements 0-3 and 4-7 of the fragment) -> fragment: register renaming only
 __device__ __forceinline__ void x3_frag_from_chunks(Frag<x3_t>& f, const u32x4_t c0, const u32x4_t c1) {
   f.hi = u32x4_t{c0.x, c0.y, c1.x, c1.y};
@@ -148,6 +174,14 @@ __device__ __forceinline__ void x3_frag_from_chunks(Frag<x3_t>& f, const u32x4_t
 // eight fp32 values -> fragment (the `a_raw` operands: 20 VALU per fragment)
 __device__ __forceinline__ void x3_frag_from_f32(Frag<x3_t>& f, const float4 a, const float4 b) {
   x3_frag_from_chunks(f, x3_split4(a), x3_split4(b));
+}
+__device__ __forceinline__ void x3_frag_from_chunks(Frag<x2_t>& f, const u32x4_t c0, const u32x4_t c1) {
+  f.hi = u32x4_t{c0.x, c0.y, c1.x, c1.y};
+  f.lo = u32x4_t{c0.z, c0.w, c1.z, c1.w};
+}
+// activation fragment of the asymmetric split from plain fp32 values: four conversions
+__device__ __forceinline__ void x3_frag_from_f32(FragHi& f, const float4 a, const float4 b) {
+  f.hi = u32x4_t{pack2_f16(a.x, a.y), pack2_f16(a.z, a.w), pack2_f16(b.x, b.y), pack2_f16(b.z, b.w)};
 }
 
 // Swizzled LDS tile: row r (128 B), logical chunk c (16 B) lives at physical chunk c ^ ((r >> 1) & 7).
@@ -175,8 +209,18 @@ __device__ __forceinline__ void ld_frag(Frag<x3_t>& f, const char* tile, int r, 
   x3_frag_from_chunks(f, *reinterpret_cast<const u32x4_t*>(tile + lds_chunk_off(r, 4 * ks + 2 * h)),
                       *reinterpret_cast<const u32x4_t*>(tile + lds_chunk_off(r, 4 * ks + 2 * h + 1)));
 }
-// RAW = the LDS image holds plain fp32 rows (x3 arithmetic only): convert while reading.  Every other type: ld_frag.
-template <bool RAW, typename T> __device__ __forceinline__ void ld_frag_a(Frag<T>& f, const char* tile, int r, int ks, int h) {
+__device__ __forceinline__ void ld_frag(Frag<x2_t>& f, const char* tile, int r, int ks, int h) {
+  x3_frag_from_chunks(f, *reinterpret_cast<const u32x4_t*>(tile + lds_chunk_off(r, 4 * ks + 2 * h)),
+                      *reinterpret_cast<const u32x4_t*>(tile + lds_chunk_off(r, 4 * ks + 2 * h + 1)));
+}
+// asymmetric split, activation operand in x3 chunks: the hi halves (first 8 bytes) of the same two chunks
+__device__ __forceinline__ void ld_frag(FragHi& f, const char* tile, int r, int ks, int h) {
+  const u32x2_t a = *reinterpret_cast<const u32x2_t*>(tile + lds_chunk_off(r, 4 * ks + 2 * h));
+  const u32x2_t b = *reinterpret_cast<const u32x2_t*>(tile + lds_chunk_off(r, 4 * ks + 2 * h + 1));
+  f.hi = u32x4_t{a.x, a.y, b.x, b.y};
+}
+// RAW = the LDS image holds plain fp32 rows (split arithmetics only): convert while reading.  Every other type: ld_frag.
+template <bool RAW, typename T, typename F> __device__ __forceinline__ void ld_frag_a(F& f, const char* tile, int r, int ks, int h) {
   if constexpr (RAW && is_x3<T>::value) {
     x3_frag_from_f32(f, *reinterpret_cast<const float4*>(tile + lds_chunk_off(r, 4 * ks + 2 * h)),
                      *reinterpret_cast<const float4*>(tile + lds_chunk_off(r, 4 * ks + 2 * h + 1)));
@@ -205,6 +249,11 @@ __device__ __forceinline__ void mma_atom(f32x16_t& acc, const Frag<x3_t>& a, con
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a.hi), __builtin_bit_cast(f16x8_t, b.hi), acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a.hi), __builtin_bit_cast(f16x8_t, b.lo), acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a.lo), __builtin_bit_cast(f16x8_t, b.hi), acc, 0, 0, 0);
+}
+// asymmetric split: first operand = the WEIGHT fragment (hi, lo), second = the activation's hi halves: w_hi.a_hi + w_lo.a_hi
+__device__ __forceinline__ void mma_atom(f32x16_t& acc, const Frag<x2_t>& w, const FragHi& a) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, w.hi), __builtin_bit_cast(f16x8_t, a.hi), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, w.lo), __builtin_bit_cast(f16x8_t, a.hi), acc, 0, 0, 0);
 }
 // factor the epilogues apply to an accumulator before anything else (undoes the weights' power-of-two pre-scale)
 template <typename T> __device__ __forceinline__ float acc_unscale(float v) {
@@ -297,6 +346,7 @@ template <> struct Vec16<float> {
   }
 };
 template <> struct Vec16<x3_t> : Vec16<float> {};
+template <> struct Vec16<x2_t> : Vec16<float> {};
 
 #define K22_CHECK_LAUNCH()                                   \
   do {                                                       \

@@ -27,8 +27,18 @@ __device__ __forceinline__ void ld_frag_at(Frag<x3_t>& f, const char* rowp, int 
   x3_frag_from_chunks(f, *reinterpret_cast<const u32x4_t*>(rowp + (((4 * ks + 2 * h) ^ sw) << 4)),
                       *reinterpret_cast<const u32x4_t*>(rowp + (((4 * ks + 2 * h + 1) ^ sw) << 4)));
 }
-// RAW operands (x3 arithmetic only): plain fp32 rows in the LDS, split while they are read; every other type = ld_frag_at
-template <bool RAW, typename T> __device__ __forceinline__ void ld_frag_at_a(Frag<T>& f, const char* rowp, int sw, int ks, int h) {
+__device__ __forceinline__ void ld_frag_at(Frag<x2_t>& f, const char* rowp, int sw, int ks, int h) {
+  x3_frag_from_chunks(f, *reinterpret_cast<const u32x4_t*>(rowp + (((4 * ks + 2 * h) ^ sw) << 4)),
+                      *reinterpret_cast<const u32x4_t*>(rowp + (((4 * ks + 2 * h + 1) ^ sw) << 4)));
+}
+// asymmetric split, activation operand: the hi halves (first 8 bytes) of the two chunks
+__device__ __forceinline__ void ld_frag_at(FragHi& f, const char* rowp, int sw, int ks, int h) {
+  const u32x2_t a = *reinterpret_cast<const u32x2_t*>(rowp + (((4 * ks + 2 * h) ^ sw) << 4));
+  const u32x2_t b = *reinterpret_cast<const u32x2_t*>(rowp + (((4 * ks + 2 * h + 1) ^ sw) << 4));
+  f.hi = u32x4_t{a.x, a.y, b.x, b.y};
+}
+// RAW operands (split arithmetics only): plain fp32 rows in the LDS, split while they are read; every other type = ld_frag_at
+template <bool RAW, typename T, typename F> __device__ __forceinline__ void ld_frag_at_a(F& f, const char* rowp, int sw, int ks, int h) {
   if constexpr (RAW && is_x3<T>::value) {
     x3_frag_from_f32(f, *reinterpret_cast<const float4*>(rowp + (((4 * ks + 2 * h) ^ sw) << 4)),
                      *reinterpret_cast<const float4*>(rowp + (((4 * ks + 2 * h + 1) ^ sw) << 4)));
@@ -59,6 +69,7 @@ template <> __device__ __forceinline__ void store8<float>(float* dst, const floa
   *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
 template <> __device__ __forceinline__ void store8<x3_t>(x3_t* dst, const float* v) { store8<float>(reinterpret_cast<float*>(dst), v); }
+template <> __device__ __forceinline__ void store8<x2_t>(x2_t* dst, const float* v) { store8<float>(reinterpret_cast<float*>(dst), v); }
 template <typename T> __device__ __forceinline__ void load8f(const T* src, float* v);
 template <> __device__ __forceinline__ void load8f<bf16_t>(const bf16_t* src, float* v) {
   const uint4 r = *reinterpret_cast<const uint4*>(src);
@@ -76,12 +87,14 @@ template <> __device__ __forceinline__ void load8f<float>(const float* src, floa
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
 template <> __device__ __forceinline__ void load8f<x3_t>(const x3_t* src, float* v) { load8f<float>(reinterpret_cast<const float*>(src), v); }
+template <> __device__ __forceinline__ void load8f<x2_t>(const x2_t* src, float* v) { load8f<float>(reinterpret_cast<const float*>(src), v); }
 // value as it will be read back from memory (the GroupNorm statistics are those of the stored tensor)
 template <typename T> __device__ __forceinline__ float stored(float v);
 template <> __device__ __forceinline__ float stored<bf16_t>(float v) { return bf16_to_f32(f32_to_bf16(v)); }
 template <> __device__ __forceinline__ float stored<f16_t>(float v) { return (float)(f16_t)v; }
 template <> __device__ __forceinline__ float stored<float>(float v) { return v; }
 template <> __device__ __forceinline__ float stored<x3_t>(float v) { return v; }
+template <> __device__ __forceinline__ float stored<x2_t>(float v) { return v; }
 
 __device__ __forceinline__ int xcd_remap_h(int bid, int nblocks) {
   const int q = nblocks >> 3, r = nblocks & 7, x = bid & 7;
@@ -135,6 +148,7 @@ __device__ __forceinline__ u32x4_t gn_rewrite16(x3_t, u32x4_t raw, const float* 
   const u32x4_t o = x3_split4(v[0], v[1], v[2], v[3]);
   return border ? u32x4_t{0u, 0u, 0u, 0u} : o;
 }
+__device__ __forceinline__ u32x4_t gn_rewrite16(x2_t, u32x4_t raw, const float* cf, int act, bool border) { return gn_rewrite16(x3_t{}, raw, cf, act, border); }
 // plain 16-byte global load from inline asm: one more entry of the producers' hand-counted VMEM queue (a compiler-issued load would
 // make hipcc wait vmcnt(0) - draining every LDS-DMA in flight - before its first use); the destination is valid only behind a
 // gn_wait_* statement that names it
@@ -255,11 +269,14 @@ __device__ __forceinline__ void halo_tail(const IgemmParams& p, f32x16_t (&acc)[
         const char* sA = smem + buf * SBUF;
         const char* sB = sA + BM * 128;
         if (cw) {
+        // (asymmetric split: the skip input is the un-normalised residual stream - its operand rounding alone costs as much as that of
+        // every GroupNorm output together, tests/golden/drift_ablation_x2.json - so this K loop keeps all three MFMAs)
+        using TSK = typename SkipT<T>::type;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-          Frag<T> a[MI], b[NI];
+          Frag<TSK> a[MI], b[NI];
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi) ld_frag_at_a<true>(a[mi], sA + (abase + mi * 32) * 128, bsw, ks, h);   // S0 / S1: plain T rows
+          for (int mi = 0; mi < MI; ++mi) ld_frag_at_a<true, TSK>(a[mi], sA + (abase + mi * 32) * 128, bsw, ks, h);   // S0 / S1: plain T rows
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) ld_frag_at(b[ni], sB + brow[ni], bsw, ks, h);
 #pragma unroll

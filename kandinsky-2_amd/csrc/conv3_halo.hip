@@ -134,10 +134,11 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const IgemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  Frag<T> pa[MI], pb[NI];   // PIPE: fragments read but not yet multiplied (zero = a no-op group before the first tap)
+  FragA<T> pa[MI];          // PIPE: fragments read but not yet multiplied (zero = a no-op group before the first tap)
+  Frag<T> pb[NI];
   if constexpr (PIPE) {
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) pa[mi] = Frag<T>{};
+    for (int mi = 0; mi < MI; ++mi) pa[mi] = FragA<T>{};
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) pb[ni] = Frag<T>{};
   }
@@ -222,7 +223,8 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const IgemmParams p) {
           asw[mi] = (ar >> 1) & 7;                                                                         \
         }                                                                                                  \
         if constexpr (PIPE) {                                                                              \
-          Frag<T> ca[MI], cb[NI];                                                                          \
+          FragA<T> ca[MI];                                                                                 \
+          Frag<T> cb[NI];                                                                                  \
           _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ks += 2) {                                       \
             _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) ld_frag_at(ca[mi], arow[mi], asw[mi], ks, h); \
             _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) ld_frag_at(cb[ni], Bcur + brow[ni], bsw, ks, h); \
@@ -241,7 +243,8 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const IgemmParams p) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
         } else {                                                                                           \
         _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks) {                                            \
-          Frag<T> a[MI], b[NI];                                                                            \
+          FragA<T> a[MI];                                                                                  \
+          Frag<T> b[NI];                                                                                   \
           _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) ld_frag_at(a[mi], arow[mi], asw[mi], ks, h);   \
           _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) ld_frag_at(b[ni], Bcur + brow[ni], bsw, ks, h); \
           if constexpr (DBG_NOMMA) {                                                                       \
@@ -389,9 +392,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const IgemmParams p) {
       const char* St = smem + cur * BUF;
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
-        Frag<T> a[MI], b[NI];
+        FragA<T> a[MI];
+        Frag<T> b[NI];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) ld_frag_at_a<ARAW>(a[mi], St + arow[mi], sw, ks, h);
+        for (int mi = 0; mi < MI; ++mi) ld_frag_at_a<ARAW, T>(a[mi], St + arow[mi], sw, ks, h);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) ld_frag_at(b[ni], St + brow[ni], sw, ks, h);
 #pragma unroll
@@ -884,6 +888,10 @@ int launch_gemm8(const IgemmParams& p, int dtype, int bm, int splitk, hipStream_
     if (bm == 256) return launch_gemm8_cfg<x3_t, 256, 3>(p, splitk, stream);
     return nst == 2 ? launch_gemm8_cfg<x3_t, 128, 2>(p, splitk, stream) : launch_gemm8_cfg<x3_t, 128, 4>(p, splitk, stream);
   }
+  if (dtype == K22_F16X2) {
+    if (bm == 256) return launch_gemm8_cfg<x2_t, 256, 3>(p, splitk, stream);
+    return nst == 2 ? launch_gemm8_cfg<x2_t, 128, 2>(p, splitk, stream) : launch_gemm8_cfg<x2_t, 128, 4>(p, splitk, stream);
+  }
   if (bm == 256) return launch_gemm8_cfg<float, 256, 3>(p, splitk, stream);
   return nst == 2 ? launch_gemm8_cfg<float, 128, 2>(p, splitk, stream) : launch_gemm8_cfg<float, 128, 4>(p, splitk, stream);
 }
@@ -893,7 +901,7 @@ bool conv3_halo_supported(const IgemmParams& p, int dtype, int bm) {
   if (p.taps != 9 || (bm != 256 && bm != 128)) return false;
   // split precision: the input is read in x3 chunks; instantiated forms = the lock-step kernel with asm LDS-DMA (algo 2 / 5 / 6 / 7 all
   // run it) and the specialised kernel (11 / 12)
-  if (dtype == K22_F16X3 && (p.a_raw || p.algo == 3 || p.algo == 4)) return false;
+  if (k22_is_split(dtype) && (p.a_raw || p.algo == 3 || p.algo == 4)) return false;
   if (p.gn_coeff != nullptr) {   // fused GroupNorm-apply: the specialised kernels only; slabs never straddle the two raw sources
     if (!conv3_algo_fuses_gn(p.algo) || !p.gn_x0 || p.gn_C0 <= 0 || p.gn_C0 > p.Kc || p.gn_C0 % BK || (p.gn_C0 < p.Kc && !p.gn_x1)) return false;
     if ((int64_t)p.H * p.W * p.Kc >= (1ll << 31)) return false;
@@ -1000,11 +1008,12 @@ int launch_conv3_halo_trace(const IgemmParams& p, int dtype, hipStream_t stream)
 // 5 the 128-byte-row kernel with loader-wave specialisation, anything else the symmetric 128-byte-row one.
 int launch_conv3_halo(const IgemmParams& p, int dtype, int bm, int splitk, hipStream_t stream) {
   if (!conv3_halo_supported(p, dtype, bm)) return k22_set_error(K22_EINVAL, "conv3_halo: unsupported problem");
-  if (dtype == K22_F16X3) {
+  if (k22_is_split(dtype)) {
     int nb = halo_pick_nbst(p, bm);
     if (p.stages >= 2 && p.stages < nb) nb = p.stages == 5 ? 4 : p.stages;
     if (p.algo == 11 || p.algo == 12) return launch_conv3_halo_spec(p, dtype, bm, nb, splitk, stream);
     if (p.algo == 13 || p.algo == 14 || p.algo == 8 || p.algo == 9) return k22_set_error(K22_EINVAL, "conv3_halo: no measurement-only variants in split precision");
+    if (dtype == K22_F16X2) return bm == 256 ? launch_halo_nbst<x2_t, 256, 8, 2>(p, nb, splitk, stream) : launch_halo_nbst<x2_t, 128, 8, 2>(p, nb, splitk, stream);
     return bm == 256 ? launch_halo_nbst<x3_t, 256, 8, 2>(p, nb, splitk, stream) : launch_halo_nbst<x3_t, 128, 8, 2>(p, nb, splitk, stream);
   }
   if (p.algo == 4 && dtype != K22_F16) {   // (fp16: not instantiated - never a tuner candidate; the default kernel below)

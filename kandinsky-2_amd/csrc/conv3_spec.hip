@@ -296,10 +296,11 @@ __global__ __launch_bounds__(512) void conv3_halo_spec_kernel(const IgemmParams 
       const int bsw = (l31 >> 1) & 7;
       int cur = 0;
       // (s_setprio 3 in the consumers, so that they win issue arbitration against the producer on their SIMD: measured +-1 %)
-      Frag<T> pa[MI], pb[NI];   // PIPE: fragments read but not yet multiplied (zero = a no-op group before the first tap)
+      FragA<T> pa[MI];          // PIPE: fragments read but not yet multiplied (zero = a no-op group before the first tap)
+      Frag<T> pb[NI];
       if constexpr (PIPE) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) pa[mi] = Frag<T>{};
+        for (int mi = 0; mi < MI; ++mi) pa[mi] = FragA<T>{};
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) pb[ni] = Frag<T>{};
       }
@@ -333,7 +334,8 @@ __global__ __launch_bounds__(512) void conv3_halo_spec_kernel(const IgemmParams 
             asw[mi] = (ar >> 1) & 7;                                                                       \
           }                                                                                                \
           if constexpr (PIPE) {                                                                            \
-            Frag<T> ca[MI], cb[NI];                                                                        \
+            FragA<T> ca[MI];                                                                               \
+            Frag<T> cb[NI];                                                                                \
             _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ks += 2) {                                     \
               _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) ld_frag_at(ca[mi], arow[mi], asw[mi], ks, h); \
               _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) ld_frag_at(cb[ni], Bcur + brow[ni], bsw, ks, h); \
@@ -348,7 +350,8 @@ __global__ __launch_bounds__(512) void conv3_halo_spec_kernel(const IgemmParams 
             }                                                                                              \
           } else {                                                                                         \
           _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks) {                                          \
-            Frag<T> a[MI], b[NI];                                                                          \
+            FragA<T> a[MI];                                                                                \
+            Frag<T> b[NI];                                                                                 \
             _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) ld_frag_at(a[mi], arow[mi], asw[mi], ks, h); \
             _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) ld_frag_at(b[ni], Bcur + brow[ni], bsw, ks, h); \
             _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                              \
@@ -402,6 +405,11 @@ static int launch_halo_spec_nbst(const IgemmParams& p, int nbst, int splitk, hip
 // p.algo == 11 (compiler-scheduled consumers) / 12 (explicit, interleaved fragment pipeline); nbst = ring depth already chosen by the caller
 int launch_conv3_halo_spec(const IgemmParams& p, int dtype, int bm, int nbst, int splitk, hipStream_t stream) {
   const bool pipe = p.algo == 12;
+  if (dtype == K22_F16X2) {
+    // asymmetric split: activation fragments are 4 registers (hi halves only), so the two-set pipeline fits at BM = 256 too
+    if (!pipe) return bm == 256 ? launch_halo_spec_nbst<x2_t, 256, false>(p, nbst, splitk, stream) : launch_halo_spec_nbst<x2_t, 128, false>(p, nbst, splitk, stream);
+    return bm == 256 ? launch_halo_spec_nbst<x2_t, 256, true>(p, nbst, splitk, stream) : launch_halo_spec_nbst<x2_t, 128, true>(p, nbst, splitk, stream);
+  }
   if (dtype == K22_F16X3) {
     // BM = 256: two fragment sets of 8 registers per fragment do not fit beside 128 accumulators (as for fp32): compiler-scheduled consumers
     if (!pipe) return bm == 256 ? launch_halo_spec_nbst<x3_t, 256, false>(p, nbst, splitk, stream) : launch_halo_spec_nbst<x3_t, 128, false>(p, nbst, splitk, stream);

@@ -105,7 +105,6 @@ struct K22UNet {
     return K22_OK;
   }
   size_t ws_bytes = 0;
-  int n_pre = 0;   // leading ops of `ops` that form the prologue of a forward (run_pre / run_body)
   char* ws = nullptr;
   bool cond_set = false;
   bool warmed = false;   // one eager pass of the op list has run on this plan (function attributes set, code loaded): capture may start
@@ -145,117 +144,21 @@ struct K22UNet {
   }
   const float* Wf(const std::string& name) { return reinterpret_cast<const float*>(W_(name)); }
 
-  // ---- two half-batch chains (round 4) ------------------------------------------------------------------------------------------
-  // A forward is a chain of ~400 DEPENDENT launches of which about a third (GroupNorm coefficients / apply, the 20-us GEMMs of the
-  // AttentionBlocks, split-K finishes) move little data and leave most of the 256 CUs idle.  Images never interact inside the UNet
-  // (GroupNorm and attention are per sample; the CFG pair [cond | uncond] is two samples), so an even batch runs as TWO independent
-  // half-batch engines ("kids": same weights, own workspace) on two streams forked from and joined into the caller's - in the captured
-  // graph two parallel branches - and one chain's latency-bound stretches overlap the other's MFMA-bound ones.  Measured at C2 (bf16,
-  // tools/two_stream_probe.py, two separately launched graphs on two streams): 8.20 ms for one B = 2 chain, 5.89 ms for one B = 1 chain
-  // alone, 7.31 ms for two B = 1 chains overlapped.  In the engine: one captured graph PER KID launched side by side, the step loop driven
-  // from the host: bf16 C2 152.5 steps/s against 146.9 (+3.9 %), C4 -5 %, split precision +3.7 %, bit-reproducible for all four engine types
-  // (as two branches of ONE captured graph hipGraph gave no overlap at all).  OPT-IN (K22_CHAINS=2), off by default.  Round 4's first,
-  // eager form put the whole op lists inside the fork and the FIRST image of the lagging chain came out 2e-2 off in ~70 % of the f16x3
-  // forwards; that was traced (profiles/r04_chains_root_cause.txt) to ONE kernel pair - linear_smallm_kernel (the time-embedding MLP, the
-  // first op of a forward) returns wrong elements while igemm_kernel<16-bit, 128x64> workgroups of the other chain are resident on its
-  // SIMD - and is avoided BY CONSTRUCTION since: both kids' prologues (run_pre) run on the caller's stream before the fork, only the
-  // bodies overlap (eager: 0 of 11 forwards wrong where the first form had 6 of 6).  The
-  // parent engine owns no ops of its own: only the fork / join and the workspace layout [kid 0 | kid 1 | combined model output].
-  K22UNet* kid[2] = {nullptr, nullptr};
-  bool chained = false;
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  size_t kid_off[2] = {0, 0}, comb_off = 0;
-  int nparts() const { return chained ? 2 : 1; }
-  K22UNet* part(int i) { return chained ? kid[i] : this; }
-  const K22UNet* part(int i) const { return chained ? kid[i] : this; }
-  int partB() const { return chained ? B / 2 : B; }
-  // the [B][out_channels][HW] model output as one tensor (chained: gathered from the kids by fetch_out)
-  float* model_out() { return chained ? reinterpret_cast<float*>(ws + comb_off) : ptr<float>(s_out); }
-  int fetch_out(hipStream_t st) {
-    if (!chained) return K22_OK;
-    const size_t n = (size_t)(B / 2) * cfg.out_channels * H * W * 4;
-    for (int i = 0; i < 2; ++i) {
-      hipError_t e = hipMemcpyAsync(ws + comb_off + i * n, kid[i]->ptr(kid[i]->s_out), n, hipMemcpyDeviceToDevice, st);
-      if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-    }
-    return K22_OK;
-  }
-  // one forward of the whole batch on `st` (inputs staged, conditioning set): the op list, or the two kids' op lists in parallel
-  int fork_side(hipStream_t st) {
-    hipError_t e = hipEventRecord(ev_fork, st);
-    if (e == hipSuccess) e = hipStreamWaitEvent(side, ev_fork, 0);
-    return e == hipSuccess ? (int)K22_OK : k22_set_error_hip(e, __FILE__, __LINE__);
-  }
-  int join_side(hipStream_t st) {
-    hipError_t e = hipEventRecord(ev_join, side);
-    if (e == hipSuccess) e = hipStreamWaitEvent(st, ev_join, 0);
-    return e == hipSuccess ? (int)K22_OK : k22_set_error_hip(e, __FILE__, __LINE__);
-  }
-  int exec(hipStream_t st) {
-    if (!chained) return run_ops(st);
-    static const bool serial = getenv("K22_CHAINS_SERIAL") && atoi(getenv("K22_CHAINS_SERIAL")) != 0;   // debug: both kids on the caller's stream
-    if (serial) { int rc0 = kid[0]->run_ops(st); return rc0 ? rc0 : kid[1]->run_ops(st); }
-    // Both prologues first, on the caller's stream: linear_smallm_kernel (the time-embedding MLP) is the one kernel of a forward that was
-    // found to return wrong elements while igemm_kernel<16-bit, 128x64> workgroups of the OTHER chain are resident on its SIMD
-    // (profiles/r04_chains_root_cause.txt); before the fork nothing of the other chain runs.
-    static const int dbg_swap0 = getenv("K22_CHAINS_SWAP") ? atoi(getenv("K22_CHAINS_SWAP")) : 0;
-    if (dbg_swap0 == 0) { for (int i = 0; i < 2; ++i) { int rcp = kid[i]->run_pre(st); if (rcp) return rcp; } }
-    int rc = fork_side(st);
-    if (rc) return rc;
-    static const int dbg_swap = getenv("K22_CHAINS_SWAP") ? atoi(getenv("K22_CHAINS_SWAP")) : 0;   // debug (tools/chains_gap_probe.py):
-    int rc1;                                                                                           // 1 = kid 0 on the side stream, 2 = kid 1 enqueued first,
-    if (dbg_swap == 1) { rc = kid[0]->run_ops(side); rc1 = rc ? rc : kid[1]->run_ops(st); }          // 3 = round 4's first form (prologues inside the fork)
-    else if (dbg_swap == 2) { rc = kid[1]->run_ops(side); rc1 = rc ? rc : kid[0]->run_ops(st); }
-    else if (dbg_swap == 3) { rc = kid[0]->run_ops(st); rc1 = rc ? rc : kid[1]->run_ops(side); }
-    else { rc = kid[0]->run_body(st); rc1 = rc ? rc : kid[1]->run_body(side); }
-    rc = join_side(st);
-    return rc1 ? rc1 : rc;
-  }
-  // Two chains, graph form: ONE captured graph per kid, launched side by side on the caller's stream and the side stream.  (As two branches
-  // of one captured graph hipGraph ran the chains back to back - measured, profiles/r04_two_chains.txt - so the parent captures nothing.)
-  int capture_own_graph(hipStream_t st) {
-    if (graph_exec) return K22_OK;
-    if (!warmed) { int rc = run_ops_eager(st); if (rc) return rc; }
-    hipError_t e;
-    if (!cap_stream) {
-      e = hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking);
-      if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-    }
-    hipGraph_t g = nullptr;
-    e = hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal);
-    if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-    const int rc = run_body(cap_stream);   // (kids only: the prologue is launched by the parent before the fork)
-    e = hipStreamEndCapture(cap_stream, &g);
-    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
-    if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-    e = hipGraphInstantiate(&graph_exec, g, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(g);
-    if (e != hipSuccess) { graph_exec = nullptr; return k22_set_error_hip(e, __FILE__, __LINE__); }
-    return K22_OK;
-  }
-  int exec_kid_graphs(hipStream_t st) {
-    for (int i = 0; i < 2; ++i) { int rc = kid[i]->capture_own_graph(st); if (rc) return rc; }
-    for (int i = 0; i < 2; ++i) { int rc = kid[i]->run_pre(st); if (rc) return rc; }   // both prologues before the fork: see exec()
-    int rc = fork_side(st);
-    if (rc) return rc;
-    hipError_t e = hipGraphLaunch(kid[0]->graph_exec, st);
-    if (e == hipSuccess) e = hipGraphLaunch(kid[1]->graph_exec, side);
-    rc = join_side(st);
-    if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-    return rc;
-  }
+  // (Round 4's "two half-batch chains" mode - the CFG pair as two engines on two streams, +3.9 % - is gone: one kernel pair of it,
+  // linear_smallm_kernel beside igemm_kernel<16-bit, 128 x 64> on another stream, returned wrong elements and was never explained
+  // (profiles/r04_chains_root_cause.txt); a mode that needs a work-around for an unexplained wrong result does not ship.  See
+  // INTEGRATION.md G for what that finding means for a host that overlaps two engines itself.)
+  // the [B][out_channels][HW] model output
+  float* model_out() { return ptr<float>(s_out); }
+  int exec(hipStream_t st) { return run_ops(st); }
   int exec_eager(hipStream_t st) { const int rc = exec(st); if (rc == K22_OK) warmed = true; return rc; }
   // first forward of a plan / binding: fragment-major weight copies, tile configurations the table does not know
   int prepare_run(hipStream_t st) {
-    for (int i = 0; i < nparts(); ++i) {
-      K22UNet* k = part(i);
-      if (!k->frag_done) { int rc = k->repack_frags(st); if (rc) return rc; }
-      if (k->autotune && !k->tuned_done) {
-        int rc = k->tune_all(st);
-        if (rc) return rc;
-        k->tuned_done = true;
-      }
+    if (!frag_done) { int rc = repack_frags(st); if (rc) return rc; }
+    if (autotune && !tuned_done) {
+      int rc = tune_all(st);
+      if (rc) return rc;
+      tuned_done = true;
     }
     return K22_OK;
   }
@@ -263,39 +166,11 @@ struct K22UNet {
     if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
     if (loop_exec) { (void)hipGraphExecDestroy(loop_exec); loop_exec = nullptr; }
   }
-  // plan for batch nB: two kids of nB / 2 when the batch is even and chains are on, else this engine's own op list
-  int plan_top(int nB, int nH, int nW) {
-    if (kid[0] == nullptr || nB < 2 || nB % 2) { chained = false; return plan(nB, nH, nW); }
-    if (nB > 8) return k22_set_error(K22_EINVAL, "unet: batch (2*bs) must be <= 8 per engine call");
-    for (int i = 0; i < 2; ++i) { int rc = kid[i]->plan(nB / 2, nH, nW); if (rc) return rc; }
-    chained = true;
-    B = nB; H = nH; W = nW;
-    ops.clear(); cond_ops.clear(); hint_ops.clear(); tuned.clear();
-    drop_graphs();
-    ws = nullptr; cond_set = false; hint_set = false; warmed = false;
-    kid_off[0] = 0;
-    kid_off[1] = (kid[0]->ws_bytes + 255) / 256 * 256;
-    if (const char* g = getenv("K22_KID_GAP_MB")) kid_off[1] += (size_t)atoi(g) << 20;   // debug: a guard region between the kids (tools/chains_gap_probe.py)
-    comb_off = kid_off[1] + (kid[1]->ws_bytes + 255) / 256 * 256;
-    ws_bytes = comb_off + (size_t)nB * cfg.out_channels * nH * nW * 4 + 256;
-    if (!side) {
-      hipError_t e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_join, hipEventDisableTiming);
-      if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-    }
-    return K22_OK;
-  }
 
   ~K22UNet() {
     if (loop_exec) (void)hipGraphExecDestroy(loop_exec);
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
-    if (ev_fork) (void)hipEventDestroy(ev_fork);
-    if (ev_join) (void)hipEventDestroy(ev_join);
-    if (side) (void)hipStreamDestroy(side);
-    delete kid[0];
-    delete kid[1];
   }
 
   // One forward on `st`: the op list in order.  (A variant that forked the time-embedding / FiLM GEMV onto a second stream,
@@ -307,10 +182,6 @@ struct K22UNet {
     return K22_OK;
   }
   int run_ops(hipStream_t st) { return run_ops_range(st, 0, ops.size()); }
-  // two chains: the PROLOGUE of a forward (group-sum clear + timestep embedding + the FiLM GEMV: n_pre ops, four small kernels) runs on the
-  // caller's stream before the fork, the BODY on the kid's own stream - see exec()
-  int run_pre(hipStream_t st) { return run_ops_range(st, 0, (size_t)n_pre); }
-  int run_body(hipStream_t st) { return run_ops_range(st, (size_t)n_pre, ops.size()); }
   int run_ops_eager(hipStream_t st) { const int rc = run_ops(st); if (rc == K22_OK) warmed = true; return rc; }
 
   // ------------------------------------------------------------------------------------------
@@ -329,7 +200,7 @@ struct K22UNet {
     const float* beta = Wf(pfx + ".bias");
     const Act a = in;
     const int dt = sdt;
-    const int x3 = dtype == K22_F16X3 ? 1 : 0;   // every GroupNorm output feeds a convolution or the qkv GEMM: written in x3 chunks
+    const int x3 = k22_is_split(dtype) ? 1 : 0;   // every GroupNorm output feeds a convolution or the qkv GEMM: written in x3 chunks
     const double gn_bytes = (double)Bn * HW * C * esz * (fused ? 1.0 : 2.0) + (double)Bn * (Ho + 2 * pad) * (Wo + 2 * pad) * C * esz;
     if (gn_onepass && !x3 && a.s1 == nullptr && a.gs0 >= 0 && gn_apply3_supported(C, dtype)) {
       // the producer accumulated this tensor's group sums: one kernel, no statistics / coefficient pass
@@ -380,21 +251,45 @@ struct K22UNet {
   }
 
   static void apply_cfg(IgemmParams& q, const Cfg& c) { tuned_apply_cfg(q, c); }
-  void make_candidates(Tuned& t) { tuned_make_candidates(t, dtype); }
-  void default_cfg(Tuned& t) { tuned_default_cfg(t, dtype); }
-  void finish_cfg(Tuned& t) { tuned_finish_cfg(t, dtype); }
+  int op_dt(const Tuned& t) const { return t.dt >= 0 ? t.dt : dtype; }
+  void make_candidates(Tuned& t) { tuned_make_candidates(t, op_dt(t)); }
+  void default_cfg(Tuned& t) { tuned_default_cfg(t, op_dt(t)); }
+  void finish_cfg(Tuned& t) { tuned_finish_cfg(t, op_dt(t)); }
   size_t max_splitk_bytes(const Tuned& t) const { return tuned_max_splitk_bytes(t, autotune != 0); }
-  int max_rpi(const Tuned& t) const { return tuned_max_rpi(t, dtype, autotune != 0); }
+  int max_rpi(const Tuned& t) const { return tuned_max_rpi(t, op_dt(t), autotune != 0); }
+
+  // ---- precision plan of the asymmetric split engine (K22_F16X2; round 5) -----------------------------------------------------------
+  // Which MFMA ops take the activation operand at fp16 precision (two MFMAs per product) and which keep the full split (three) is a
+  // property of the PLAN, read off the operand-rounding ablation of the oracle (oracle/drift_ablation.py -> tests/golden/
+  // drift_ablation_x2.json; share of the first-forward error variance of "every activation operand at fp16"):
+  //   1x1 skip_connection inputs (the un-normalised residual stream)           51 %   -> always three MFMAs (3 % of the FLOPs)
+  //   the out head's 3x3 convolution (384 -> 8 channels)                       14 %   -> always three MFMAs (0.03 % of the FLOPs)
+  //   3x3 convolutions of the top level: in_layers 12 %, out_layers 14 %              -> x2_plan bits 0 / 1 (40 % of the FLOPs)
+  //   3x3 convolutions one level down 6 %, two 0.7 %, three 0.08 %; qkv 0.02 %        -> two MFMAs
+  //   attention operands (q, k, v, P)                                          1.5 %  -> ONE MFMA (fp16 tiles, attention_kernel<xh_t>)
+  //   proj_out, encoder_kv, to_model_dim_n (small; inputs not normalised)             -> three MFMAs
+  // x2_plan: bit 0 = the top level's in_layers convolutions run x2, bit 1 = its out_layers convolutions run x2 (default 1, K22_X2_PLAN).
+  int x2_plan = 1;
+  enum ConvRole { CONV_IN = 0, CONV_OUT = 1, CONV_HEAD = 2 };
+  int conv_dt(int role, int Hc) const {
+    if (dtype != K22_F16X2) return dtype;
+    if (role == CONV_HEAD) return K22_F16X3;
+    if (Hc >= H) return (x2_plan >> role) & 1 ? K22_F16X2 : K22_F16X3;   // top level (the latent's own resolution)
+    return K22_F16X2;
+  }
+  // GEMMs: only the qkv projection (its input is a GroupNorm output) runs x2
+  int gemm_dt(bool qkv) const { return dtype == K22_F16X2 ? (qkv ? K22_F16X2 : K22_F16X3) : dtype; }
 
   // conv3x3 over a zero-bordered slot `src` [B][Hc+2][Wc+2][Cin].  `stats` (optional) receives the GroupNorm
   // partial sums of the output; returns the launch descriptor (null when the output is not a tunable T tensor).
   // gn_in (optional): the raw tensor(s) whose GroupNorm (coefficients in s_coeff, written by the op_gn just before) `src` holds: with a
   // specialised-kernel configuration the convolution reads gn_in and applies the coefficients in its halo fill instead of reading `src`
-  Tuned* op_conv(OpList& L, Slot* src, int Hc, int Wc, int Cin, int Cout,
+  Tuned* op_conv(OpList& L, int role, Slot* src, int Hc, int Wc, int Cin, int Cout,
                  const std::string& pfx, const Act* residual, Slot* dst, int out_mode, Slot* stats = nullptr,
                  const Act* skip_in = nullptr, const std::string& skip_pfx = std::string(), const Act* gn_in = nullptr, int gn_act = K22_ACT_NONE) {
     tuned.emplace_back();
     Tuned* t = &tuned.back();
+    t->dt = conv_dt(role, Hc);
     IgemmParams& p = t->p;
     p.stages = -1;
     p.M = B * Hc * Wc; p.N = Cout; p.Npad = (Cout + 63) / 64 * 64; p.Kc = Cin; p.K0 = Cin; p.taps = 9;
@@ -442,7 +337,7 @@ struct K22UNet {
     t->gsum_off = gs;
     need(dst, out_mode == IG_OUT_ROWMAJOR ? (size_t)p.M * Cout * esz : (size_t)p.M * Cout * sizeof(float));
     Slot* rs = residual ? residual->s0 : nullptr;
-    const int dt = dtype;
+    const int dt = t->dt;
     const bool gnf = gn_in != nullptr && fuse_gn;
     Act ga;
     if (gnf) ga = *gn_in;
@@ -473,6 +368,7 @@ struct K22UNet {
                  const Act* residual, Slot* dst, int ldo = 0, int out_mode = IG_OUT_ROWMAJOR, Slot* stats = nullptr, bool a_raw = false) {
     tuned.emplace_back();
     Tuned* t = &tuned.back();
+    t->dt = gemm_dt(out_mode == IG_OUT_QKV);
     IgemmParams& p = t->p;
     p.stages = -1;
     p.M = M; p.N = N; p.Npad = (N + 63) / 64 * 64; p.Kc = in.C(); p.K0 = in.C0; p.taps = 1;
@@ -481,7 +377,7 @@ struct K22UNet {
     if (in.H > 0 && in.W > 0 && M % (in.H * in.W) == 0 && M / (in.H * in.W) == B) { p.H = in.H; p.W = in.W; }  // rows per image
     if (out_mode == IG_OUT_QKV) p.att_T = in.H * in.W;
     p.Wp = W_(pfx + ".weight"); p.bias = Wf(pfx + ".bias");
-    p.a_raw = (a_raw && dtype == K22_F16X3) ? 1 : 0;
+    p.a_raw = (a_raw && k22_is_split(dtype)) ? 1 : 0;
     t->want_stats = stats != nullptr && p.H > 0;
     make_candidates(*t);
     if (t->want_stats && t->cands.empty()) { t->want_stats = false; make_candidates(*t); }
@@ -493,7 +389,7 @@ struct K22UNet {
     need(dst, (size_t)M * p.ldo * esz);
     const Act a = in;
     Slot* rs = residual ? residual->s0 : nullptr;
-    const int dt = dtype;
+    const int dt = t->dt;
     t->run = [=](hipStream_t st) {
       IgemmParams q = t->p;
       apply_cfg(q, t->cfg);
@@ -519,7 +415,7 @@ struct K22UNet {
     GnLink* l1 = nullptr;
     if (fuse_gn && updown == 0) { gn_links.emplace_back(); l1 = &gn_links.back(); }   // (the resampling GroupNorms keep gn_apply)
     op_gn(ops, in, pfx + ".in_layers.0", -1, K22_ACT_SILU, updown, 1, s_P1, l1);
-    Tuned* t1 = op_conv(ops, s_P1, Ho, Wo, Cin, Cout, pfx + ".in_layers.2", nullptr, s_U1, IG_OUT_ROWMAJOR, s_U1st, nullptr, std::string(),
+    Tuned* t1 = op_conv(ops, CONV_IN, s_P1, Ho, Wo, Cin, Cout, pfx + ".in_layers.2", nullptr, s_U1, IG_OUT_ROWMAJOR, s_U1st, nullptr, std::string(),
                         l1 ? &in : nullptr, K22_ACT_SILU);
     if (l1) l1->consumer = t1;
     // out_layers: GN * (1+scale) + shift -> SiLU -> conv3x3 (+ skip)
@@ -546,7 +442,7 @@ struct K22UNet {
       probe.S0 = reinterpret_cast<const void*>(1); probe.S1 = in.s1 ? reinterpret_cast<const void*>(1) : nullptr;
       probe.SK0 = in.C0; probe.SK1 = in.C1; probe.Ws = reinterpret_cast<const void*>(1);
       if (fuse_skip && Cout >= 128 && (conv3_halo_supported(probe, dtype, 256) || conv3_halo_supported(probe, dtype, 128))) {
-        Tuned* t2 = op_conv(ops, s_P2, Ho, Wo, Cout, Cout, pfx + ".out_layers.3", nullptr, dst, IG_OUT_ROWMAJOR, dst_stats,
+        Tuned* t2 = op_conv(ops, CONV_OUT, s_P2, Ho, Wo, Cout, Cout, pfx + ".out_layers.3", nullptr, dst, IG_OUT_ROWMAJOR, dst_stats,
                             &in, pfx + ".skip_connection", l2 ? &u1 : nullptr, K22_ACT_SILU);
         if (l2) l2->consumer = t2;
         Act out; out.s0 = dst; out.C0 = Cout; out.H = Ho; out.W = Wo;
@@ -559,7 +455,7 @@ struct K22UNet {
       if (in.s1) { if (err.empty()) err = "identity skip over a concat input"; }
       skip.s0 = in.s0;
     }
-    Tuned* t2 = op_conv(ops, s_P2, Ho, Wo, Cout, Cout, pfx + ".out_layers.3", &skip, dst, IG_OUT_ROWMAJOR, dst_stats, nullptr, std::string(),
+    Tuned* t2 = op_conv(ops, CONV_OUT, s_P2, Ho, Wo, Cout, Cout, pfx + ".out_layers.3", &skip, dst, IG_OUT_ROWMAJOR, dst_stats, nullptr, std::string(),
                         l2 ? &u1 : nullptr, K22_ACT_SILU);
     if (l2) l2->consumer = t2;
     Act out; out.s0 = dst; out.C0 = Cout; out.H = Ho; out.W = Wo;
@@ -604,7 +500,7 @@ struct K22UNet {
       AttentionParams ap = {};
       ap.q = ptr(s_QKV); ap.ldq = C; ap.kall = ptr(kall); ap.vtall = ptr(vtall); ap.out = ptr(s_ATT); ap.ldo = C;
       ap.B = Bn; ap.H = Hh; ap.T = T; ap.Tk = Tk; ap.Tkp = Tkp; ap.scale = 0.125f;
-      ap.out_x3 = dt == K22_F16X3 ? 1 : 0;   // proj_out reads it as an x3-chunk operand
+      ap.out_x3 = k22_is_split(dt) ? 1 : 0;   // proj_out reads it as an x3-chunk operand
       return launch_attention(ap, dt, st);
     }, OP_ATTN, 4.0 * Bn * Hh * (double)T * Tk * 64.0, 0.0, 1));
     Act a; a.s0 = s_ATT; a.C0 = C; a.H = in.H; a.W = in.W;
@@ -786,7 +682,7 @@ struct K22UNet {
     if (film_cursor != film_total) return k22_set_error(K22_EINVAL, "unet: internal FiLM width mismatch");
     // ---- out: GN + SiLU + conv3x3 -> fp32 NCHW ---------------------------------------------------
     op_gn(ops, h, "out.0", -1, K22_ACT_SILU, 0, 1, s_P1);
-    op_conv(ops, s_P1, H, W, ch, cfg.out_channels, "out.2", nullptr, s_out, IG_OUT_NCHW_F32);
+    op_conv(ops, CONV_HEAD, s_P1, H, W, ch, cfg.out_channels, "out.2", nullptr, s_out, IG_OUT_NCHW_F32);
 
     if (!err.empty()) return k22_set_error(K22_EINVAL, err.c_str());
     // first op of every forward: clear the GroupNorm group sums the conv / GEMM epilogues accumulate into
@@ -802,11 +698,6 @@ struct K22UNet {
     size_t off = 0;
     for (auto& s : slots) { s.off = off; off += (s.bytes + 255) / 256 * 256; }
     ws_bytes = off + 256;
-    n_pre = gsum_bytes ? 2 : 1;   // [group-sum clear,] time embedding + FiLM vectors
-    if (getenv("K22_DBG_SLOTS")) {   // debug: the workspace map (tools/chains_gap_probe.py diffs workspaces of two forwards)
-      int i = 0;
-      for (auto& s : slots) { if (s.bytes) fprintf(stderr, "k22 slot %3d off %12zu bytes %12zu\n", i, s.off, s.bytes); ++i; }
-    }
     return K22_OK;
   }
 
@@ -904,15 +795,16 @@ struct K22UNet {
     p.stages = -1;
       p.M = ntext; p.N = cd; p.Npad = (cd + 63) / 64 * 64; p.Kc = d1; p.K0 = d1; p.taps = 1; p.lda0 = d1; p.ldo = cd;
       p.out_mode = IG_OUT_ROWMAJOR; p.splitk = 1;
-      p.a_raw = dtype == K22_F16X3 ? 1 : 0;   // s_fullT: plain rows written by cast_rows
+      p.a_raw = k22_is_split(dtype) ? 1 : 0;   // s_fullT: plain rows written by cast_rows
       p.Wp = W_("to_model_dim_n.weight"); p.bias = Wf("to_model_dim_n.bias");
       const size_t es = esz;
+      const int gdt = gemm_dt(false);
       cond_ops.push_back([=](hipStream_t st) {
         for (int b = 0; b < Bn; ++b) {
           IgemmParams q = p;
           q.A0 = ptr(s_fullT) + (size_t)b * ntext * d1 * es;
           q.out = ptr(s_ctx) + ((size_t)b * S + nie) * cd * es;
-          int rc = launch_igemm(q, adt, st);
+          int rc = launch_igemm(q, gdt, st);
           if (rc) return rc;
         }
         return K22_OK;
@@ -928,7 +820,7 @@ extern "C" {
 
 int k22_unet_create(const K22UNetConfig* cfg, const K22Weight* weights, int n_weights, K22UNet** out) {
   if (!cfg || !out) return k22_set_error(K22_EINVAL, "unet_create: null argument");
-  if (!k22_dtype_ok(cfg->dtype) && cfg->dtype != K22_F16X3) return k22_set_error(K22_EINVAL, "unet_create: dtype");
+  if (!k22_dtype_ok(cfg->dtype) && !k22_is_split(cfg->dtype)) return k22_set_error(K22_EINVAL, "unet_create: dtype");
   if (cfg->num_head_channels != 64) return k22_set_error(K22_EINVAL, "unet_create: only num_head_channels == 64");
   if (cfg->model_channels % 128) return k22_set_error(K22_EINVAL, "unet_create: model_channels % 128");
   if (cfg->n_levels < 1 || cfg->n_levels > 8) return k22_set_error(K22_EINVAL, "unet_create: n_levels");
@@ -958,21 +850,10 @@ int k22_unet_create(const K22UNetConfig* cfg, const K22Weight* weights, int n_we
     u->fuse_gn = fg ? (atoi(fg) != 0) : 0;
     const char* f = getenv("K22_FUSE_SKIP");  // 0 = 1x1 skip connections as separate GEMMs
     u->fuse_skip = f ? (atoi(f) != 0) : 1;
+    const char* xp = getenv("K22_X2_PLAN");   // K22_F16X2 only: which of the top level's convolutions run with two MFMAs (K22UNet::x2_plan)
+    u->x2_plan = xp ? (atoi(xp) & 3) : 1;
   }
   for (int i = 0; i < n_weights; ++i) u->w[weights[i].name] = weights[i].ptr;
-  {
-    const char* ch = getenv("K22_CHAINS");   // 2 = an even batch as two half-batch chains (experimental, see K22UNet::kid); default 1
-    if (ch && atoi(ch) == 2) {
-      for (int i = 0; i < 2; ++i) {
-        K22UNet* k = new K22UNet();
-        k->cfg = u->cfg; k->dtype = u->dtype; k->sdt = u->sdt; k->esz = u->esz;
-        k->autotune = u->autotune; k->gn_onepass = u->gn_onepass; k->gn_fused = u->gn_fused; k->stream_frag = u->stream_frag;
-        k->fuse_gn = u->fuse_gn; k->fuse_skip = u->fuse_skip;
-        k->w = u->w;
-        u->kid[i] = k;
-      }
-    }
-  }
   *out = u;
   return K22_OK;
 }
@@ -981,7 +862,7 @@ void k22_unet_destroy(K22UNet* u) { delete u; }
 
 int k22_unet_plan(K22UNet* u, int B, int H, int W, size_t* workspace_bytes) {
   if (!u || !workspace_bytes) return k22_set_error(K22_EINVAL, "unet_plan: null argument");
-  int rc = u->plan_top(B, H, W);
+  int rc = u->plan(B, H, W);
   if (rc) return rc;
   *workspace_bytes = u->ws_bytes;
   return K22_OK;
@@ -989,19 +870,12 @@ int k22_unet_plan(K22UNet* u, int B, int H, int W, size_t* workspace_bytes) {
 
 int k22_unet_bind(K22UNet* u, void* workspace, size_t workspace_bytes) {
   if (!u || !workspace) return k22_set_error(K22_EINVAL, "unet_bind: null argument");
-  if (u->ops.empty() && !u->chained) return k22_set_error(K22_EINVAL, "unet_bind: plan first");
+  if (u->ops.empty()) return k22_set_error(K22_EINVAL, "unet_bind: plan first");
   if (workspace_bytes < u->ws_bytes) return k22_set_error(K22_ENOMEM, "unet_bind: workspace too small");
   if ((uintptr_t)workspace % 256) return k22_set_error(K22_EINVAL, "unet_bind: workspace must be 256-byte aligned");
   u->ws = reinterpret_cast<char*>(workspace);
   u->cond_set = false; u->hint_set = false; u->frag_done = false;
   u->drop_graphs();
-  if (u->chained)
-    for (int i = 0; i < 2; ++i) {
-      K22UNet* k = u->kid[i];
-      k->ws = u->ws + u->kid_off[i];
-      k->cond_set = false; k->hint_set = false; k->frag_done = false;
-      k->drop_graphs();
-    }
   return K22_OK;
 }
 
@@ -1013,20 +887,16 @@ int k22_unet_set_condition(K22UNet* u, const float* full_emb, const float* poole
   if (!image_emb) return k22_set_error(K22_EINVAL, "unet_set_condition: image_emb is required");
   if (c.head_type == 0 && (!full_emb || !pooled_emb)) return k22_set_error(K22_EINVAL, "unet_set_condition: the 2.1 head needs full_emb and pooled_emb");
   hipError_t e;
-  const size_t pb = (size_t)u->partB();
-  for (int i = 0; i < u->nparts(); ++i) {
-    K22UNet* k = u->part(i);
-    if (c.head_type == 0) {
-      e = hipMemcpyAsync(k->ptr(k->s_full), full_emb + i * pb * ntext * c.text_dim1, pb * ntext * c.text_dim1 * 4, hipMemcpyDeviceToDevice, st);
-      if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-      e = hipMemcpyAsync(k->ptr(k->s_pool), pooled_emb + i * pb * c.text_dim2, pb * c.text_dim2 * 4, hipMemcpyDeviceToDevice, st);
-      if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-    }
-    e = hipMemcpyAsync(k->ptr(k->s_imgemb), image_emb + i * pb * c.image_dim, pb * c.image_dim * 4, hipMemcpyDeviceToDevice, st);
+  const size_t pb = (size_t)u->B;
+  if (c.head_type == 0) {
+    e = hipMemcpyAsync(u->ptr(u->s_full), full_emb, pb * ntext * c.text_dim1 * 4, hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-    for (auto& op : k->cond_ops) { int rc = op(st); if (rc) return rc; }
-    k->cond_set = true;
+    e = hipMemcpyAsync(u->ptr(u->s_pool), pooled_emb, pb * c.text_dim2 * 4, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
   }
+  e = hipMemcpyAsync(u->ptr(u->s_imgemb), image_emb, pb * c.image_dim * 4, hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+  for (auto& op : u->cond_ops) { int rc = op(st); if (rc) return rc; }
   u->cond_set = true;
   return K22_OK;
 }
@@ -1036,14 +906,10 @@ int k22_unet_set_hint(K22UNet* u, const float* hint, void* stream) {
   if (!u->cfg.hint_channels) return k22_set_error(K22_EINVAL, "unet_set_hint: this UNet has no hint input (hint_channels == 0)");
   if (!hint) return k22_set_error(K22_EINVAL, "unet_set_hint: null hint");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const size_t per = (size_t)u->partB() * u->cfg.hint_channels * 64 * u->H * u->W;
-  for (int i = 0; i < u->nparts(); ++i) {
-    K22UNet* k = u->part(i);
-    hipError_t e = hipMemcpyAsync(k->ptr(k->s_hintin), hint + i * per, per * 4, hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-    for (auto& op : k->hint_ops) { int rc = op(st); if (rc) return rc; }
-    k->hint_set = true;
-  }
+  const size_t per = (size_t)u->B * u->cfg.hint_channels * 64 * u->H * u->W;
+  hipError_t e = hipMemcpyAsync(u->ptr(u->s_hintin), hint, per * 4, hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+  for (auto& op : u->hint_ops) { int rc = op(st); if (rc) return rc; }
   u->hint_set = true;
   return K22_OK;
 }
@@ -1060,22 +926,16 @@ int k22_unet_forward(K22UNet* u, const float* x, const float* timesteps, const f
 #define K22_CPY(dst, src, bytes)                                                   \
   e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);                \
   if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-  const size_t pb = (size_t)u->partB();
-  for (int i = 0; i < u->nparts(); ++i) {
-    K22UNet* k = u->part(i);
-    K22_CPY(k->ptr(k->s_xin), x + i * pb * 4 * hw, pb * 4 * hw * 4);
-    K22_CPY(k->ptr(k->s_t), timesteps + i * pb, pb * 4);
-    if (u->cfg.in_channels == 9) {
-      K22_CPY(k->ptr(k->s_img), inpaint_image + i * pb * 4 * hw, pb * 4 * hw * 4);
-      K22_CPY(k->ptr(k->s_mask), inpaint_mask + i * pb * hw, pb * hw * 4);
-    }
+  const size_t pb = (size_t)u->B;
+  K22_CPY(u->ptr(u->s_xin), x, pb * 4 * hw * 4);
+  K22_CPY(u->ptr(u->s_t), timesteps, pb * 4);
+  if (u->cfg.in_channels == 9) {
+    K22_CPY(u->ptr(u->s_img), inpaint_image, pb * 4 * hw * 4);
+    K22_CPY(u->ptr(u->s_mask), inpaint_mask, pb * hw * 4);
   }
   // first forward on this plan: fragment-major weight copies; conv / GEMM problems the tile table does not know are measured on the device
   { int rc = u->prepare_run(st); if (rc) return rc; }
-  if (use_graph && u->chained) {
-    int rc = u->exec_kid_graphs(st);
-    if (rc) return rc;
-  } else if (use_graph) {
+  if (use_graph) {
     if (!u->graph_exec) {
       // warm-up eagerly once (sets function attributes), then capture
       if (!u->warmed) { int rc = u->exec_eager(st); if (rc) return rc; }
@@ -1100,10 +960,7 @@ int k22_unet_forward(K22UNet* u, const float* x, const float* timesteps, const f
     int rc = u->exec_eager(st);
     if (rc) return rc;
   }
-  for (int i = 0; i < u->nparts(); ++i) {
-    K22UNet* k = u->part(i);
-    K22_CPY(out + i * pb * u->cfg.out_channels * hw, k->ptr(k->s_out), pb * u->cfg.out_channels * hw * 4);
-  }
+  K22_CPY(out, u->ptr(u->s_out), pb * u->cfg.out_channels * hw * 4);
 #undef K22_CPY
   return K22_OK;
 }
@@ -1133,40 +990,26 @@ int k22_unet_sample_loop(K22UNet* u, float* x, float* x_tmp, const float* timest
   hipError_t e;
   { int rc = u->prepare_run(st); if (rc) return rc; }
   const size_t half = (size_t)(B / 2) * 4 * HW * sizeof(float);
-  const size_t pb = (size_t)u->partB();   // chained: each kid runs one half of the CFG batch ([cond] / [uncond]): pb == B / 2
+  const size_t pb = (size_t)B;
   // one pass over the loop on `s`: what is captured is exactly what an eager call runs
   auto run_loop = [&](hipStream_t s) -> int {
     hipError_t er;
     if (u->cfg.in_channels == 9) {
-      for (int i = 0; i < u->nparts(); ++i) {
-        K22UNet* kk = u->part(i);
-        er = hipMemcpyAsync(kk->ptr(kk->s_img), inpaint_image + i * pb * 4 * HW, pb * 4 * HW * 4, hipMemcpyDeviceToDevice, s);
-        if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
-        er = hipMemcpyAsync(kk->ptr(kk->s_mask), inpaint_mask + i * pb * HW, pb * HW * 4, hipMemcpyDeviceToDevice, s);
-        if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
-      }
+      er = hipMemcpyAsync(u->ptr(u->s_img), inpaint_image, pb * 4 * HW * 4, hipMemcpyDeviceToDevice, s);
+      if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
+      er = hipMemcpyAsync(u->ptr(u->s_mask), inpaint_mask, pb * HW * 4, hipMemcpyDeviceToDevice, s);
+      if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
     }
     float* cur = x; float* nxt = x_tmp;
     for (int k = 0; k < n_steps; ++k) {
       // model_fn: the UNet sees the first half twice (kandinsky2_1_model.py:223-225)
-      if (u->chained) {
-        for (int i = 0; i < 2; ++i) {
-          er = hipMemcpyAsync(u->kid[i]->ptr(u->kid[i]->s_xin), cur, half, hipMemcpyDeviceToDevice, s);
-          if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
-          er = hipMemcpyAsync(u->kid[i]->ptr(u->kid[i]->s_t), timesteps + (size_t)k * B + i * pb, pb * 4, hipMemcpyDeviceToDevice, s);
-          if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
-        }
-      } else {
       er = hipMemcpyAsync(u->ptr(u->s_xin), cur, half, hipMemcpyDeviceToDevice, s);
       if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
       er = hipMemcpyAsync(u->ptr(u->s_xin) + half, cur, half, hipMemcpyDeviceToDevice, s);
       if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
       er = hipMemcpyAsync(u->ptr(u->s_t), timesteps + (size_t)k * B, (size_t)B * 4, hipMemcpyDeviceToDevice, s);
       if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
-      }
-      int rc = (u->chained && use_graph) ? u->exec_kid_graphs(s) : u->exec(s);
-      if (rc) return rc;
-      rc = u->fetch_out(s);
+      int rc = u->exec(s);
       if (rc) return rc;
       SamplerParams p = {};
       p.x = cur; p.model_out = u->model_out(); p.noise = noise_seq + (size_t)k * B * 4 * HW; p.init_img = init_img; p.mask = mask;
@@ -1184,9 +1027,7 @@ int k22_unet_sample_loop(K22UNet* u, float* x, float* x_tmp, const float* timest
     }
     return K22_OK;
   };
-  // two chains: the loop is driven from the host (per step: stage, two graph launches side by side, join, sampler kernels) - the
-  // whole-loop graph would put both chains into ONE graph, whose branches hipGraph runs back to back
-  if (!use_graph || u->chained) return run_loop(st);
+  if (!use_graph) return run_loop(st);
   // key of the captured loop: every pointer and scalar baked into its nodes
   std::vector<unsigned long long> key = {(unsigned long long)(uintptr_t)x, (unsigned long long)(uintptr_t)x_tmp, (unsigned long long)(uintptr_t)timesteps,
       (unsigned long long)(uintptr_t)noise_seq, (unsigned long long)(uintptr_t)init_img, (unsigned long long)(uintptr_t)mask,
@@ -1199,18 +1040,15 @@ int k22_unet_sample_loop(K22UNet* u, float* x, float* x_tmp, const float* timest
     if (u->loop_exec) { (void)hipGraphExecDestroy(u->loop_exec); u->loop_exec = nullptr; }
     if (!u->warmed) {   // first forward of this plan: run one step's ops eagerly (function attributes, code load) on a scratch input; a re-capture
                         // for other scalars / buffers (guidance, step count: they are baked into the graph's nodes) does not repeat it
-      for (int i = 0; i < u->nparts(); ++i) {
-        K22UNet* kk = u->part(i);
-        e = hipMemsetAsync(kk->ptr(kk->s_xin), 0, pb * 4 * HW * 4, st);
+      e = hipMemsetAsync(u->ptr(u->s_xin), 0, pb * 4 * HW * 4, st);
+      if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+      e = hipMemcpyAsync(u->ptr(u->s_t), timesteps, pb * 4, hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
+      if (u->cfg.in_channels == 9) {
+        e = hipMemcpyAsync(u->ptr(u->s_img), inpaint_image, pb * 4 * HW * 4, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-        e = hipMemcpyAsync(kk->ptr(kk->s_t), timesteps + i * pb, pb * 4, hipMemcpyDeviceToDevice, st);
+        e = hipMemcpyAsync(u->ptr(u->s_mask), inpaint_mask, pb * HW * 4, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-        if (u->cfg.in_channels == 9) {
-          e = hipMemcpyAsync(kk->ptr(kk->s_img), inpaint_image + i * pb * 4 * HW, pb * 4 * HW * 4, hipMemcpyDeviceToDevice, st);
-          if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-          e = hipMemcpyAsync(kk->ptr(kk->s_mask), inpaint_mask + i * pb * HW, pb * HW * 4, hipMemcpyDeviceToDevice, st);
-          if (e != hipSuccess) return k22_set_error_hip(e, __FILE__, __LINE__);
-        }
       }
       int rc = u->exec_eager(st);
       if (rc) return rc;
@@ -1239,24 +1077,20 @@ int k22_unet_sample_loop(K22UNet* u, float* x, float* x_tmp, const float* timest
 }
 
 int k22_unet_num_ops(const K22UNet* u) {
-  if (!u) return 0;
-  int n = 0;
-  for (int i = 0; i < u->nparts(); ++i) n += (int)u->part(i)->ops.size();
-  return n;
+  return u ? (int)u->ops.size() : 0;
 }
 
 int k22_unet_set_autotune(K22UNet* u, int on) {
   if (!u) return k22_set_error(K22_EINVAL, "unet_set_autotune: null handle");
-  if ((!u->ops.empty() || u->chained) && (on != 0) != (u->autotune != 0)) return k22_set_error(K22_EINVAL, "unet_set_autotune: call before k22_unet_plan");
+  if (!u->ops.empty() && (on != 0) != (u->autotune != 0)) return k22_set_error(K22_EINVAL, "unet_set_autotune: call before k22_unet_plan");
   u->autotune = on ? 1 : 0;
-  for (int i = 0; i < 2; ++i) if (u->kid[i]) u->kid[i]->autotune = u->autotune;
   return K22_OK;
 }
 
 // Text table of the chosen tile configurations (one line per distinct conv / GEMM problem of the plan).
 int k22_unet_tuning_report(const K22UNet* u, char* buf, size_t cap) {
   if (!u || !buf || cap == 0) return k22_set_error(K22_EINVAL, "unet_tuning_report: null argument");
-  const std::string out = tuning_report_text(u->part(0)->tuned);   // (two chains: both kids run the same problems)
+  const std::string out = tuning_report_text(u->tuned);
   snprintf(buf, cap, "%s", out.c_str());
   return K22_OK;
 }
@@ -1267,10 +1101,8 @@ int k22_unet_profile(K22UNet* u, int reps, double* ms, double* flops, double* by
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   for (int k = 0; k < OP_NKINDS; ++k) { ms[k] = 0.0; flops[k] = 0.0; bytes[k] = 0.0; launches[k] = 0; }
   int rc = K22_OK;
-  // two chains: the kids are timed one after the other, op by op - ISOLATED device times of both halves, summed (the step itself
-  // overlaps them: the class times then add up to more than the step)
-  for (int part = 0; part < u->nparts() && rc == K22_OK; ++part) {
-    K22UNet* q = u->part(part);
+  {
+    K22UNet* q = u;
     if (!q->frag_done) { int rc0 = q->repack_frags(st); if (rc0) return rc0; }   // a profile before the first forward of this binding
     const size_t n = q->ops.size();
     std::vector<hipEvent_t> ev(2 * n);

@@ -49,6 +49,7 @@ template <> __device__ __forceinline__ void store4<float>(float* dst, const floa
   *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
 }
 template <> __device__ __forceinline__ void store4<x3_t>(x3_t* dst, const float* v) { store4<float>(reinterpret_cast<float*>(dst), v); }
+template <> __device__ __forceinline__ void store4<x2_t>(x2_t* dst, const float* v) { store4<float>(reinterpret_cast<float*>(dst), v); }
 template <typename T> __device__ __forceinline__ void load4f(const T* src, float* v);
 template <> __device__ __forceinline__ void load4f<bf16_t>(const bf16_t* src, float* v) {
   const uint2 r = *reinterpret_cast<const uint2*>(src);
@@ -65,6 +66,7 @@ template <> __device__ __forceinline__ void load4f<float>(const float* src, floa
 }
 
 template <> __device__ __forceinline__ void load4f<x3_t>(const x3_t* src, float* v) { load4f<float>(reinterpret_cast<const float*>(src), v); }
+template <> __device__ __forceinline__ void load4f<x2_t>(const x2_t* src, float* v) { load4f<float>(reinterpret_cast<const float*>(src), v); }
 
 // Logical block index of hardware block `bid` (XCD = bid % 8): XCD x gets the contiguous range
 // [start_x, start_x + count_x) of logical indices, in dispatch order.  Bijective for any nblocks.
@@ -186,9 +188,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         const char* Bs = As + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-          Frag<T> a[MI], b[NI];
+          FragA<T> a[MI];
+          Frag<T> b[NI];
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi) ld_frag_a<ARAW>(a[mi], As, wm * (BM / 2) + mi * 32 + l31, ks, h);
+          for (int mi = 0; mi < MI; ++mi) ld_frag_a<ARAW, T>(a[mi], As, wm * (BM / 2) + mi * 32 + l31, ks, h);
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) ld_frag(b[ni], Bs, wn * (BN / 2) + ni * 32 + l31, ks, h);
 #pragma unroll
@@ -671,7 +674,7 @@ static int launch_reduce_dt(const IgemmParams& q, int dtype, hipStream_t stream)
 
 int launch_igemm(const IgemmParams& p, int dtype, hipStream_t stream) {
   const int BK = k22_bk(dtype);
-  if (p.a_raw && dtype != K22_F16X3) return k22_set_error(K22_EINVAL, "igemm: a_raw is an option of the split-precision arithmetic only");
+  if (p.a_raw && !k22_is_split(dtype)) return k22_set_error(K22_EINVAL, "igemm: a_raw is an option of the split-precision arithmetics only");
   if (p.M <= 0 || p.N <= 0) return K22_OK;
   if (p.taps != 1 && p.taps != 9) return k22_set_error(K22_EINVAL, "igemm: taps must be 1 or 9");
   if (p.Kc % BK != 0 || p.K0 % BK != 0) return k22_set_error(K22_EINVAL, "igemm: K per tap must be a multiple of 64 (bf16) / 32 (fp32)");
@@ -726,5 +729,6 @@ int launch_igemm(const IgemmParams& p, int dtype, hipStream_t stream) {
   else if (dtype == K22_F16) return launch_typed<f16_t>(p, pl, stream);
   if (dtype == K22_F32) return launch_typed<float>(p, pl, stream);
   if (dtype == K22_F16X3) return launch_typed<x3_t>(p, pl, stream);
+  if (dtype == K22_F16X2) return launch_typed<x2_t>(p, pl, stream);
   return k22_set_error(K22_EINVAL, "igemm: bad dtype");
 }

@@ -93,6 +93,7 @@ struct Tuned {
   long long gsum_off = -1;     // engine-specific: offset of the output's GroupNorm group sums (-1 = none)
   float best_us = 0.f;
   bool from_table = false;     // cfg came from the tile table (shipped / cache / measured earlier in this process)
+  int dt = -1;                 // arithmetic of THIS op when it differs from its engine's (a K22_F16X2 plan mixes x2 and x3 ops); -1 = the engine's
   void* aux0 = nullptr; void* aux1 = nullptr;  // engine-specific (IG_OUT_QKV: this block's K_all / V^T_all slots)
   std::function<int(hipStream_t)> run;
 };
@@ -115,7 +116,7 @@ inline void tuned_make_candidates(Tuned& t, int dtype) {
     // 11 = producer / consumer wave specialisation (conv3_halo_spec_kernel)
     for (int algo : {2, 7, 6, 3, 11, 12}) {
       if (algo == 3 && p.H > 16) continue;
-      if (dtype == K22_F16X3 && (algo == 2 || algo == 6)) continue;   // split precision: one lock-step form (7) + the specialised ones
+      if (k22_is_split(dtype) && (algo == 2 || algo == 6)) continue;   // split precision: one lock-step form (7) + the specialised ones
       IgemmParams ph = p;
       ph.algo = algo;
       const int nsplit_max = (p.Kc / BK) * (algo == 3 ? 2 : 1);
@@ -200,6 +201,8 @@ inline TileKey tuned_key(const Tuned& t, int dtype) {
   const IgemmParams& p = t.p;
   // fp16 runs the same kernels on the same bytes at the same MFMA rate as bf16: one table line serves both 16-bit types
   if (dtype == K22_F16) dtype = K22_BF16;
+  // the asymmetric split runs the split-precision kernels' frames on the same bytes with two of their three MFMAs: it resolves through
+  // their lines unless a line of its own exists (tile_table_lookup tries its own key first)
   return TileKey(dtype, p.taps, p.M, p.N, p.Kc, p.K0 + (p.S0 ? 100000 * (p.SK0 + p.SK1) : 0), p.H, p.W,
                  p.out_mode + 16 * p.res_f32 + 32 * p.act + 256 * p.a_raw, t.want_stats);
 }
@@ -216,6 +219,7 @@ inline bool tile_table_lookup(const Tuned& t, int dtype, Cfg* out, float* us) {
   TileTable& tt = tile_table();
   std::lock_guard<std::mutex> lk(tt.mu);
   auto it = tt.m.find(tuned_key(t, dtype));
+  if ((it == tt.m.end() || !tuned_is_candidate(t, it->second.first)) && dtype == K22_F16X2) it = tt.m.find(tuned_key(t, K22_F16X3));
   if (it == tt.m.end() || !tuned_is_candidate(t, it->second.first)) return false;
   *out = it->second.first;
   if (us) *us = it->second.second * 1e3f;
@@ -265,7 +269,7 @@ inline int tuned_max_rpi(const Tuned& t, int dtype, bool autotune) {
 // Measures every candidate of every distinct problem that the tile table does not know yet (outputs written meanwhile are
 // garbage; the caller runs the real forward afterwards).  flush / flush_bytes: a scratch region memset between runs to
 // evict the Infinity Cache.  Problems already resolved from the table (Tuned::from_table) are left alone.
-inline int tune_igemm_ops(std::deque<Tuned>& tuned, int dtype, void* flush, size_t flush_bytes, hipStream_t st) {
+inline int tune_igemm_ops(std::deque<Tuned>& tuned, int engine_dtype, void* flush, size_t flush_bytes, hipStream_t st) {
   tile_table_load_env_once();
   TileTable& tt = tile_table();
   hipEvent_t e0, e1;
@@ -276,6 +280,7 @@ inline int tune_igemm_ops(std::deque<Tuned>& tuned, int dtype, void* flush, size
     if (!t.run || t.cands.size() < 2) continue;
     const IgemmParams& p = t.p;
     if (p.M < 64) continue;
+    const int dtype = t.dt >= 0 ? t.dt : engine_dtype;
     Cfg hit; float hit_us = 0.f;
     if (tile_table_lookup(t, dtype, &hit, &hit_us)) {
       t.cfg = hit; t.best_us = hit_us; t.from_table = true;

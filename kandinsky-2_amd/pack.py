@@ -61,7 +61,7 @@ def packed_entries(arch: UNetArch, sd: Dict[str, torch.Tensor], tdtype, device) 
     def get(name):
         return sd[name].detach().to(device=device, dtype=f32)
 
-    x3 = tdtype == "f16x3"   # split-precision engine: MFMA weights in x3 chunks, everything else fp32
+    x3 = tdtype in ("f16x3", "f16x2")   # split-precision engines: MFMA weights in x3 chunks, everything else fp32
     vdtype = f32 if x3 else tdtype   # weights read by the vector (non-MFMA) kernels
 
     def cast(w):

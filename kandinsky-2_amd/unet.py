@@ -43,8 +43,9 @@ class Text2ImUNetHIP(nn.Module):
     def __init__(self, arch: UNetArch, backend_dtype: torch.dtype = torch.bfloat16, use_graph: bool = True,
                  cache_text_emb: bool = True, meta_params: bool = False):
         super().__init__()
-        if backend_dtype not in (torch.bfloat16, torch.float16, torch.float32, _lib.F16X3):
-            raise ValueError('backend_dtype must be torch.bfloat16, torch.float16, torch.float32 or "f16x3" (split precision)')
+        if backend_dtype not in (torch.bfloat16, torch.float16, torch.float32, _lib.F16X3, _lib.F16X2):
+            raise ValueError('backend_dtype must be torch.bfloat16, torch.float16, torch.float32, "f16x3" (split precision) or "f16x2" '
+                             '(asymmetric split: per-op precision plan)')
         self.arch = arch
         self.backend_dtype = backend_dtype
         self.use_graph = use_graph

@@ -83,9 +83,16 @@ class Rounder:
                 self.fn[k] = ROUNDERS[dt]
         self.kinds = set(self.fn)
 
-    def __call__(self, x, kind):
-        f = self.fn.get(kind)
-        return f(x) if f is not None else x
+    def __call__(self, x, kind, sub=""):
+        # round 5: a kind may be narrowed to a position ('g1' = in_layers conv input, 'g2' = out_layers conv input, 'gq' = qkv input,
+        # 'go' = the out head's conv input) and / or to a resolution ('g@96', 'g1@24': the tensor's width) - the per-layer precision
+        # plan of the K22_F16X2 engine is read off such runs (tests/golden/drift_ablation_x2.json)
+        res = "@%d" % x.shape[-1] if x.dim() == 4 else ""
+        for key in (kind, kind + sub, kind + res, kind + sub + res):
+            f = self.fn.get(key)
+            if f is not None:
+                return f(x)
+        return x
 
 
 W_SUFFIXES = (".in_layers.2.weight", ".out_layers.3.weight", ".skip_connection.weight", ".qkv.weight", ".proj_out.weight",
@@ -141,12 +148,12 @@ def res_block(sd, pfx, x, emb, updown, r):
         h, x = F.avg_pool2d(h, 2), r(F.avg_pool2d(x, 2), "h")
     elif updown == 2:
         h, x = F.interpolate(h, scale_factor=2, mode="nearest"), F.interpolate(x, scale_factor=2, mode="nearest")
-    h = r(h, "g")
+    h = r(h, "g", "1")
     h = r(conv3(h, sd[pfx + ".in_layers.2.weight"], sd[pfx + ".in_layers.2.bias"], r), "u")
     e = F.linear(F.silu(emb), sd[pfx + ".emb_layers.1.weight"], sd[pfx + ".emb_layers.1.bias"])[..., None, None]
     scale, shift = torch.chunk(e, 2, dim=1)
     h = gn(h, sd[pfx + ".out_layers.0.weight"], sd[pfx + ".out_layers.0.bias"], False) * (1 + scale) + shift
-    h = conv3(r(F.silu(h), "g"), sd[pfx + ".out_layers.3.weight"], sd[pfx + ".out_layers.3.bias"], r)
+    h = conv3(r(F.silu(h), "g", "2"), sd[pfx + ".out_layers.3.weight"], sd[pfx + ".out_layers.3.bias"], r)
     if (pfx + ".skip_connection.weight") in sd:   # fused into the second convolution's accumulator by the engine: no rounding
         x = F.conv2d(r(x, "s"), sd[pfx + ".skip_connection.weight"], sd[pfx + ".skip_connection.bias"])
     return r(x + h, "h")
@@ -154,7 +161,7 @@ def res_block(sd, pfx, x, emb, updown, r):
 
 def attention_block(sd, pfx, x, encoder_out, r, head_ch=64):
     b, c, hh, ww = x.shape
-    n = r(gn(x, sd[pfx + ".norm.weight"], sd[pfx + ".norm.bias"], False), "g").view(b, c, -1)
+    n = r(gn(x, sd[pfx + ".norm.weight"], sd[pfx + ".norm.bias"], False), "g", "q").view(b, c, -1)
     qkv = r(F.conv1d(n, sd[pfx + ".qkv.weight"], sd[pfx + ".qkv.bias"]), "a")
     ekv = r(F.conv1d(encoder_out, sd[pfx + ".encoder_kv.weight"], sd[pfx + ".encoder_kv.bias"]), "a")
     n_heads = c // head_ch
@@ -209,7 +216,7 @@ def unet_forward(sd, arch, x, timesteps, cond, r):
             h = torch.cat([h, hs.pop()], dim=1)
             cur = seq
         h = apply(b, h)
-    h = r(gn(h, sd["out.0.weight"], sd["out.0.bias"], True), "g")
+    h = r(gn(h, sd["out.0.weight"], sd["out.0.bias"], True), "g", "o")
     return F.conv2d(h, sd["out.2.weight"], sd["out.2.bias"], padding=1)
 
 
@@ -225,7 +232,8 @@ def run_mode(mode, sd0, arch, fx, dev):
     cond = (xf_proj, r(xf_out, "a"))
     first = unet_forward(sd, arch, torch.cat([x_T[:bs], x_T[:bs]], 0), fx["first_ts"].float().to(dev), cond, r)
     d0 = (first.cpu() - fx["first_out"]).abs().max().item()
-    rep = {"mode": mode, "first_forward_max_abs": d0, "first_forward_rel": d0 / fx["first_out"].abs().max().item()}
+    rep = {"mode": mode, "first_forward_max_abs": d0, "first_forward_rel": d0 / fx["first_out"].abs().max().item(),
+           "first_forward_rms": (first.cpu() - fx["first_out"]).pow(2).mean().sqrt().item()}
     if steps > 0 and not os.environ.get("K22_ABLATE_FIRST_ONLY"):
         d = diffusion_ref.RefDiffusion(steps)
         x = d.p_sample_loop(lambda xc, t: unet_forward(sd, arch, xc, t.to(dev), cond, r), x_T, noise_seq, fx["guidance"])
