@@ -60,6 +60,7 @@ def main(argv=None):
                          "replayed as ONE hipGraph (k22_unet_sample_loop); the loop graph needs --steps to be a multiple of --sched-steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity_paths object (fp16 / fp32 engines + final-latent distances)")
+    ap.add_argument("--parity-timed-only", action="store_true", help="parity_paths for the timed engine only (A/B runs)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end images/sec pass (prior + denoise + MoVQ + uint8)")
     ap.add_argument("--e2e-images", type=int, default=2, help="images timed by the end-to-end pass (after one untimed image)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-op HIP-event pass (roofline object = null)")
@@ -450,7 +451,7 @@ def parity_paths(m_timed, arch, sd, a, dev):
     # f16x3 = the split-precision engine (fp32 tensors, fp16 (hi, lo) operand pairs, three fp16 MFMAs per product): the path built to
     # hold the 1e-3 gate at 16-bit MFMA rate
     for name, dt in (("fp16", torch.float16), ("f16x2", k22.F16X2), ("f16x3", k22.F16X3), ("fp32", torch.float32)):
-        if name == a.dtype:
+        if name == a.dtype or a.parity_timed_only:
             continue
         mm = k22.Text2ImUNetHIP(arch, backend_dtype=dt, use_graph=not a.no_graph)
         mm.load_state_dict(sd)
@@ -516,12 +517,10 @@ def box_state(dev):
         r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp", "--json"], capture_output=True, text=True, timeout=20)
         js = json.loads(r.stdout)
         card = js.get(f"card{dev.index or 0}") or next(iter(js.values()))
-        for k_, v in card.items():
+        for k_, v in card.items():     # keys differ between rocm-smi releases: keep what names a clock, the socket power or the junction temperature
             kl = k_.lower()
-            if "sclk" in kl and "clock" in kl: out["sclk"] = v
-            elif "mclk" in kl and "clock" in kl: out["mclk"] = v
-            elif "power" in kl and "socket" in kl: out["power_w"] = v
-            elif "temperature" in kl and "junction" in kl: out["temp_junction_c"] = v
+            if any(t in kl for t in ("sclk", "mclk", "fclk", "socket", "junction")):
+                out[k_] = v
     except Exception as e:  # rocm-smi missing / other output format: the calibration number below still normalises
         out["rocm_smi"] = f"unavailable ({type(e).__name__})"
     try:

@@ -51,9 +51,7 @@ const char* k22_last_error(void);
  * 2 LDS-resident halo kernel for the 3x3 convolutions (3-7: its variants, see conv3_halo.hip; 8-9: measurement only);
  * "gemm_algo" = 0 generic implicit-GEMM kernel, 10 = 8-wave BM x 128 tile kernel where it applies;
  * "conv_algo" / "gemm_algo" = 20: the weight-streaming small-M kernel (stream_gemm.hip; bm = 160 / 288 picks 5 / 9 m-blocks
- * per workgroup, needs the fp32 partial buffer also for splitk == 1);
- * "gn_fused" = 0 (default) / 1: k22_groupnorm (the kernel-level entry below, not the engines) runs coefficients + apply as one launch
- * (gn_fused_kernel) or as gn_coeff + gn_apply. */
+ * per workgroup, needs the fp32 partial buffer also for splitk == 1). */
 int k22_set_option(const char* name, int value);
 /* Launch counters for tests ("stream_launches": launches of the weight-streaming kernel since the library was loaded);
  * -1 for an unknown name. */
@@ -242,19 +240,16 @@ int k22_conv3x3_skip(const void* x_padded, const void* Wp, const float* bias, co
 /* Same convolution (row-major T output, no activation) that also emits the per-channel partial sums the next
  * GroupNorm needs (ResBlock: conv -> GroupNorm32, unet.py:157-164/212-216), so the tensor is not re-read:
  * stats[row][c] = (sum, sum of squares) of the STORED outputs, image b owning rows [b*rpi, (b+1)*rpi);
- * *rows_per_image receives rpi.  Fails (K22_EINVAL) for configurations that cannot produce them.
- * group_sums (optional, Cout % 32 == 0): [B][32] (sum, sumsq) pairs per GroupNorm group of the OUTPUT tensor as 64-bit FIXED-POINT
- * integers (sum in units of 2^-24, sumsq in units of 2^-20), ACCUMULATED by the epilogue with integer atomics - associative, so the
- * same bits whatever order the tiles finish in (zero it before the call); k22_groupnorm_from_group_sums consumes it. */
+ * *rows_per_image receives rpi.  Fails (K22_EINVAL) for configurations that cannot produce them. */
 int k22_conv3x3_gnstats(const void* x_padded, const void* Wp, const float* bias, const void* residual, void* out,
                         void* partial, int B, int H, int W, int Cin, int Cout, int Npad, int splitk, int bm, int bn,
-                        float* stats, int stats_capacity_rows, int* rows_per_image, long long* group_sums, int dtype, void* stream);
+                        float* stats, int stats_capacity_rows, int* rows_per_image, int dtype, void* stream);
 /* Same for a 1x1 convolution over unpadded rows [B*H*W][K] (AttentionBlock proj_out, unet.py:244-268, whose output the
  * next ResBlock's GroupNorm32 normalises): out = A W^T + bias (+ residual) through the 8-wave BM x 128 GEMM kernel
  * (bm = 256 / 128 / 0 = auto), with the per-tile (sum, sum of squares) rows as above. */
 int k22_gemm_gnstats(const void* A, const void* Wp, const float* bias, const void* residual, void* out, void* partial,
                      int B, int H, int W, int N, int Npad, int K, int splitk, int bm, float* stats,
-                     int stats_capacity_rows, int* rows_per_image, long long* group_sums, int dtype, void* stream);
+                     int stats_capacity_rows, int* rows_per_image, int dtype, void* stream);
 /* Developer tool: runs the 256-row bf16 halo kernel once with s_memtime stamps; trace = device u64 [2][1024][4]
  * (wave 0 / wave 5 of workgroup 0; per tap: before the counted vmcnt wait, after it, after the barrier, after the last
  * MFMA was issued).  tools/conv_trace.py prints the per-phase cycle budget. */
@@ -269,12 +264,6 @@ int k22_debug_conv_trace(const void* x_padded, const void* Wp, const float* bias
 int k22_conv3x3_gn(const void* x0, const void* x1, int C0, int C1, const float* gamma, const float* beta, const float* film, long film_ld,
                    float eps, int act, void* scratch, const void* Wp, const float* bias, const void* residual, void* out, void* partial,
                    int B, int H, int W, int Cout, int Npad, int splitk, int bm, int algo, int dtype, void* stream);
-/* GroupNorm32 (+FiLM, +activation, +resample, +zero border as k22_groupnorm) of ONE tensor whose per-group sums are already
- * known (accumulated by the producing conv / GEMM, see above, fixed point): a single pass, no statistics or coefficient kernel.
- * C a multiple of 32, at most 3072. */
-int k22_groupnorm_from_group_sums(const void* x, int C, int B, int H, int W, const long long* group_sums, const float* gamma,
-                                  const float* beta, const float* film, long film_ld, float eps, int act, int mode, int pad,
-                                  void* out, int dtype, void* stream);
 int k22_groupnorm(const void* x0, const void* x1, int C0, int C1, int B, int H, int W, const float* gamma,
                   const float* beta, const float* film, long film_ld, float eps, int act, int mode, int pad,
                   void* scratch, void* out, int dtype, void* stream);

@@ -12,6 +12,7 @@ from .prior import (PRIOR_HPARAMS_2_1, PRIOR_DIFFUSION_2_1, PriorDiffusionModelH
                     init_prior_state_dict, tiny_prior_hparams)
 from . import prestep
 from ._lib import F16X2, F16X3
+from .tokenizer import ClipBPETokenizer
 from . import pipeline22
 from .unet22 import (DDPM_SCHEDULER_DEFAULTS, SCHEDULER_CONFIG_2_2, SCHEDULER_CONFIG_2_2_LEARNED_RANGE, UNET2D_DEFAULTS, UNET_CONFIG_2_2,
                      DDPMSchedulerHIP, UNet2DConditionHIP, init_unet22_state_dict, make_arch22, param_shapes22, resolve_unet22_config,
@@ -28,6 +29,7 @@ from .movq import (MOVQ_CONFIG_2_1, MoVQArch, MoVQDecoderHIP, MoVQEncoderHIP, mo
 __all__ = [
     "F16X3",
     "F16X2",
+    "ClipBPETokenizer",
     "MODEL_CONFIG_2_1", "DIFFUSION_CONFIG_2_1", "UNetArch", "make_arch", "param_shapes", "tiny_model_config",
     "Text2ImUNetHIP", "create_model", "SpacedDiffusionHIP", "DDIMSamplerHIP", "PLMSSamplerHIP", "create_gaussian_diffusion", "space_timesteps",
     "percentile_index", "init_unet_state_dict", "make_conditioning",

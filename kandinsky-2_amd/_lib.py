@@ -124,9 +124,8 @@ SIGNATURES = {
     "k22_x3_pack": (_I, [_P, _P, _L, _F, _P]),
     "k22_conv3x3": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "k22_conv3x3_skip": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "k22_gemm_gnstats": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, C.POINTER(_I), _P, _I, _P]),
-    "k22_groupnorm_from_group_sums": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _L, _F, _I, _I, _I, _P, _I, _P]),
-    "k22_conv3x3_gnstats": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, C.POINTER(_I), _P, _I, _P]),
+    "k22_gemm_gnstats": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, C.POINTER(_I), _I, _P]),
+    "k22_conv3x3_gnstats": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, C.POINTER(_I), _I, _P]),
     "k22_conv3x3_gn": (_I, [_P, _P, _I, _I, _P, _P, _P, _L, _F, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "k22_debug_conv_trace": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "k22_groupnorm": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _L, _F, _I, _I, _I, _P, _P, _I, _P]),

@@ -22,13 +22,11 @@ extern "C" {
 
 int k22_version(void) { return 100; }
 
-static bool g_gn_fused_test = false;
 int k22_set_option(const char* name, int value) {
   if (name && !strcmp(name, "igemm_stages")) { igemm_set_default_stages(value); return K22_OK; }
   if (name && !strcmp(name, "igemm_xcd_remap")) { igemm_set_xcd_remap(value); return K22_OK; }
   if (name && !strcmp(name, "conv_algo")) { igemm_set_conv_algo(value); return K22_OK; }
   if (name && !strcmp(name, "gemm_algo")) { igemm_set_gemm_algo(value); return K22_OK; }
-  if (name && !strcmp(name, "gn_fused")) { g_gn_fused_test = value != 0; return K22_OK; }   // k22_groupnorm (test entry) only: 0 = gn_coeff + gn_apply
   return k22_set_error(K22_EINVAL, "k22_set_option: unknown option");
 }
 const char* k22_last_error(void) { return g_err; }
@@ -175,7 +173,7 @@ int k22_conv3x3(const void* x_padded, const void* Wp, const float* bias, const v
 
 int k22_conv3x3_gnstats(const void* x_padded, const void* Wp, const float* bias, const void* residual, void* out,
                         void* partial, int B, int H, int W, int Cin, int Cout, int Npad, int splitk, int bm, int bn,
-                        float* stats, int stats_capacity_rows, int* rows_per_image, long long* group_sums, int dtype, void* stream) {
+                        float* stats, int stats_capacity_rows, int* rows_per_image, int dtype, void* stream) {
   IgemmParams p = {};
   p.stages = -1;
   p.A0 = x_padded; p.Wp = Wp; p.bias = bias; p.residual = residual; p.out = out;
@@ -188,14 +186,13 @@ int k22_conv3x3_gnstats(const void* x_padded, const void* Wp, const float* bias,
   if (rpi <= 0) return k22_set_error(K22_EINVAL, "conv3x3_gnstats: this configuration cannot produce GroupNorm partial sums");
   if (rpi * B > stats_capacity_rows) return k22_set_error(K22_ENOMEM, "conv3x3_gnstats: stats buffer too small");
   p.stats = stats;
-  p.gsum = (group_sums && p.N % 32 == 0) ? group_sums : nullptr;
   K22_DBG_FRAG(p);
   return launch_igemm(p, dtype, reinterpret_cast<hipStream_t>(stream));
 }
 
 int k22_gemm_gnstats(const void* A, const void* Wp, const float* bias, const void* residual, void* out, void* partial,
                      int B, int H, int W, int N, int Npad, int K, int splitk, int bm, float* stats,
-                     int stats_capacity_rows, int* rows_per_image, long long* group_sums, int dtype, void* stream) {
+                     int stats_capacity_rows, int* rows_per_image, int dtype, void* stream) {
   IgemmParams p = {};
   p.stages = -1;
   p.A0 = A; p.Wp = Wp; p.bias = bias; p.residual = residual; p.out = out; p.partial = reinterpret_cast<float*>(partial);
@@ -208,7 +205,6 @@ int k22_gemm_gnstats(const void* A, const void* Wp, const float* bias, const voi
   if (rpi <= 0) return k22_set_error(K22_EINVAL, "gemm_gnstats: this configuration cannot produce GroupNorm partial sums");
   if (rpi * B > stats_capacity_rows) return k22_set_error(K22_ENOMEM, "gemm_gnstats: stats buffer too small");
   p.stats = stats;
-  p.gsum = (group_sums && p.N % 32 == 0) ? group_sums : nullptr;
   K22_DBG_FRAG(p);
   return launch_igemm(p, dtype, reinterpret_cast<hipStream_t>(stream));
 }
@@ -262,7 +258,6 @@ int k22_groupnorm(const void* x0, const void* x1, int C0, int C1, int B, int H, 
   GnApplyParams ap = {};
   ap.x0 = x0; ap.x1 = x1; ap.C0 = C0; ap.C1 = C1; ap.B = B; ap.H = H; ap.W = W; ap.mode = mode; ap.pad = pad; ap.act = act;
   ap.coeff = coeff; ap.out = out; ap.out_x3 = out_x3;
-  if (!out_x3 && g_gn_fused_test && gn_fused_supported(C, C0, dtype)) return launch_gn_fused(cp, ap, dtype, st);   // coefficients + apply in one launch
   rc = launch_gn_coeff(cp, B, st);
   if (rc) return rc;
   return launch_gn_apply(ap, dtype, st);
@@ -298,17 +293,6 @@ int k22_conv3x3_gn(const void* x0, const void* x1, int C0, int C1, const float* 
   return launch_igemm(p, dtype, st);
 }
 
-int k22_groupnorm_from_group_sums(const void* x, int C, int B, int H, int W, const long long* group_sums, const float* gamma,
-                                  const float* beta, const float* film, long film_ld, float eps, int act, int mode, int pad,
-                                  void* out, int dtype, void* stream) {
-  GnApply3Params q = {};
-  GnApplyParams& ap = q.a;
-  ap.x0 = x; ap.x1 = nullptr; ap.C0 = C; ap.C1 = 0; ap.B = B; ap.H = H; ap.W = W; ap.mode = mode; ap.pad = pad; ap.act = act;
-  ap.coeff = nullptr; ap.out = out;
-  q.gsum = group_sums; q.inv_n = 1.0 / ((double)H * W * (C / 32)); q.eps = eps; q.gamma = gamma; q.beta = beta;
-  q.film = film; q.film_ld = film_ld;
-  return launch_gn_apply3(q, dtype, reinterpret_cast<hipStream_t>(stream));
-}
 
 int k22_attention(const void* qkv, const void* ctxkv, void* kall, void* vtall, void* out, int B, int H, int T, int S,
                   int dtype, void* stream) {

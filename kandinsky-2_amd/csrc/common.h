@@ -282,38 +282,6 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// ---- GroupNorm group sums, accumulated by the producer ------------------------------------------------------------
-// A conv / GEMM epilogue that knows the per-channel (sum, sumsq) of its tile (chs[nc][2] in LDS, channels c0 .. c0+nc-1
-// of image `img`) also adds them, per GroupNorm group of ITS OWN tensor (groups of C/32 channels), into
-// gsum[img][32][2] (zeroed once per forward): fixed-order fp64 sum over the group's channels inside the tile, then ONE
-// 64-bit INTEGER atomic add per (group, statistic) of that sum in fixed point (sum: 2^-24 units, sumsq: 2^-20 units).
-// Integer addition is associative, so the accumulated value does not depend on the order in which the <= ~150 tiles
-// arrive: the same bits every run (an fp64 atomic sum would differ in its last bit between runs).  Resolution: each
-// tile's contribution is rounded to 6e-8 (sum) / 1e-6 (sumsq) absolute, against group totals of >= 1728 elements;
-// range +-5.5e11 / +-8.8e12 (a GroupNorm group of 4.4e5 elements of magnitude 4e3 still fits; values are clamped).
-// A consumer GroupNorm over exactly this tensor (not a virtual concat) then needs no statistics pass and no
-// coefficient kernel: gn_apply3_kernel derives mean / rstd from the 64 integers of its image.
-// Call with all threads of the workgroup after chs[] is complete (__syncthreads() before).
-constexpr double K22_GSUM_SCALE_SUM = 16777216.0;   // 2^24
-constexpr double K22_GSUM_SCALE_SQ = 1048576.0;     // 2^20
-__device__ __forceinline__ void gn_add_group_sums(const float* chs, long long* gsum, int img, int C, int c0, int nc) {
-  const int cpg = C / 32;
-  const int g_lo = c0 / cpg, g_hi = (c0 + nc - 1) / cpg;
-  const int t = threadIdx.x, gi = t >> 1, which = t & 1;
-  if (gi <= g_hi - g_lo) {
-    const int g = g_lo + gi;
-    const int lo = (g * cpg > c0 ? g * cpg : c0) - c0;
-    const int hi = ((g + 1) * cpg < c0 + nc ? (g + 1) * cpg : c0 + nc) - c0;
-    double a = 0.0;
-    for (int c = lo; c < hi; ++c) a += (double)chs[c * 2 + which];
-    a *= which ? K22_GSUM_SCALE_SQ : K22_GSUM_SCALE_SUM;
-    a = a > 9.0e18 ? 9.0e18 : (a < -9.0e18 ? -9.0e18 : a);   // also maps NaN to a finite value (comparisons false -> a itself; cvt of NaN is 0)
-    const long long f = __double2ll_rn(a);
-    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(gsum) + ((int64_t)img * 32 + g) * 2 + which, (unsigned long long)f,
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
 // ---- vector load/store of 8 (bf16) / 4 (f32) elements = 16 bytes -----------------------
 template <typename T> struct Vec16;
 template <> struct Vec16<bf16_t> {

@@ -413,7 +413,7 @@ __device__ __forceinline__ void halo_tail(const IgemmParams& p, f32x16_t (&acc)[
     }
     if (p.out_mode == IG_OUT_ROWMAJOR) store8<T>(reinterpret_cast<T*>(p.out) + m * p.ldo + n, val);
     else store8<float>(reinterpret_cast<float*>(p.out) + m * p.ldo + n, val);
-    if (p.stats != nullptr || p.gsum != nullptr) {
+    if (p.stats != nullptr) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float sv = (p.out_mode == IG_OUT_ROWMAJOR) ? stored<T>(val[e]) : val[e];
@@ -422,7 +422,7 @@ __device__ __forceinline__ void halo_tail(const IgemmParams& p, f32x16_t (&acc)[
       }
     }
   }
-  if (!finish || (p.stats == nullptr && p.gsum == nullptr)) return;
+  if (!finish || p.stats == nullptr) return;
 
   // ---- epilogue 3: per-channel (sum, sumsq) of this tile's stored values, fixed-order reduction ---------
   __syncthreads();  // tile fully consumed
@@ -432,18 +432,12 @@ __device__ __forceinline__ void halo_tail(const IgemmParams& p, f32x16_t (&acc)[
     *reinterpret_cast<float2*>(red + ((rg * BN) + cs * 8 + e) * 2) = make_float2(ssum[e], ssq[e]);
   }
   __syncthreads();
-  float* chs = reinterpret_cast<float*>(smem + 40 * 1024);   // [BN][2], past red[RGS][BN][2] (32 KB)
   if (tid < BN * 2) {
     const int ch = tid >> 1, which = tid & 1;
     float a = 0.f;
 #pragma unroll 8
     for (int r = 0; r < RGS; ++r) a += red[((r * BN) + ch) * 2 + which];
-    if (n0 + ch < p.N && p.stats != nullptr) p.stats[((int64_t)bx * p.N + n0 + ch) * 2 + which] = a;
-    chs[tid] = a;
-  }
-  if (p.gsum != nullptr) {
-    __syncthreads();
-    gn_add_group_sums(chs, p.gsum, img, p.N, n0, (p.N - n0 < BN ? p.N - n0 : BN));
+    if (n0 + ch < p.N) p.stats[((int64_t)bx * p.N + n0 + ch) * 2 + which] = a;
   }
 }
 

@@ -29,27 +29,6 @@ struct GnApplyParams {
   int out_x3;           // fp32 launches only (the K22_F16X3 engine): write the output in x3 chunks (common.h) - what the consuming
                         // convolution / GEMM of the split-precision arithmetic reads as its A operand
 };
-// GroupNorm of a tensor whose producer accumulated its per-group sums (common.h: gn_add_group_sums): no statistics pass
-// and no coefficient kernel; every thread derives mean / rstd of its (at most two) groups from gsum and folds gamma, beta
-// and FiLM itself, then applies them to RPT rows of the same channels.
-struct GnApply3Params {
-  GnApplyParams a;                         // a.coeff unused; a.x1 / a.C1 must be null / 0 (no virtual concat)
-  const long long* gsum;                   // [B][32][2] fixed point (common.h: K22_GSUM_SCALE_*)
-  double inv_n;                            // 1 / (H*W * C/32)
-  float eps;
-  const float* gamma; const float* beta;   // [C]
-  const float* film; int64_t film_ld;      // optional [B][film_ld]: scale at +c, shift at +C+c
-};
-// GroupNorm32 from the producers' per-channel partial sums in ONE launch (gn_fused_kernel: coefficients + apply).  A workgroup owns a
-// block of CB = NG * (C/32) channels (NG whole groups: it needs only ITS groups' partial sums) and a chunk of the padded output pixels.
-struct GnFusedParams {
-  GnCoeffParams c;                          // c.coeff unused
-  GnApplyParams a;                          // a.coeff unused
-  int NG, CB, P, chunk_px;                  // groups / channels per block, pixel chunks per image, padded output pixels per chunk
-  int xcd_remap;
-};
-bool gn_fused_supported(int C, int C0, int dtype);
-int launch_gn_fused(const GnCoeffParams& c, const GnApplyParams& a, int dtype, hipStream_t s);
 struct ConvInParams {
   const float* x; const float* img; const float* mask;  // NCHW fp32; img/mask only for Cin == 9
   const float* w; const float* bias;                    // [Cin*3*3][Cout] (pack.py transposes the reference's [Cout][Cin][3][3]), [Cout] fp32
@@ -112,8 +91,6 @@ int gn_nsplit(int B, int HW);
 int launch_gn_stats(const GnStatsParams& p, int dtype, hipStream_t s);
 int launch_gn_coeff(const GnCoeffParams& p, int B, hipStream_t s);
 int launch_gn_apply(const GnApplyParams& p, int dtype, hipStream_t s);
-bool gn_apply3_supported(int C, int dtype);
-int launch_gn_apply3(const GnApply3Params& p, int dtype, hipStream_t s);
 int launch_resample(const void* x, void* y, int B, int H, int W, int C, int mode, int dtype, hipStream_t s);
 int launch_conv_in(const ConvInParams& p, int dtype, hipStream_t s);
 int launch_timestep_embedding(const float* t, const float* freqs, float* out, int B, int half, hipStream_t s);

@@ -254,328 +254,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyParams p) {
   *reinterpret_cast<decltype(o.raw)*>(out) = o.raw;
 }
 
-// ---- GroupNorm32 (+FiLM, +act, +resample, +zero border) straight from the producer's group sums -------------------
-// One launch instead of gn_coeff + gn_apply.  A workgroup owns 256 * IPT consecutive 16-byte items (item = padded output x position *
-// channel vector) of ONE padded output row of one image:
-//   1. its activation loads are issued first (IPT per thread, all in flight together);
-//   2. while they fly, 32 threads turn the image's 32 (sum, sumsq) fixed-point group sums into mean / rstd (fp64: the cancellation in
-//      E[x^2] - mean^2 and the square root), and all 256 threads fold gamma / beta / FiLM into y = x * A[c] + Bc[c] for every channel,
-//      written to the LDS as [EPV / 2 planes][C / EPV vectors] float4 = (A[c], Bc[c], A[c+1], Bc[c+1]): consecutive lanes read
-//      consecutive 16 bytes of a plane (conflict-free), 4 reads per item instead of the 64 bytes of coefficients per item that
-//      gn_apply pulls through the L1;
-//   3. apply, round once, store.
-// The round-2 form of this kernel derived the coefficients in every thread (2 group sums, 4 x 32 bytes of gamma / beta / FiLM per
-// 64 bytes of output) and lost to the two-kernel path; here that work is C scalar loads per workgroup.
-// POOL (mode 1, 2x2 average after the activation: the three downsampling ResBlocks) reads four input vectors per item.
-template <typename T, bool POOL>
-__global__ __launch_bounds__(256) void gn_apply3_kernel(GnApply3Params q) {
-  extern __shared__ __attribute__((aligned(16))) float gn3_smem[];
-  __shared__ float ms[64];
-  constexpr int EPV = Vec16<T>::N;
-  constexpr int NPL = EPV / 2;
-  constexpr int IPT = POOL ? 1 : 4;
-  constexpr int NV = POOL ? 4 : 1;
-  const GnApplyParams& p = q.a;
-  const int C = p.C0, CV = C / EPV, cpg = C / 32;
-  const int Ho = p.mode == 1 ? p.H / 2 : (p.mode == 2 ? p.H * 2 : p.H);
-  const int Wo = p.mode == 1 ? p.W / 2 : (p.mode == 2 ? p.W * 2 : p.W);
-  const int pad = p.pad, Hp = Ho + 2 * pad, Wp = Wo + 2 * pad;
-  const int tid = threadIdx.x, b = blockIdx.z, yp = blockIdx.y, yo = yp - pad;
-  const int n_items = Wp * CV;
-  const int base = blockIdx.x * (256 * IPT) + tid;
-  const T* src = reinterpret_cast<const T*>(p.x0);
-  const bool y_in = yo >= 0 && yo < Ho;
-
-  Vec16<T> v[IPT][NV];
-  int cvs[IPT];
-  bool inside[IPT];
-#pragma unroll
-  for (int i = 0; i < IPT; ++i) {
-    const int idx = base + i * 256;
-    const int xp = idx / CV, cv = idx - xp * CV, xo = xp - pad;
-    cvs[i] = cv;
-    inside[i] = idx < n_items && y_in && xo >= 0 && xo < Wo;
-    if (inside[i]) {
-      const int c = cv * EPV;
-      if constexpr (POOL) {
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < 2; ++dx)
-            v[i][dy * 2 + dx].raw = *reinterpret_cast<const decltype(v[0][0].raw)*>(src + ((int64_t)(b * p.H + 2 * yo + dy) * p.W + 2 * xo + dx) * C + c);
-      } else {
-        const int yi = p.mode == 2 ? yo >> 1 : yo, xi = p.mode == 2 ? xo >> 1 : xo;
-        v[i][0].raw = *reinterpret_cast<const decltype(v[0][0].raw)*>(src + ((int64_t)(b * p.H + yi) * p.W + xi) * C + c);
-      }
-    }
-  }
-  if (!y_in) {   // a border row: zeros only, no coefficients (uniform over the workgroup)
-#pragma unroll
-    for (int i = 0; i < IPT; ++i) {
-      const int idx = base + i * 256;
-      if (idx < n_items) {
-        Vec16<T> o;
-#pragma unroll
-        for (int k = 0; k < NPL; ++k) o.set2(k, 0.f, 0.f);
-        *reinterpret_cast<decltype(o.raw)*>(reinterpret_cast<T*>(p.out) + ((int64_t)b * Hp + yp) * Wp * C + (int64_t)idx * EPV) = o.raw;
-      }
-    }
-    return;
-  }
-  if (tid < 32) {
-    const long long s = q.gsum[((int64_t)b * 32 + tid) * 2], ss = q.gsum[((int64_t)b * 32 + tid) * 2 + 1];
-    const double mean = (double)s * (1.0 / K22_GSUM_SCALE_SUM) * q.inv_n;
-    double var = (double)ss * (1.0 / K22_GSUM_SCALE_SQ) * q.inv_n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    ms[tid] = (float)mean;
-    ms[32 + tid] = (float)(1.0 / sqrt(var + (double)q.eps));
-  }
-  // gamma / beta / FiLM do not depend on the statistics: in flight across the barrier
-  constexpr int CPT = 12;                     // channels per thread: C <= 3072
-  float pg[CPT], pb[CPT], psc[CPT], psh[CPT];
-#pragma unroll
-  for (int j = 0; j < CPT; ++j) {
-    const int c = tid + 256 * j;
-    pg[j] = 0.f; pb[j] = 0.f; psc[j] = 1.f; psh[j] = 0.f;
-    if (c < C) {
-      pg[j] = q.gamma[c]; pb[j] = q.beta[c];
-      if (q.film != nullptr) {
-        psc[j] = 1.f + q.film[(int64_t)b * q.film_ld + c];
-        psh[j] = q.film[(int64_t)b * q.film_ld + C + c];
-      }
-    }
-  }
-  __syncthreads();
-  float2* coef2 = reinterpret_cast<float2*>(gn3_smem);
-#pragma unroll
-  for (int j = 0; j < CPT; ++j) {
-    const int c = tid + 256 * j;
-    if (c < C) {
-      const int g = c / cpg;
-      float A = ms[32 + g] * pg[j];
-      float Bc = pb[j] - ms[g] * A;
-      if (q.film != nullptr) {
-        A *= psc[j];
-        Bc = Bc * psc[j] + psh[j];
-      }
-      const int cv = c / EPV, e = c - cv * EPV;
-      coef2[((e >> 1) * CV + cv) * 2 + (e & 1)] = make_float2(A, Bc);
-    }
-  }
-  __syncthreads();
-  const float4* coef4 = reinterpret_cast<const float4*>(gn3_smem);
-#pragma unroll
-  for (int i = 0; i < IPT; ++i) {
-    const int idx = base + i * 256;
-    if (idx >= n_items) break;
-    Vec16<T> o;
-    if (!inside[i]) {
-#pragma unroll
-      for (int k = 0; k < NPL; ++k) o.set2(k, 0.f, 0.f);
-    } else {
-      float A[EPV], Bc[EPV];
-#pragma unroll
-      for (int k = 0; k < NPL; ++k) {
-        const float4 t = coef4[k * CV + cvs[i]];
-        A[2 * k] = t.x; Bc[2 * k] = t.y; A[2 * k + 1] = t.z; Bc[2 * k + 1] = t.w;
-      }
-      float rr[EPV];
-      if constexpr (POOL) {
-#pragma unroll
-        for (int k = 0; k < EPV; ++k) {
-          float acc = 0.f;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) acc += apply_act(v[i][u].get(k) * A[k] + Bc[k], p.act);
-          rr[k] = acc * 0.25f;
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < EPV; ++k) rr[k] = apply_act(v[i][0].get(k) * A[k] + Bc[k], p.act);
-      }
-#pragma unroll
-      for (int k = 0; k < NPL; ++k) o.set2(k, rr[2 * k], rr[2 * k + 1]);
-    }
-    *reinterpret_cast<decltype(o.raw)*>(reinterpret_cast<T*>(p.out) + ((int64_t)b * Hp + yp) * Wp * C + (int64_t)idx * EPV) = o.raw;
-  }
-}
-
-// ---- GroupNorm32 in ONE launch from the producers' per-channel partial sums: coefficients + apply --------------------------
-// gn_coeff + gn_apply were two dependent launches of ~5 us each for tensors that move in 1-5 us (95 GroupNorms per forward: 0.45 ms of
-// launch floor).  A row-oriented apply kernel cannot fold the coefficients itself: every workgroup would need the partial sums of ALL
-// groups (rpi x C x 8 bytes: 110 KB at 96x96).  Here the work is cut the other way:
-//   * a workgroup owns CB = NG x (C/32) channels - NG whole groups (1, 2 or 4; CB x esz = 48..192 bytes contiguous per pixel) - and a
-//     chunk of the padded output pixels of one image.  It needs only ITS groups' partial sums (rpi x CB x 8 bytes: 3-14 KB), which
-//     4/NG waves per group add in a fixed strided order (fp64), shuffle + LDS reduction in a fixed order: every workgroup of a channel
-//     block derives bit-identical coefficients, run to run (no atomics anywhere);
-//   * EVERY global load of a workgroup is issued before anything is waited for: its activations (8 pixels per lane = the whole chunk), gamma /
-//     beta / FiLM, 8 partial sums per thread - one memory round trip, then the reduction, two barriers, FMA + SiLU, store;
-//   * thread (pixel lane, vector) keeps its 8 (A, Bc) pairs in registers.
-// Workgroups that share pixels (the C/CB channel blocks of a chunk) are consecutive in the XCD-local order, so the 128-byte lines they
-// share are fetched into one L2.  Modes / border / virtual concat as gn_apply_kernel.
-template <typename T, bool POOL>
-__global__ __launch_bounds__(256) void gn_fused_kernel(GnFusedParams q) {
-  constexpr int EPV = Vec16<T>::N;
-  constexpr int NV = POOL ? 4 : 1;
-  constexpr int U = POOL ? 2 : 8;              // pixels per lane: the host sizes the chunks so that ONE batch of loads covers a chunk
-  __shared__ double red[4][2];
-  __shared__ float ms[4][2];
-  __shared__ float2 coef[192];                 // CB <= 192 (host check)
-  const GnCoeffParams& cp = q.c;
-  const GnApplyParams& p = q.a;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int C = p.C0 + p.C1, cg = C / 32, CB = q.CB, NCB = C / CB;
-  int L = blockIdx.x;
-  if (q.xcd_remap) {
-    const int nb = gridDim.x, qq = nb >> 3, r = nb & 7, x = L & 7;
-    L = (x < r ? x * (qq + 1) : r * (qq + 1) + (x - r) * qq) + (L >> 3);
-  }
-  const int cb = L % NCB;
-  const int chunk = (L / NCB) % q.P, b = L / (NCB * q.P);
-  const int c0 = cb * CB;
-
-  // ---- 1. every global load of the workgroup goes out first: activations, affine / FiLM operands, the first 8 partial sums per thread --------
-  const int VPB = CB / EPV, PPI = 256 / VPB;
-  const int pl = tid / VPB, vv = tid - pl * VPB;
-  const bool active = pl < PPI;
-  const int Ho = p.mode == 1 ? p.H / 2 : (p.mode == 2 ? p.H * 2 : p.H);
-  const int Wo = p.mode == 1 ? p.W / 2 : (p.mode == 2 ? p.W * 2 : p.W);
-  const int pad = p.pad, Hp = Ho + 2 * pad, Wp = Wo + 2 * pad;
-  const int npx = Hp * Wp;
-  const int px0 = chunk * q.chunk_px, px1 = min(npx, px0 + q.chunk_px);
-  const int c = c0 + vv * EPV;
-  const T* src; int cs, ld;
-  if (c < p.C0) { src = reinterpret_cast<const T*>(p.x0); cs = c; ld = p.C0; }
-  else { src = reinterpret_cast<const T*>(p.x1); cs = c - p.C0; ld = p.C1; }
-  Vec16<T> v[U][NV];
-  bool inside[U];
-  auto issue = [&](int pp0) __attribute__((always_inline)) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int pp = pp0 + u * PPI;
-      const int yp = pp / Wp, xp = pp - yp * Wp, yo = yp - pad, xo = xp - pad;
-      inside[u] = active && pp < px1 && yo >= 0 && yo < Ho && xo >= 0 && xo < Wo;
-      if (inside[u]) {
-        if constexpr (POOL) {
-#pragma unroll
-          for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx)
-              v[u][dy * 2 + dx].raw = *reinterpret_cast<const decltype(v[0][0].raw)*>(src + ((int64_t)(b * p.H + 2 * yo + dy) * p.W + 2 * xo + dx) * ld + cs);
-        } else {
-          const int yi = p.mode == 2 ? yo >> 1 : yo, xi = p.mode == 2 ? xo >> 1 : xo;
-          v[u][0].raw = *reinterpret_cast<const decltype(v[0][0].raw)*>(src + ((int64_t)(b * p.H + yi) * p.W + xi) * ld + cs);
-        }
-      }
-    }
-  };
-  int pp0 = px0 + pl;
-  issue(pp0);
-  float pg = 0.f, pb = 0.f, psc = 1.f, psh = 0.f;
-  if (tid < CB) {
-    const int cc = c0 + tid;
-    pg = cp.gamma[cc]; pb = cp.beta[cc];
-    if (cp.film != nullptr) {
-      psc = 1.f + cp.film[(int64_t)b * cp.film_ld + cc];
-      psh = cp.film[(int64_t)b * cp.film_ld + C + cc];
-    }
-  }
-  // ---- 2. partial sums of the NG groups: 4/NG waves per group, 8 loads in flight per thread ---------------------------------------
-  const int wpg = 4 / q.NG, gi = wave / wpg, nthr = wpg * 64, tloc = tid - gi * nthr;
-  const int g = cb * q.NG + gi;
-  double s = 0.0, sq = 0.0;
-  {
-    int off = 0;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const GnSrc sr = cp.src[k];
-      if (sr.C > 0) {
-        const int c_lo = max(g * cg, off), c_hi = min((g + 1) * cg, off + sr.C);
-        const int nc = c_hi - c_lo;
-        if (nc > 0) {
-          const float* base = sr.st + ((int64_t)b * sr.rpi * sr.C + (c_lo - off)) * 2;
-          const int items = sr.rpi * nc;
-          for (int i = tloc; i < items; i += 8 * nthr) {
-            float2 t[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              const int ii = i + nthr * u;
-              const int ic = ii < items ? ii : i;           // clamped: the duplicate is not added
-              const int r = ic / nc, cc = ic - r * nc;
-              t[u] = *reinterpret_cast<const float2*>(base + ((int64_t)r * sr.C + cc) * 2);
-              if (ii >= items) t[u] = make_float2(0.f, 0.f);
-            }
-            s += (((double)t[0].x + (double)t[1].x) + ((double)t[2].x + (double)t[3].x)) + (((double)t[4].x + (double)t[5].x) + ((double)t[6].x + (double)t[7].x));
-            sq += (((double)t[0].y + (double)t[1].y) + ((double)t[2].y + (double)t[3].y)) + (((double)t[4].y + (double)t[5].y) + ((double)t[6].y + (double)t[7].y));
-          }
-        }
-      }
-      off += sr.C;
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    s += __shfl_xor(s, o, 64);
-    sq += __shfl_xor(sq, o, 64);
-  }
-  if (lane == 0) { red[wave][0] = s; red[wave][1] = sq; }
-  __syncthreads();
-  if (tid < CB) {   // every thread of a channel derives its group's mean / rstd itself (same operands, same order: same bits) - one barrier less
-    const int gl = tid / cg;
-    double st = 0.0, qt = 0.0;
-    for (int w = 0; w < wpg; ++w) { st += red[gl * wpg + w][0]; qt += red[gl * wpg + w][1]; }   // fixed order
-    const double inv_n = 1.0 / ((double)cp.HW * (double)cg);
-    const double mean = st * inv_n;
-    double var = qt * inv_n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)cp.eps));
-    float A = rstd * pg;
-    float Bc = pb - (float)mean * A;
-    if (cp.film != nullptr) {
-      A *= psc;
-      Bc = Bc * psc + psh;
-    }
-    coef[tid] = make_float2(A, Bc);
-  }
-  __syncthreads();
-  float A[EPV], Bc[EPV];
-#pragma unroll
-  for (int k = 0; k < EPV; ++k) {
-    const float2 t = coef[active ? vv * EPV + k : 0];
-    A[k] = t.x; Bc[k] = t.y;
-  }
-  T* out = reinterpret_cast<T*>(p.out) + (int64_t)b * npx * C + c;
-  for (; pp0 < px1; pp0 += U * PPI) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int pp = pp0 + u * PPI;
-      if (!active || pp >= px1) continue;
-      Vec16<T> o;
-      if (!inside[u]) {
-#pragma unroll
-        for (int k = 0; k < EPV / 2; ++k) o.set2(k, 0.f, 0.f);
-      } else {
-        float rr[EPV];
-        if constexpr (POOL) {
-#pragma unroll
-          for (int k = 0; k < EPV; ++k) {
-            float acc = 0.f;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc += apply_act(v[u][t].get(k) * A[k] + Bc[k], p.act);
-            rr[k] = acc * 0.25f;
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < EPV; ++k) rr[k] = apply_act(v[u][0].get(k) * A[k] + Bc[k], p.act);
-        }
-#pragma unroll
-        for (int k = 0; k < EPV / 2; ++k) o.set2(k, rr[2 * k], rr[2 * k + 1]);
-      }
-      *reinterpret_cast<decltype(o.raw)*>(out + (int64_t)pp * C) = o.raw;
-    }
-    if (pp0 + U * PPI < px1) issue(pp0 + U * PPI);   // chunks longer than one batch (tensors too large for the workgroup budget)
-  }
-}
-
 // ---- raw 2x resample of the residual branch (x_upd), unpadded NHWC -> unpadded NHWC ------------
 template <typename T>
 __global__ __launch_bounds__(256) void resample_kernel(const void* xin, void* yout, int B, int H, int W, int C, int mode) {
@@ -890,72 +568,6 @@ int launch_gn_apply(const GnApplyParams& p, int dtype, hipStream_t s) {
   if (dtype == K22_BF16) hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, p);
   else if (dtype == K22_F16) hipLaunchKernelGGL(gn_apply_kernel<f16_t>, grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, p);
-  K22_CHECK_LAUNCH();
-  return K22_OK;
-}
-bool gn_apply3_supported(int C, int dtype) {
-  const int epv = dtype == K22_F32 ? 4 : 8;
-  return C % 32 == 0 && C % epv == 0 && C <= 3072;
-}
-template <typename T, bool POOL>
-static int launch_gn_apply3_t(const GnApply3Params& q, dim3 grid, size_t smem, hipStream_t s) {
-  hipLaunchKernelGGL((gn_apply3_kernel<T, POOL>), grid, dim3(256), smem, s, q);
-  K22_CHECK_LAUNCH();
-  return K22_OK;
-}
-int launch_gn_apply3(const GnApply3Params& q, int dtype, hipStream_t s) {
-  const GnApplyParams& p = q.a;
-  const int C = p.C0;
-  const int epv = dtype == K22_F32 ? 4 : 8;
-  if (p.C1 != 0 || p.x1 != nullptr || !gn_apply3_supported(C, dtype) || q.gsum == nullptr)
-    return k22_set_error(K22_EINVAL, "gn_apply3: one source tensor, C a multiple of 32 and at most 3072");
-  const int Ho = p.mode == 1 ? p.H / 2 : (p.mode == 2 ? p.H * 2 : p.H);
-  const int Wo = p.mode == 1 ? p.W / 2 : (p.mode == 2 ? p.W * 2 : p.W);
-  const int Hp = Ho + 2 * p.pad, Wp = Wo + 2 * p.pad;
-  if (Hp > 65535 || p.B > 65535) return k22_set_error(K22_EINVAL, "gn_apply3: tensor too large");
-  const bool pool = p.mode == 1;
-  const int per_wg = 256 * (pool ? 1 : 4);                   // gn_apply3_kernel::IPT
-  const dim3 grid((Wp * (C / epv) + per_wg - 1) / per_wg, Hp, p.B);
-  const size_t smem = (size_t)C * 2 * sizeof(float);
-  if (dtype == K22_BF16) return pool ? launch_gn_apply3_t<bf16_t, true>(q, grid, smem, s) : launch_gn_apply3_t<bf16_t, false>(q, grid, smem, s);
-  if (dtype == K22_F16) return pool ? launch_gn_apply3_t<f16_t, true>(q, grid, smem, s) : launch_gn_apply3_t<f16_t, false>(q, grid, smem, s);
-  return pool ? launch_gn_apply3_t<float, true>(q, grid, smem, s) : launch_gn_apply3_t<float, false>(q, grid, smem, s);
-}
-// channel block of gn_fused_kernel: NG whole groups, a multiple of the 16-byte vector, <= 96 channels when possible (else the smallest)
-static int gn_fused_ng(int C, int dtype) {
-  const int epv = dtype == K22_F32 ? 4 : 8, cg = C / 32;
-  for (int ng : {4, 2, 1}) if ((ng * cg) % epv == 0 && ng * cg <= 96) return ng;
-  for (int ng : {1, 2, 4}) if ((ng * cg) % epv == 0 && ng * cg <= 192) return ng;
-  return 0;
-}
-bool gn_fused_supported(int C, int C0, int dtype) {
-  const int epv = dtype == K22_F32 ? 4 : 8;
-  return C % 32 == 0 && C0 % epv == 0 && (C - C0) % epv == 0 && gn_fused_ng(C, dtype) != 0;
-}
-int launch_gn_fused(const GnCoeffParams& c, const GnApplyParams& a, int dtype, hipStream_t s) {
-  const int C = a.C0 + a.C1;
-  if (c.groups != 32 || c.C != C || !gn_fused_supported(C, a.C0, dtype)) return k22_set_error(K22_EINVAL, "gn_fused: unsupported channel count");
-  GnFusedParams q;
-  q.c = c; q.a = a;
-  q.NG = gn_fused_ng(C, dtype); q.CB = q.NG * (C / 32);
-  const int epv = dtype == K22_F32 ? 4 : 8;
-  const int Ho = a.mode == 1 ? a.H / 2 : (a.mode == 2 ? a.H * 2 : a.H);
-  const int Wo = a.mode == 1 ? a.W / 2 : (a.mode == 2 ? a.W * 2 : a.W);
-  const int npx = (Ho + 2 * a.pad) * (Wo + 2 * a.pad);
-  const int ncb = C / q.CB, ppi = 256 / (q.CB / epv);
-  // one batch of loads per lane covers a chunk (8 pixels, 2 in pool mode: gn_fused_kernel::U); at most ~4096 workgroups
-  const int per_chunk = (a.mode == 1 ? 2 : 8) * ppi;
-  int P = (npx + per_chunk - 1) / per_chunk;
-  const int pcap = 4096 / (a.B * ncb) > 0 ? 4096 / (a.B * ncb) : 1;
-  if (P > pcap) P = pcap;
-  q.chunk_px = (npx + P - 1) / P;
-  q.P = (npx + q.chunk_px - 1) / q.chunk_px;
-  q.xcd_remap = 1;
-  const dim3 grid(a.B * q.P * ncb);
-  const bool pool = a.mode == 1;
-  if (dtype == K22_BF16) { if (pool) hipLaunchKernelGGL((gn_fused_kernel<bf16_t, true>), grid, dim3(256), 0, s, q); else hipLaunchKernelGGL((gn_fused_kernel<bf16_t, false>), grid, dim3(256), 0, s, q); }
-  else if (dtype == K22_F16) { if (pool) hipLaunchKernelGGL((gn_fused_kernel<f16_t, true>), grid, dim3(256), 0, s, q); else hipLaunchKernelGGL((gn_fused_kernel<f16_t, false>), grid, dim3(256), 0, s, q); }
-  else { if (pool) hipLaunchKernelGGL((gn_fused_kernel<float, true>), grid, dim3(256), 0, s, q); else hipLaunchKernelGGL((gn_fused_kernel<float, false>), grid, dim3(256), 0, s, q); }
   K22_CHECK_LAUNCH();
   return K22_OK;
 }

@@ -54,8 +54,6 @@ struct Act {  // unpadded NHWC activation, optionally a virtual channel concat o
   // GroupNorm partial sums delivered by the producing convolution (null = none: run gn_stats_kernel)
   const Tuned* p0 = nullptr; Slot* st0 = nullptr;
   const Tuned* p1 = nullptr; Slot* st1 = nullptr;
-  // byte offset, in the group-sum arena, of the per-group sums the producer of s0 accumulated for ITS tensor (-1 = none)
-  int64_t gs0 = -1;
   int C() const { return C0 + C1; }
 };
 
@@ -88,8 +86,6 @@ struct K22UNet {
   int fuse_gn = 0;
   struct GnLink { const Tuned* consumer = nullptr; };   // GroupNorm op -> the convolution that reads its output (set after both exist)
   std::deque<GnLink> gn_links;
-  int gn_onepass = 0;
-  int gn_fused = 0;
   // weight-streaming kernel (stream_gemm.hip) for the small-M 3x3 convolutions: fragment-major copies of their weights live in the
   // workspace (one more copy of those weights: ~1.2 GB of the 2.1 UNet in bf16), written once per bind before the first forward
   int stream_frag = 1;
@@ -120,7 +116,7 @@ struct K22UNet {
   Slot *s_temb, *s_e1, *s_emb, *s_film, *s_xfproj, *s_ctx;
   Slot *s_full, *s_pool, *s_imgemb, *s_tmpf, *s_tmpf2, *s_fullT;
   Slot *s_part, *s_coeff, *s_P1, *s_U1, *s_P2, *s_S, *s_N, *s_QKV, *s_KALL, *s_VT, *s_ATT, *s_splitk, *s_flush;
-  Slot *s_U1st, *s_gsum;
+  Slot *s_U1st;
   Slot *s_ctxf = nullptr, *s_hint = nullptr, *s_hintin = nullptr, *s_hbuf[2] = {nullptr, nullptr};
   Slot* s_h[3];
   Slot* s_hst[3];
@@ -129,11 +125,6 @@ struct K22UNet {
   int64_t film_total = 0;
 
   Slot* new_slot(size_t bytes = 0) { slots.emplace_back(); slots.back().bytes = bytes; return &slots.back(); }
-  // GroupNorm group sums of every conv / GEMM output (common.h: gn_add_group_sums): [B][32][2] doubles each, in one arena
-  // (s_gsum) that a single memset clears at the start of a forward
-  size_t gsum_bytes = 0;
-  int64_t new_gsum() { const size_t off = gsum_bytes; gsum_bytes += ((size_t)B * 32 * 16 + 255) / 256 * 256; return (int64_t)off; }
-  long long* gsum_at(int64_t off) const { return reinterpret_cast<long long*>(ws + s_gsum->off + off); }
   static void need(Slot* s, size_t bytes) { if (bytes > s->bytes) s->bytes = bytes; }
   template <typename T = char> T* ptr(const Slot* s) const { return reinterpret_cast<T*>(ws + s->off); }
 
@@ -202,22 +193,6 @@ struct K22UNet {
     const int dt = sdt;
     const int x3 = k22_is_split(dtype) ? 1 : 0;   // every GroupNorm output feeds a convolution or the qkv GEMM: written in x3 chunks
     const double gn_bytes = (double)Bn * HW * C * esz * (fused ? 1.0 : 2.0) + (double)Bn * (Ho + 2 * pad) * (Wo + 2 * pad) * C * esz;
-    if (gn_onepass && !x3 && a.s1 == nullptr && a.gs0 >= 0 && gn_apply3_supported(C, dtype)) {
-      // the producer accumulated this tensor's group sums: one kernel, no statistics / coefficient pass
-      const int64_t gs = a.gs0;
-      const double inv_n = 1.0 / ((double)HW * (double)(C / 32));
-      L.push_back(Op([=](hipStream_t st) {
-        GnApply3Params q = {};
-        GnApplyParams& ap = q.a;
-        ap.x0 = ptr(a.s0); ap.x1 = nullptr; ap.C0 = a.C0; ap.C1 = 0; ap.B = Bn; ap.H = a.H; ap.W = a.W;
-        ap.mode = mode; ap.pad = pad; ap.act = act; ap.coeff = nullptr; ap.out = ptr(dst);
-        q.gsum = gsum_at(gs); q.inv_n = inv_n; q.eps = 1e-5f; q.gamma = gamma; q.beta = beta;
-        q.film = film_off >= 0 ? ptr<float>(s_film) + film_off : nullptr; q.film_ld = film_total;
-        return launch_gn_apply3(q, dt, st);
-      }, OP_GN, 0.0, (double)Bn * HW * C * esz + (double)Bn * (Ho + 2 * pad) * (Wo + 2 * pad) * C * esz, 1));
-        return;
-    }
-    const bool one_launch = gn_fused && !x3 && link == nullptr && gn_fused_supported(C, a.C0, dtype);
     L.push_back(Op([=](hipStream_t st) {
       const void* x0 = ptr(a.s0);
       const void* x1 = a.s1 ? ptr(a.s1) : nullptr;
@@ -241,13 +216,12 @@ struct K22UNet {
       GnApplyParams ap = {};
       ap.x0 = x0; ap.x1 = x1; ap.C0 = a.C0; ap.C1 = a.C1; ap.B = Bn; ap.H = a.H; ap.W = a.W;
       ap.mode = mode; ap.pad = pad; ap.act = act; ap.coeff = ptr<float>(s_coeff); ap.out = ptr(dst); ap.out_x3 = x3;
-      if (one_launch) return launch_gn_fused(cp, ap, dt, st);   // coefficients + apply in one launch (elementwise.hip: gn_fused_kernel)
       int rc = launch_gn_coeff(cp, Bn, st);
       if (rc) return rc;
       // the consuming convolution applies the coefficients itself while it fills its LDS halo (fused GroupNorm-apply): nothing to write
       if (link != nullptr && link->consumer != nullptr && conv3_algo_fuses_gn(link->consumer->cfg.algo)) return K22_OK;
       return launch_gn_apply(ap, dt, st);
-    }, OP_GN, 0.0, gn_bytes, (fused ? 2 : 3) - (one_launch ? 1 : 0)));
+    }, OP_GN, 0.0, gn_bytes, fused ? 2 : 3));
   }
 
   static void apply_cfg(IgemmParams& q, const Cfg& c) { tuned_apply_cfg(q, c); }
@@ -268,8 +242,11 @@ struct K22UNet {
   //   3x3 convolutions one level down 6 %, two 0.7 %, three 0.08 %; qkv 0.02 %        -> two MFMAs
   //   attention operands (q, k, v, P)                                          1.5 %  -> ONE MFMA (fp16 tiles, attention_kernel<xh_t>)
   //   proj_out, encoder_kv, to_model_dim_n (small; inputs not normalised)             -> three MFMAs
-  // x2_plan: bit 0 = the top level's in_layers convolutions run x2, bit 1 = its out_layers convolutions run x2 (default 1, K22_X2_PLAN).
-  int x2_plan = 1;
+  // x2_plan: bit 0 = the top level's in_layers convolutions run x2, bit 1 = its out_layers convolutions run x2 (K22_X2_PLAN).  Default 0:
+  // measured at C2 on MI355X (profiles/r05_x2_plans.txt; same box, x3 = 59.5 steps/s at 3.6e-6): plan 0 69.4 steps/s at 2.7e-4 max-abs /
+  // 5.4e-5 rms, plan 1 71.9 at 5.3e-4 / 8.5e-5, plan 2 71.3 at 4.6e-4 / 9.3e-5, plan 3 73.9 at 5.8e-4 / 1.14e-4 - the rms values are the
+  // ablation's predictions to 4 %; the last 6 % of speed cost the margin to the 5e-4 bar.
+  int x2_plan = 0;
   enum ConvRole { CONV_IN = 0, CONV_OUT = 1, CONV_HEAD = 2 };
   int conv_dt(int role, int Hc) const {
     if (dtype != K22_F16X2) return dtype;
@@ -333,8 +310,6 @@ struct K22UNet {
     }
     need(s_splitk, max_splitk_bytes(*t));
     if (t->want_stats) need(stats, (size_t)B * max_rpi(*t) * Cout * 2 * sizeof(float));
-    const int64_t gs = (gn_onepass && t->want_stats && Cout % 32 == 0) ? new_gsum() : -1;
-    t->gsum_off = gs;
     need(dst, out_mode == IG_OUT_ROWMAJOR ? (size_t)p.M * Cout * esz : (size_t)p.M * Cout * sizeof(float));
     Slot* rs = residual ? residual->s0 : nullptr;
     const int dt = t->dt;
@@ -349,7 +324,6 @@ struct K22UNet {
         q.gn_coeff = ptr<float>(s_coeff); q.gn_x0 = ptr(ga.s0); q.gn_x1 = ga.s1 ? ptr(ga.s1) : nullptr; q.gn_C0 = ga.C0; q.gn_act = gn_act;
       }
       q.stats = t->want_stats ? ptr<float>(stats) : nullptr;
-      q.gsum = gs >= 0 ? gsum_at(gs) : nullptr;
       if (q.S0) { q.S0 = ptr(sk.s0); q.S1 = sk.s1 ? ptr(sk.s1) : nullptr; }
       q.Wfrag = wf ? ptr(wf) : nullptr; q.Wsfrag = wsf ? ptr(wsf) : nullptr;
       return launch_igemm(q, dt, st);
@@ -384,8 +358,6 @@ struct K22UNet {
     default_cfg(*t);
     need(s_splitk, max_splitk_bytes(*t));
     if (t->want_stats) need(stats, (size_t)B * max_rpi(*t) * N * 2 * sizeof(float));
-    const int64_t gs = (gn_onepass && t->want_stats && N % 32 == 0) ? new_gsum() : -1;
-    t->gsum_off = gs;
     need(dst, (size_t)M * p.ldo * esz);
     const Act a = in;
     Slot* rs = residual ? residual->s0 : nullptr;
@@ -397,7 +369,6 @@ struct K22UNet {
       q.residual = rs ? ptr(rs) : nullptr; q.out = ptr(dst); q.partial = ptr<float>(s_splitk);
       if (t->aux0) { q.kall = ptr(reinterpret_cast<Slot*>(t->aux0)); q.vtall = ptr(reinterpret_cast<Slot*>(t->aux1)); }
       q.stats = t->want_stats ? ptr<float>(stats) : nullptr;
-      q.gsum = gs >= 0 ? gsum_at(gs) : nullptr;
       return launch_igemm(q, dt, st);
     };
     L.push_back(Op([=](hipStream_t st) { return t->run(st); }, OP_GEMM, 2.0 * p.M * (double)p.N * p.Kc, 0.0, 1));
@@ -420,7 +391,7 @@ struct K22UNet {
     if (l1) l1->consumer = t1;
     // out_layers: GN * (1+scale) + shift -> SiLU -> conv3x3 (+ skip)
     Act u1; u1.s0 = s_U1; u1.C0 = Cout; u1.H = Ho; u1.W = Wo;
-    if (t1->want_stats) { u1.p0 = t1; u1.st0 = s_U1st; u1.gs0 = t1->gsum_off; }
+    if (t1->want_stats) { u1.p0 = t1; u1.st0 = s_U1st; }
     const int64_t film_off = film_cursor;
     film_cursor += 2 * Cout;
     GnLink* l2 = nullptr;
@@ -446,7 +417,7 @@ struct K22UNet {
                             &in, pfx + ".skip_connection", l2 ? &u1 : nullptr, K22_ACT_SILU);
         if (l2) l2->consumer = t2;
         Act out; out.s0 = dst; out.C0 = Cout; out.H = Ho; out.W = Wo;
-        if (t2->want_stats) { out.p0 = t2; out.st0 = dst_stats; out.gs0 = t2->gsum_off; }
+        if (t2->want_stats) { out.p0 = t2; out.st0 = dst_stats; }
         return out;
       }
       op_gemm(ops, in, B * Ho * Wo, Cout, pfx + ".skip_connection", nullptr, s_S, 0, IG_OUT_ROWMAJOR, nullptr, /*a_raw=*/true);
@@ -459,7 +430,7 @@ struct K22UNet {
                         l2 ? &u1 : nullptr, K22_ACT_SILU);
     if (l2) l2->consumer = t2;
     Act out; out.s0 = dst; out.C0 = Cout; out.H = Ho; out.W = Wo;
-    if (t2->want_stats) { out.p0 = t2; out.st0 = dst_stats; out.gs0 = t2->gsum_off; }
+    if (t2->want_stats) { out.p0 = t2; out.st0 = dst_stats; }
     return out;
   }
 
@@ -507,7 +478,7 @@ struct K22UNet {
     // proj_out + residual; its epilogue also delivers the GroupNorm partial sums the next ResBlock needs
     Tuned* tp = op_gemm(ops, a, B * T, C, pfx + ".proj_out", &in, dst, 0, IG_OUT_ROWMAJOR, dst_stats);
     Act out; out.s0 = dst; out.C0 = C; out.H = in.H; out.W = in.W;
-    if (tp->want_stats) { out.p0 = tp; out.st0 = dst_stats; out.gs0 = tp->gsum_off; }
+    if (tp->want_stats) { out.p0 = tp; out.st0 = dst_stats; }
     return out;
   }
 
@@ -524,7 +495,7 @@ struct K22UNet {
     if (nB > 8) return k22_set_error(K22_EINVAL, "unet: batch (2*bs) must be <= 8 per engine call");
     B = nB; H = nH; W = nW;
     gn_links.clear();
-    slots.clear(); ops.clear(); cond_ops.clear(); hint_ops.clear(); s_ctxkv.clear(); gsum_bytes = 0; frag_jobs.clear(); frag_done = false; n_attn = 0; err.clear();
+    slots.clear(); ops.clear(); cond_ops.clear(); hint_ops.clear(); s_ctxkv.clear(); frag_jobs.clear(); frag_done = false; n_attn = 0; err.clear();
     tuned.clear(); tuned_done = false; warmed = false;
     ws = nullptr; cond_set = false; hint_set = false;
     if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
@@ -570,7 +541,6 @@ struct K22UNet {
     s_N = new_slot(); s_QKV = new_slot(); s_KALL = new_slot(); s_VT = new_slot(); s_ATT = new_slot();
     s_splitk = new_slot(256);
     s_U1st = new_slot();
-    s_gsum = new_slot();
     s_flush = new_slot(autotune ? ((size_t)320 << 20) : 0);  // evicts the Infinity Cache between tuning runs
     for (int i = 0; i < 3; ++i) { s_h[i] = new_slot(); s_hst[i] = new_slot(); }
     int hrot = 0, hcur = 0;
@@ -685,15 +655,6 @@ struct K22UNet {
     op_conv(ops, CONV_HEAD, s_P1, H, W, ch, cfg.out_channels, "out.2", nullptr, s_out, IG_OUT_NCHW_F32);
 
     if (!err.empty()) return k22_set_error(K22_EINVAL, err.c_str());
-    // first op of every forward: clear the GroupNorm group sums the conv / GEMM epilogues accumulate into
-    need(s_gsum, gsum_bytes);
-    if (gsum_bytes) {
-      const size_t nbytes = gsum_bytes;
-      ops.insert(ops.begin(), Op([=](hipStream_t st) {
-        hipError_t e = hipMemsetAsync(ptr(s_gsum), 0, nbytes, st);
-        return e == hipSuccess ? (int)K22_OK : k22_set_error_hip(e, __FILE__, __LINE__);
-      }, OP_GN, 0.0, (double)nbytes, 1));
-    }
     // ---- lay the slots out -----------------------------------------------------------------------
     size_t off = 0;
     for (auto& s : slots) { s.off = off; off += (s.bytes + 255) / 256 * 256; }
@@ -834,16 +795,6 @@ int k22_unet_create(const K22UNetConfig* cfg, const K22Weight* weights, int n_we
   {
     const char* e = getenv("K22_AUTOTUNE");  // 0 = heuristics only (no measurement at the first forward)
     u->autotune = e ? (atoi(e) != 0) : 1;
-    // 1 = single-source GroupNorms in one pass from group sums the producer epilogue accumulates (gn_apply3_kernel).
-    // Measured on one box, same run: 117 steps/s against 120 with gn_coeff + gn_apply (GroupNorm class 1.41 vs 1.29 ms):
-    // re-deriving the coefficients in every thread costs more than the coefficient kernel it removes.  Off by default.
-    const char* gf = getenv("K22_GN_ONEPASS");
-    u->gn_onepass = gf ? (atoi(gf) != 0) : 0;
-    // 1 = GroupNorm coefficients + apply in one launch per GroupNorm (gn_fused_kernel).  Measured (profiles/r03_groupnorm_one_launch_
-    // negative.txt): 1.57 ms against 1.21 ms for gn_coeff + gn_apply on the same box - a dependent phase inside a kernel costs what a
-    // dependent launch costs here, and the large levels lose the load / store overlap of a many-workgroup apply pass.  Off by default.
-    const char* g1 = getenv("K22_GN_FUSED");
-    u->gn_fused = g1 ? (atoi(g1) != 0) : 0;
     const char* sf = getenv("K22_STREAM");   // 0 = no fragment-major weight copies, no weight-streaming kernel
     u->stream_frag = sf ? (atoi(sf) != 0) : 1;
     const char* fg = getenv("K22_FUSE_GN");   // 0 = every GroupNorm through the stand-alone gn_apply kernel
@@ -851,7 +802,7 @@ int k22_unet_create(const K22UNetConfig* cfg, const K22Weight* weights, int n_we
     const char* f = getenv("K22_FUSE_SKIP");  // 0 = 1x1 skip connections as separate GEMMs
     u->fuse_skip = f ? (atoi(f) != 0) : 1;
     const char* xp = getenv("K22_X2_PLAN");   // K22_F16X2 only: which of the top level's convolutions run with two MFMAs (K22UNet::x2_plan)
-    u->x2_plan = xp ? (atoi(xp) & 3) : 1;
+    u->x2_plan = xp ? (atoi(xp) & 3) : 0;
   }
   for (int i = 0; i < n_weights; ++i) u->w[weights[i].name] = weights[i].ptr;
   *out = u;

@@ -427,27 +427,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(const IgemmPara
       store4<float>(reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldo + n, v);
     }
   }
-  if (p.stats == nullptr && p.gsum == nullptr) return;
+  if (p.stats == nullptr) return;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     red[r][cq * 4 + e][0] = ok ? v[e] : 0.f;
     red[r][cq * 4 + e][1] = ok ? v[e] * v[e] : 0.f;
   }
   __syncthreads();
-  __shared__ float chs[64 * 2];
   if (threadIdx.x < 128) {
     const int ch = threadIdx.x >> 1, which = threadIdx.x & 1;
     float a = 0.f;
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr) a += red[rr][ch][which];
     const int nn = blockIdx.y * 64 + ch;
-    if (nn < p.N && p.stats != nullptr) p.stats[((int64_t)blockIdx.x * p.N + nn) * 2 + which] = a;
-    chs[threadIdx.x] = a;
-  }
-  if (p.gsum != nullptr) {
-    __syncthreads();
-    const int c0 = blockIdx.y * 64;
-    gn_add_group_sums(chs, p.gsum, (blockIdx.x * 16) / (p.H * p.W), p.N, c0, (p.N - c0 < 64 ? p.N - c0 : 64));
+    if (nn < p.N) p.stats[((int64_t)blockIdx.x * p.N + nn) * 2 + which] = a;
   }
 }
 
@@ -580,7 +573,7 @@ int igemm_choose_splitk(const IgemmParams& p, int dtype) {
 
 static bool reduce_rows_ok(const IgemmParams& p) {
   // 3x3 convolutions always finish through the row-tiled reduction; plain GEMMs only when they owe GroupNorm sums
-  const int hw = (p.taps == 9 || p.stats != nullptr || p.gsum != nullptr) ? p.H * p.W : 0;
+  const int hw = (p.taps == 9 || p.stats != nullptr) ? p.H * p.W : 0;
   return hw > 0 && hw % 16 == 0 && (p.N & 3) == 0 && (p.ldo & 3) == 0 && (p.ldr & 3) == 0 &&
          (p.out_mode == IG_OUT_ROWMAJOR || p.out_mode == IG_OUT_ROWMAJOR_F32);
 }
@@ -609,7 +602,7 @@ int igemm_stats_rows_per_image(const IgemmParams& p, int dtype) {
 
 template <typename T>
 static int launch_reduce(const IgemmParams& q, hipStream_t stream) {
-  if (q.stats != nullptr || q.gsum != nullptr || reduce_rows_ok(q)) {
+  if (q.stats != nullptr || reduce_rows_ok(q)) {
     if (!reduce_rows_ok(q)) return k22_set_error(K22_EINVAL, "igemm: GroupNorm partial sums are not available for this split-K problem");
     hipLaunchKernelGGL((splitk_reduce_rows_kernel<T>), dim3((q.M + 15) / 16, (q.N + 63) / 64), dim3(256), 0, stream, q);
     K22_CHECK_LAUNCH();
@@ -704,7 +697,7 @@ int launch_igemm(const IgemmParams& p, int dtype, hipStream_t stream) {
   if (p.gn_coeff != nullptr && !conv3_algo_fuses_gn(pl.halo))
     return k22_set_error(K22_EINVAL, "igemm: the fused GroupNorm-apply input needs the specialised halo kernel (algo 11 / 12)");
   if (p.S0 != nullptr && !pl.halo) return k22_set_error(K22_EINVAL, "igemm: the fused 1x1 skip connection needs the halo kernel");
-  if ((p.stats != nullptr || p.gsum != nullptr) && pl.splitk == 1 && !pl.halo)
+  if (p.stats != nullptr && pl.splitk == 1 && !pl.halo)
     return k22_set_error(K22_EINVAL, "igemm: GroupNorm partial sums requested from a configuration that cannot produce them");
   if (pl.halo == 10) {
     IgemmParams q = p;

@@ -71,9 +71,6 @@ struct IgemmParams {
   int res_f32;           // residual is fp32 (generic kernel / split-K finish only)
   float* stats;          // optional GroupNorm side output: per-row-block, per-channel (sum, sumsq) of the STORED
                          // values, [stats_rows][N][2] fp32 (see IgemmStatsInfo); null = not wanted
-  long long* gsum;       // optional, with or without stats: per image and per GroupNorm group of the output tensor (32 groups
-                         // of N/32 channels) the (sum, sumsq) of the STORED values, [B][32][2] fixed point, ACCUMULATED with integer
-                         // atomics (common.h: gn_add_group_sums; zero it before the launch); needs N % 32 == 0 and H, W set
   // weight-streaming kernel (stream_gemm.hip): the weights again in FRAGMENT-MAJOR order - [n-block of 32 rows][(slab, tap) item][k quarter]
   // [lane][8 elements] = 1 KB contiguous per MFMA B fragment - written once by launch_stream_repack (Wsfrag: the fused 1x1 skip's weights);
   // null = fragments are gathered from the row-major Wp / Ws (32 bytes of 32 different lines per load: measured L1-lookup bound)

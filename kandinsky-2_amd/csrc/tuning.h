@@ -90,7 +90,6 @@ struct Tuned {
   Cfg cfg;                     // current choice (heuristic until tuned)
   bool want_stats = false;     // epilogue also emits the GroupNorm partial sums of its output
   int rpi = 0;                 // stats rows per image under cfg
-  long long gsum_off = -1;     // engine-specific: offset of the output's GroupNorm group sums (-1 = none)
   float best_us = 0.f;
   bool from_table = false;     // cfg came from the tile table (shipped / cache / measured earlier in this process)
   int dt = -1;                 // arithmetic of THIS op when it differs from its engine's (a K22_F16X2 plan mixes x2 and x3 ops); -1 = the engine's
@@ -219,7 +218,9 @@ inline bool tile_table_lookup(const Tuned& t, int dtype, Cfg* out, float* us) {
   TileTable& tt = tile_table();
   std::lock_guard<std::mutex> lk(tt.mu);
   auto it = tt.m.find(tuned_key(t, dtype));
-  if ((it == tt.m.end() || !tuned_is_candidate(t, it->second.first)) && dtype == K22_F16X2) it = tt.m.find(tuned_key(t, K22_F16X3));
+  // K22_X2_OWN_LINES=1 (tools/make_tile_table.py --x2-only): no fall-back, so that the asymmetric split's own lines get measured
+  static const bool x2_own = getenv("K22_X2_OWN_LINES") && atoi(getenv("K22_X2_OWN_LINES")) != 0;
+  if ((it == tt.m.end() || !tuned_is_candidate(t, it->second.first)) && dtype == K22_F16X2 && !x2_own) it = tt.m.find(tuned_key(t, K22_F16X3));
   if (it == tt.m.end() || !tuned_is_candidate(t, it->second.first)) return false;
   *out = it->second.first;
   if (us) *us = it->second.second * 1e3f;

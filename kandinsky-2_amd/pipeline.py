@@ -419,10 +419,9 @@ class _MoVQ:
 def _conditioner_from_cache_dir(cache_dir, device, backend_dtype, tokenizer2=None):
     """The encoders Kandinsky2_1.__init__ builds (kandinsky2_1_model.py:57-66; files as kandinsky2/__init__.py:124-160 stores them):
     cache_dir/text_encoder (XLM-R tokenizer + pytorch_model.bin of MultilingualCLIP) and cache_dir/ViT-L-14.pt, on the HIP encoder
-    engine.  tokenizer2 = the CLIP byte-pair tokenizer OBJECT (what the reference builds as kandinsky2.model.prior.CustomizedTokenizer():
-    callable as tokenizer2.padded_tokens_and_mask(...)): string processing on the host is out of this package's scope, so the caller
-    hands it in - the product path imports nothing from the reference package.  Raises - never substitutes seeded noise - when a file
-    or the tokenizer is missing."""
+    engine.  tokenizer2 = the CLIP byte-pair tokenizer (what the reference builds as kandinsky2.model.prior.CustomizedTokenizer()):
+    None = the package's own ClipBPETokenizer on the merges file found in cache_dir; an object with padded_tokens_and_mask(...) overrides
+    it.  The product path imports nothing from the reference package.  Raises - never substitutes seeded noise - when a file is missing."""
     if isinstance(backend_dtype, str):
         backend_dtype = torch.float32   # the split-precision arithmetic exists in the UNet engine only
     from .encoders import CLIPModelHIP, HIPConditioner, TextEncoderHIP
@@ -434,9 +433,14 @@ def _conditioner_from_cache_dir(cache_dir, device, backend_dtype, tokenizer2=Non
     from transformers import AutoTokenizer
     tokenizer1 = AutoTokenizer.from_pretrained(te_dir)
     if tokenizer2 is None:
-        raise ValueError("get_kandinsky2(..., cache_dir=) builds the encoders itself but needs the CLIP byte-pair tokenizer object: pass "
-                         "tokenizer2=kandinsky2.model.prior.CustomizedTokenizer() (the reference's wrapper around OpenAI clip's BPE), or a "
-                         "ready conditioner=HIPConditioner(text_encoder, tokenizer1, tokenizer2, clip_model)")
+        # the package's own CLIP byte-pair tokenizer (tokenizer.py: the published algorithm of OpenAI clip's SimpleTokenizer + the
+        # reference's padded_tokens_and_mask) on the merges file the `clip` package ships; tokenizer2= stays an override
+        from .tokenizer import BPE_FILE_NAMES, ClipBPETokenizer, find_bpe_file
+        bpe = find_bpe_file(cache_dir)
+        if bpe is None:
+            raise FileNotFoundError(f"CLIP byte-pair merges not found: put one of {BPE_FILE_NAMES} (it ships inside OpenAI's `clip` package) into "
+                                    f"{cache_dir}, or pass tokenizer2= (any object with padded_tokens_and_mask(texts, text_ctx)) / a ready conditioner=")
+        tokenizer2 = ClipBPETokenizer(bpe)
     clip_sd = torch.jit.load(clip_pt, map_location="cpu").state_dict()   # the OpenAI checkpoint is a TorchScript archive (clip.load)
     clip_model = CLIPModelHIP(backend_dtype=backend_dtype)
     clip_model.load_state_dict({k: v.float() for k, v in clip_sd.items() if k in clip_model.state_dict()}, strict=True)

@@ -99,14 +99,35 @@ W_SUFFIXES = (".in_layers.2.weight", ".out_layers.3.weight", ".skip_connection.w
               ".encoder_kv.weight", ".emb_layers.1.weight")
 
 
-def round_weights(sd, r):
+def block_resolutions(arch, lat):
+    """block prefix -> the latent resolution its convolutions / attention run at (a down block's convolutions run AFTER the pooling, an
+    up block's AFTER the upsampling: unet.py:157-164)"""
+    res, out = lat, {}
+    for b in arch.blocks:
+        if b[0] == "res" and b[4] == 1:
+            res //= 2
+        elif b[0] == "res" and b[4] == 2:
+            res *= 2
+        out[b[1]] = res
+    return out
+
+
+def round_weights(sd, r, arch=None, lat=0):
+    """kind 'w' rounds every block weight; 'w@<res>' (round 5) only - or, beside a plain 'w', differently - those of the blocks whose
+    convolutions run at that latent resolution ('w:x3w/w@12:fp16' = weights split everywhere except plain fp16 at 12x12)."""
     out = {}
+    bres = block_resolutions(arch, lat) if arch is not None else {}
+    has_w = any(k == "w" or k.startswith("w@") for k in r.kinds)
     for k, v in sd.items():
         if "wino" in r.kinds and k.endswith((".in_layers.2.weight", ".out_layers.3.weight")):
             out[k] = v                       # transformed in fp32 first, rounded after (conv3)
-        elif "w" in r.kinds and (k.endswith(W_SUFFIXES) or k == "to_model_dim_n.weight") and k.split(".")[0] in (
+        elif has_w and (k.endswith(W_SUFFIXES) or k == "to_model_dim_n.weight") and k.split(".")[0] in (
                 "input_blocks", "middle_block", "output_blocks", "to_model_dim_n"):
-            out[k] = r(v, "w")
+            parts = k.split(".")
+            pfx = next((".".join(parts[:n]) for n in (3, 2) if ".".join(parts[:n]) in bres), None)
+            f = r.fn.get("w@%d" % bres[pfx]) if pfx is not None else None
+            f = f or r.fn.get("w")
+            out[k] = f(v) if f is not None else v
         else:
             out[k] = v
     return out
@@ -222,8 +243,8 @@ def unet_forward(sd, arch, x, timesteps, cond, r):
 
 def run_mode(mode, sd0, arch, fx, dev):
     r = Rounder(mode)
-    sd = round_weights(sd0, r)
     B, lat, steps, bs = fx["B"], fx["lat"], fx["steps"], fx["bs"]
+    sd = round_weights(sd0, r, arch, lat)
     full, pooled, image = [t.to(dev) for t in k22.make_conditioning(arch, B, seed=2)]
     g = torch.Generator().manual_seed(42)
     x_T = torch.randn(B, 4, lat, lat, generator=g).to(dev)

@@ -495,6 +495,9 @@ BIG_CASES = {
     "c4": lambda: big_case("c4_inpaint", True, bs=4, lat=96, steps=50, keep=(1, 10, 25)),
     # configs[2] (C3) per-GPU shape: 1024x1024, 4 images per GPU -> one forward of the CFG batch [8,4,128,128]
     "c3": lambda: run_case("c3_forward", k22.MODEL_CONFIG_2_1, False, B=8, h=128, w=128, steps=0, compact=True),
+    # round 5: a 10-STEP LOOP at the C3 per-GPU shape (1024x1024, 4 images per GPU -> CFG batch [8,4,128,128]) - the
+    # sampler / dynamic-threshold path at 65 536 values per image (gaussian_diffusion.py:284-294) pinned at loop level; ~25 min on 8 cores
+    "c3loop": lambda: big_case("c3_loop", False, bs=4, lat=128, steps=10, keep=(1, 5)),
     # the production prior (2048 wide x 20 layers, K = 8192 MLP): transformer forward + a 5-step sample, bs = 2
     "prior": lambda: prior_case("prior_full", k22.PRIOR_HPARAMS_2_1, bs=2, steps=5),
     # MoVQ at real sizes: 32x32 latents (256x256 px, attention over T = 1024) and C2's 96x96 (768x768 px, T = 9216)

@@ -80,15 +80,10 @@ def _conv3x3(x, w, bias, residual, dtype, splitk, bm, bn, out_mode, stats):
         cap = B * (H * (W_ + 2) // 16 + 2)
         sbuf = torch.full((cap, Cout, 2), float("nan"), dtype=torch.float32, device=x.device)
         rpi = C.c_int(0)
-        gsum = torch.zeros(B, 32, 2, dtype=torch.int64, device=x.device)
         _lib.check(_lib.lib().k22_conv3x3_gnstats(
             xp.data_ptr(), wp.data_ptr(), _lib.ptr(bias), _lib.ptr(res), out.data_ptr(), partial.data_ptr(),
-            B, H, W_, Cin, Cout, wp.shape[0], splitk, bm, bn, sbuf.data_ptr(), cap, C.byref(rpi), gsum.data_ptr(), dtype, stream()))
+            B, H, W_, Cin, Cout, wp.shape[0], splitk, bm, bn, sbuf.data_ptr(), cap, C.byref(rpi), dtype, stream()))
         st = sbuf[: B * rpi.value].view(B, rpi.value, Cout, 2).double().sum(1)  # [B, Cout, 2]
-        if Cout % 32 == 0:
-            # per-group sums accumulated by the epilogue (fixed-point integer atomics) == the per-channel rows summed by group
-            want = st.view(B, 32, Cout // 32, 2).sum(2)
-            assert (gsum_to_double(gsum) - want).abs().max().item() <= 1e-6 * (want.abs().max().item() + 1.0) + 1e-4, "group sums"
     else:
         _lib.check(_lib.lib().k22_conv3x3(
             xp.data_ptr(), wp.data_ptr(), _lib.ptr(bias), _lib.ptr(res), out.data_ptr(), partial.data_ptr(),
@@ -153,15 +148,3 @@ def attention(qkv, ctxkv, B, H, T_, S, dtype=_lib.K22_BF16):
     w = torch.softmax((q @ k.transpose(-1, -2)) * 0.125, dim=-1)
     ref = (w @ v).permute(0, 2, 1, 3).reshape(B * T_, C)
     return out.float(), ref
-
-
-GSUM_SCALE = (2.0 ** 24, 2.0 ** 20)   # csrc/common.h: K22_GSUM_SCALE_SUM / _SQ
-
-
-def gsum_to_double(g):
-    """[B, 32, 2] fixed-point group sums (int64) -> doubles."""
-    return torch.stack([g[..., 0].double() / GSUM_SCALE[0], g[..., 1].double() / GSUM_SCALE[1]], -1)
-
-
-def gsum_from_double(g):
-    return torch.stack([(g[..., 0] * GSUM_SCALE[0]).round().long(), (g[..., 1] * GSUM_SCALE[1]).round().long()], -1).contiguous()

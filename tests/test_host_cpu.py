@@ -609,3 +609,77 @@ def test_shipped_tile_table_covers_the_split_precision_engine():
     # the C2 shapes: 3x3 convolutions at 96 / 48 / 24 / 12 pixels, batch 2
     c2 = {(int(r[6]), int(r[7])) for r in x3 if int(r[1]) == 9 and int(r[2]) == 2 * int(r[6]) * int(r[7])}
     assert {(96, 96), (48, 48), (24, 24), (12, 12)} <= c2
+
+
+# ---- CLIP byte-pair tokenizer (round 5, ADVICE r4: the package goes prompt -> image on its own) -----------------------------------------
+def _train_merges(corpus, n):
+    """a small byte-pair merge list in the format of bpe_simple_vocab_16e6.txt (what OpenAI's tokenizer reads): greedy most-frequent pair"""
+    from collections import Counter
+    from kandinsky2_amd.tokenizer import bytes_to_unicode
+    b2u = bytes_to_unicode()
+    words = Counter()
+    for w in corpus.lower().split():
+        sym = [b2u[b] for b in w.encode("utf-8")]
+        sym[-1] += "</w>"
+        words[tuple(sym)] += 1
+    merges = []
+    for _ in range(n):
+        pairs = Counter()
+        for w, c in words.items():
+            for a, b in zip(w[:-1], w[1:]):
+                pairs[(a, b)] += c
+        if not pairs:
+            break
+        best = max(sorted(pairs), key=lambda p: pairs[p])
+        merges.append(best)
+        new = Counter()
+        for w, c in words.items():
+            out, i = [], 0
+            while i < len(w):
+                if i + 1 < len(w) and (w[i], w[i + 1]) == best:
+                    out.append(w[i] + w[i + 1]); i += 2
+                else:
+                    out.append(w[i]); i += 1
+            new[tuple(out)] += c
+        words = new
+    return merges
+
+
+def test_clip_bpe_tokenizer_equals_the_transformers_implementation(tmp_path):
+    """kandinsky2_amd.tokenizer.ClipBPETokenizer restates OpenAI clip's SimpleTokenizer (an un-vendored dependency of the reference,
+    prior.py:10-12, 387-416).  transformers' CLIPTokenizer is an independent implementation of the same algorithm: both are given the
+    same generated merges list and must produce the same ids; padded_tokens_and_mask follows the reference's wrapper."""
+    import gzip
+    import json
+    from kandinsky2_amd.tokenizer import ClipBPETokenizer, _byte_symbols
+    corpus = ("a red cat sitting on the green grass near the old house , photo in 4k resolution . the cat's whiskers are long ; "
+              "don't say it's a dog ! café naïve über straße красная кошка сидит на траве 12 345 cats & dogs (best) #1 ") * 3
+    merges = _train_merges(corpus, 180)
+    bpe = tmp_path / "bpe_simple_vocab_16e6.txt.gz"
+    with gzip.open(bpe, "wb") as f:
+        f.write(("#version: 0.2\n" + "\n".join(a + " " + b for a, b in merges) + "\n").encode("utf-8"))
+    tok = ClipBPETokenizer(str(bpe))
+    assert len(tok.encoder) == 512 + len(merges) + 2 and tok.sot_token == 512 + len(merges) and tok.eot_token == tok.sot_token + 1
+    # the same vocabulary in the HF file format
+    base = _byte_symbols()
+    vocab = base + [s + "</w>" for s in base] + ["".join(m) for m in merges] + ["<|startoftext|>", "<|endoftext|>"]
+    (tmp_path / "vocab.json").write_text(json.dumps({s: i for i, s in enumerate(vocab)}), encoding="utf-8")
+    (tmp_path / "merges.txt").write_text("#version: 0.2\n" + "\n".join(a + " " + b for a, b in merges) + "\n", encoding="utf-8")
+    from transformers import CLIPTokenizer
+    hf = CLIPTokenizer(str(tmp_path / "vocab.json"), str(tmp_path / "merges.txt"))
+    prompts = ["a red cat, 4k photo", "The CAT's whiskers   are long;  don't say it's a dog!", "green grass near the old house.", "café naïve über straße",
+               "красная кошка сидит на траве", "12 345 cats & dogs (best) #1", "", "unseenword xyzzy", "tabs\tand\nnewlines"]
+    for ptxt in prompts:
+        want = hf(ptxt, add_special_tokens=False)["input_ids"]
+        assert tok.encode(ptxt) == want, ptxt
+        assert tok.encode(tok.decode(tok.encode(ptxt))) == want      # decode separates the word-final symbols by spaces, as OpenAI's does
+    # html entities are unescaped (twice) before anything else, as OpenAI's basic_clean does (transformers' fallback cleaner does not)
+    assert tok.encode("cats &amp;amp; dogs") == tok.encode("cats & dogs")
+    # the plain-text merges.txt form reads the same
+    assert ClipBPETokenizer(str(tmp_path / "merges.txt")).encode(prompts[1]) == tok.encode(prompts[1])
+    # padded_tokens_and_mask: prior.py:394-416
+    ids, mask = tok.padded_tokens_and_mask(["a red cat", " ".join(["cat"] * 100)], 77)
+    assert ids.dtype == torch.int and ids.shape == (2, 77) and mask.dtype == torch.bool
+    n0 = 2 + len(tok.encode("a red cat"))
+    assert ids[0, 0] == tok.sot_token and ids[0, n0 - 1] == tok.eot_token and (ids[0, n0:] == 0).all() and mask[0].sum() == n0
+    assert ids[1, 0] == tok.sot_token and ids[1, 76] == tok.eot_token and mask[1].all()      # truncated: still ends in <|endoftext|>

@@ -113,7 +113,7 @@ def _conv_x3(x, w, bias, res, splitk, bm, bn, algo, out_mode=0, stats=False):
             sbuf = torch.full((cap, Cout, 2), float("nan"), device="cuda")
             rpi = C.c_int(0)
             _lib.check(_lib.lib().k22_conv3x3_gnstats(xp.data_ptr(), wp.data_ptr(), _lib.ptr(bias), _lib.ptr(r), out.data_ptr(), partial.data_ptr(),
-                                                      B, H, W_, Cin, Cout, wp.shape[0], splitk, bm, bn, sbuf.data_ptr(), cap, C.byref(rpi), None, X3,
+                                                      B, H, W_, Cin, Cout, wp.shape[0], splitk, bm, bn, sbuf.data_ptr(), cap, C.byref(rpi), X3,
                                                       hp.stream()))
             st = sbuf[: B * rpi.value].view(B, rpi.value, Cout, 2).double().sum(1)
         else:

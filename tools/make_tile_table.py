@@ -16,6 +16,11 @@ ENC_ONLY = "--encoders-only" in sys.argv     # keep the shipped table and add on
 SMALL_CONV = "--small-conv" in sys.argv      # keep the shipped table except the 16-bit 3x3 convolutions with M <= 1152 rows: re-measured here
                                              # (the weight-streaming kernel joined their candidate list)
 X3_ONLY = "--x3-only" in sys.argv           # keep the shipped table and add only the split-precision (K22_F16X3) lines
+X2_ONLY = "--x2-only" in sys.argv           # keep the shipped table and add the asymmetric split's (K22_F16X2) own lines: measured with every
+                                            # convolution of the plan at two MFMAs (K22_X2_PLAN=3) and without the fall-back to the x3 lines
+if X2_ONLY:
+    os.environ["K22_X2_OWN_LINES"] = "1"
+    os.environ["K22_X2_PLAN"] = "3"
 ADD_MISSING = "--add-missing" in sys.argv   # keep the shipped table; run every UNet shape list (all engine types): whatever problem is not in the
                                             # table yet is measured and added (round 4: the half-batch problems of the two-chain execution)
 if SMALL_CONV:
@@ -32,7 +37,7 @@ if SMALL_CONV:
                 dropped += 1
     print(f"--small-conv: {kept} table lines kept, {dropped} dropped for re-measurement")
     os.environ["K22_TILE_TABLE"] = _tmp
-elif not ENC_ONLY and not X3_ONLY and not ADD_MISSING:
+elif not ENC_ONLY and not X3_ONLY and not ADD_MISSING and not X2_ONLY:
     os.environ["K22_TILE_TABLE"] = "0"      # start empty: everything below is measured here
 os.environ.setdefault("K22_TUNE_REPS", "7")
 os.environ.pop("K22_TUNE_CACHE", None)
@@ -176,6 +181,16 @@ def main():
         unet22(k22.UNET_CONFIG_2_2, False, [(2, 96, 96), (2, 32, 32)], dtypes=(torch.bfloat16,))
         unet22(k22.UNET_CONFIG_2_2, False, [(2, 32, 32)], dtypes=(torch.float32,))
         unet22(k22.UNET_CONFIG_2_2, True, [(4, 96, 96)], dtypes=(torch.bfloat16,))
+        n = _lib.lib().k22_tile_table_save(out.encode())
+        print(f"{n0} shipped + {n - n0} new = {n} entries -> {out}")
+        return
+    if X2_ONLY:
+        x2 = (k22.F16X2,)
+        n0 = _lib.lib().k22_tile_table_size()
+        unet(tiny, False, [(2, 16, 16), (4, 8, 24), (4, 16, 16)], dtypes=x2)
+        unet(tiny, True, [(4, 16, 24), (2, 16, 16), (4, 16, 16)], dtypes=x2)
+        unet(k22.MODEL_CONFIG_2_1, False, [(2, 96, 96), (2, 32, 32), (8, 128, 128)], dtypes=x2)
+        unet(k22.MODEL_CONFIG_2_1, True, [(8, 96, 96)], dtypes=x2)
         n = _lib.lib().k22_tile_table_save(out.encode())
         print(f"{n0} shipped + {n - n0} new = {n} entries -> {out}")
         return
