@@ -38,6 +38,17 @@ extern "C" {
                       significand bits per operand at 3/16 of the exact-fp32 MFMA cost.  Operand format ("x3 chunks"): 4 bytes per
                       element, every aligned group of 4 consecutive K elements stored as [hi x4 | lo x4] fp16 (csrc/common.h);
                       weights are packed so (pre-multiplied by 2^8) by pack.py / k22_x3_pack, activations by their producers. */
+#define K22_F16X2 4 /* UNet engine only - the ASYMMETRIC SPLIT (round 5): the tensors, the arena and the operand formats of K22_F16X3, with
+                      the precision of every MFMA op a property of the PLAN: weights always as (hi, lo) pairs (their rounding is the
+                      systematic error of a 16-bit engine), the activation operand at fp16 precision - two MFMAs per product,
+                      w_hi.a_hi + w_lo.a_hi - where the operand-rounding ablation (oracle/drift_ablation.py, tests/golden/
+                      drift_ablation_x2.json) prices it as cheap: the 3x3 convolutions below the top resolution level and the qkv
+                      projections; ONE MFMA (fp16 tiles, fp32 softmax) in the attention; all three where it is not: 1x1 skip
+                      connections, the out head, proj_out / encoder_kv, and (default plan; env K22_X2_PLAN bits 0 / 1 release its
+                      in_layers / out_layers convolutions) the top level.  C2 final latent 2.7e-4 from the reference p_sampler
+                      (gate 1e-3) at 1.17x the K22_F16X3 engine's speed.  The kernel-level entries accept it: k22_conv3x3* / k22_gemm* /
+                      k22_qkv_project = two MFMAs, activation operand rounded to fp16 (a fused skip keeps three); k22_attention = fp16
+                      tiles on fp32 tensors. */
 
 int k22_version(void);
 const char* k22_last_error(void);
@@ -45,7 +56,11 @@ const char* k22_last_error(void);
  * k22_conv3x3*, k22_groupnorm) and must not be changed while another thread is inside any k22_* call.  Leave them at their defaults
  * in a process that runs engines (k22_unet_*, k22_prior_*, k22_movq_*, k22_encoder_*): engine launches carry the configuration of their
  * tile-table line, but a line that says "generic kernel" (algo 0) is dispatched through the same switch these knobs override.
- * Everything else in this header is re-entrant per handle (one handle = one stream at a time).
+ * Everything else in this header is re-entrant per handle (one handle = one stream at a time).  What is NOT validated is two handles
+ * running kernels CONCURRENTLY on two streams of one device: round 4 found one kernel pair (igemm_kernel<16-bit, 128 x 64> beside
+ * linear_smallm_kernel) that returned wrong elements when co-resident and could not explain it (profiles/r04_chains_root_cause.txt);
+ * the parity suite, the bench and every engine of this library run one stream at a time.  Serialise engines on one device (or give
+ * each its own device) until that finding is closed - INTEGRATION.md G.
  * Knobs: "igemm_stages" = 2..4 LDS-DMA pipeline depth (-1 default);
  * "igemm_xcd_remap" = 0/1 XCD-aware workgroup renumbering; "conv_algo" = 0 auto, 1 generic implicit GEMM,
  * 2 LDS-resident halo kernel for the 3x3 convolutions (3-7: its variants, see conv3_halo.hip; 8-9: measurement only);
@@ -75,7 +90,7 @@ int k22_debug_set_stream_scratch(void* scratch, size_t bytes);
  * (kandinsky2/model/model_creation.py:9-83) / CONFIG_2_1["model_config"] (kandinsky2/configs.py:125-149).
  */
 typedef struct K22UNetConfig {
-  int dtype;               /* K22_BF16 | K22_F32 | K22_F16 | K22_F16X3 */
+  int dtype;               /* K22_BF16 | K22_F32 | K22_F16 | K22_F16X3 | K22_F16X2 */
   int in_channels;         /* 4; 9 for the inpainting UNet (x, image*mask, mask); 8 for the 2.2 ControlNet-depth UNet (x, hint latent) */
   int model_channels;      /* 384 */
   int out_channels;        /* 8 = eps + learned variance */

@@ -210,7 +210,7 @@ __device__ __forceinline__ void halo_tail(const IgemmParams& p, f32x16_t (&acc)[
   for (int ni = 0; ni < NI; ++ni) brow[ni] = (wn * (BN / WN) + ni * 32 + l31) * 128;
   const int bsw = (l31 >> 1) & 7;
 
-  // ---- fused 1x1 skip connection: acc += X[tile pixels][SK] . Ws[n][SK]^T, 2-stage LDS-DMA pipeline ----------
+  // ---- fused 1x1 skip connection: acc += X[tile pixels][SK] . Ws[n][SK]^T, 3- / 4-stage LDS-DMA ring ----------
   if (p.S0 != nullptr) {
     const int SK = p.SK0 + p.SK1;
     const int nss = SK / BK;
@@ -244,28 +244,37 @@ __device__ __forceinline__ void halo_tail(const IgemmParams& p, f32x16_t (&acc)[
       const T* __restrict__ X0 = reinterpret_cast<const T*>(p.S0);
       const T* __restrict__ X1 = reinterpret_cast<const T*>(p.S1);
       const T* __restrict__ Ws = reinterpret_cast<const T*>(p.Ws);
+      // NSK-deep LDS-DMA ring with a COUNTED vmcnt (round 5).  The 2-stage form this replaces waited vmcnt(0) at every slab: one DMA round
+      // trip (1-2 us from L2 / HBM) per 0.25-0.5 us of MFMA work, i.e. +13...25 us on every convolution with a fused skip - the reason the
+      // tile table gave seven of the 96x96 convolutions to the lock-step kernel.  Now NSK - 1 slabs are in flight across the one raw
+      // barrier per slab; the DMA is issued from inline asm (glds16_asm) so that hipcc neither drains it nor waits lgkmcnt(0) for it.
+      // Slot reuse: iteration q refills the stage iteration q - 1 read, after the barrier every wave reaches only behind its
+      // lgkmcnt(0); past-the-end issues re-load the last slab (uniform counting), drained by the vmcnt(0) below the loop.
+      constexpr int NSK = BM == 256 ? 3 : 4;               // 3 x 48 KB / 4 x 32 KB of the 160 KB
+      constexpr int SCH = SA_SLOTS + B_SLOTS;              // LDS-DMA instructions per wave per slab
+      const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
 #define K22_ISSUE_SKIP(Q, BUFI)                                                                            \
       {                                                                                                    \
-        const int k0_ = (Q) * BK;                                                                          \
+        int q_ = (Q);                                                                                      \
+        if (q_ > q1 - 1) q_ = q1 - 1;                                                                      \
+        const int k0_ = q_ * BK;                                                                           \
         const bool second_ = k0_ >= p.SK0;                                                                 \
         const T* xs_ = second_ ? X1 : X0;                                                                  \
         const int ldx_ = second_ ? p.SK1 : p.SK0;                                                          \
         const int kk_ = second_ ? k0_ - p.SK0 : k0_;                                                       \
-        char* dA_ = smem + (BUFI) * SBUF + wave * 1024;                                                    \
+        const unsigned dA_ = lds0 + (BUFI) * SBUF + wave * 1024;                                           \
         _Pragma("unroll") for (int i = 0; i < SA_SLOTS; ++i)                                               \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs_ + (int64_t)spix[i] * ldx_ + kk_ + schunk[i]), \
-                                             (__attribute__((address_space(3))) void*)(dA_ + i * NW * 1024), 16, 0, 0); \
-        char* dB_ = smem + (BUFI) * SBUF + BM * 128 + wave * 1024;                                         \
+            glds16_asm(xs_ + (int64_t)spix[i] * ldx_ + kk_ + schunk[i], __builtin_amdgcn_readfirstlane(dA_ + i * NW * 1024)); \
         _Pragma("unroll") for (int i = 0; i < B_SLOTS; ++i)                                                \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ws + wsoff[i] + k0_), \
-                                             (__attribute__((address_space(3))) void*)(dB_ + i * NW * 1024), 16, 0, 0); \
+            glds16_asm(Ws + wsoff[i] + k0_, __builtin_amdgcn_readfirstlane(dA_ + BM * 128 + i * NW * 1024)); \
       }
-      K22_ISSUE_SKIP(q0, 0);
-      int buf = 0;
+#pragma unroll
+      for (int t = 0; t < NSK - 1; ++t) K22_ISSUE_SKIP(q0 + t, t);
+      int buf = 0, fill = NSK - 1;
       for (int q = q0; q < q1; ++q) {
-        wait_vmcnt<0>();
+        wait_vmcnt<(NSK - 2) * SCH>();
         raw_barrier();
-        if (q + 1 < q1) K22_ISSUE_SKIP(q + 1, buf ^ 1);
+        K22_ISSUE_SKIP(q + NSK - 1, fill);
         const char* sA = smem + buf * SBUF;
         const char* sB = sA + BM * 128;
         if (cw) {
@@ -285,7 +294,9 @@ __device__ __forceinline__ void halo_tail(const IgemmParams& p, f32x16_t (&acc)[
             for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], b[ni], a[mi]);
         }
         }
-        buf ^= 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // no fragment read of this stage in flight when it is refilled after the next barrier
+        buf = (buf + 1 == NSK) ? 0 : buf + 1;
+        fill = (fill + 1 == NSK) ? 0 : fill + 1;
       }
 #undef K22_ISSUE_SKIP
     }
@@ -449,7 +460,7 @@ inline size_t halo_smem_bytes(const IgemmParams& p, int bm, int nbst) {
   const size_t main_loop = (size_t)2 * halo_rows(p, bm) * 128 + (size_t)nbst * HALO_BN * 128 + (p.gn_coeff ? 1024 : 0);
   const size_t epi = (size_t)bm * (HALO_BN * 4 + 16);
   const size_t red = (size_t)32 * HALO_BN * 2 * 4;
-  const size_t skip = p.S0 ? (size_t)2 * (bm * 128 + HALO_BN * 128) : 0;
+  const size_t skip = p.S0 ? (size_t)(bm == 256 ? 3 : 4) * (bm * 128 + HALO_BN * 128) : 0;   // halo_tail: NSK stages
   size_t m = main_loop > epi ? main_loop : epi;
   m = m > skip ? m : skip;
   return m > red ? m : red;

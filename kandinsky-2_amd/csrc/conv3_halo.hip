@@ -814,7 +814,7 @@ static int halo3_rows(const IgemmParams& p, int bm) { return (bm + 2 * (p.W + 2)
 static size_t halo3_smem_bytes(const IgemmParams& p, int bm, int rb) {
   const size_t main_loop = (size_t)2 * halo3_rows(p, bm) * 64 + (size_t)rb * 3 * HALO_BN * 64;
   const size_t epi = (size_t)bm * (HALO_BN * 4 + 16);
-  const size_t skip = p.S0 ? (size_t)2 * (bm * 128 + HALO_BN * 128) : 0;
+  const size_t skip = p.S0 ? (size_t)(bm == 256 ? 3 : 4) * (bm * 128 + HALO_BN * 128) : 0;   // halo_tail: NSK stages
   size_t m = main_loop > epi ? main_loop : epi;
   return m > skip ? m : skip;
 }

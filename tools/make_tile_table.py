@@ -16,14 +16,30 @@ ENC_ONLY = "--encoders-only" in sys.argv     # keep the shipped table and add on
 SMALL_CONV = "--small-conv" in sys.argv      # keep the shipped table except the 16-bit 3x3 convolutions with M <= 1152 rows: re-measured here
                                              # (the weight-streaming kernel joined their candidate list)
 X3_ONLY = "--x3-only" in sys.argv           # keep the shipped table and add only the split-precision (K22_F16X3) lines
+FUSED_SKIP = "--fused-skip" in sys.argv     # keep the shipped table except the 3x3 convolutions WITH A FUSED 1x1 SKIP (key column 6 >= 100000): re-measured
+                                            # (round 5: their second K loop became an NSK-deep LDS-DMA ring - the specialised kernels may win them now)
 X2_ONLY = "--x2-only" in sys.argv           # keep the shipped table and add the asymmetric split's (K22_F16X2) own lines: measured with every
                                             # convolution of the plan at two MFMAs (K22_X2_PLAN=3) and without the fall-back to the x3 lines
 if X2_ONLY:
     os.environ["K22_X2_OWN_LINES"] = "1"
     os.environ["K22_X2_PLAN"] = "3"
-ADD_MISSING = "--add-missing" in sys.argv   # keep the shipped table; run every UNet shape list (all engine types): whatever problem is not in the
+ADD_MISSING = "--add-missing" in sys.argv or "--fused-skip" in sys.argv   # keep the shipped table; run every UNet shape list (all engine types): whatever problem is not in the
                                             # table yet is measured and added (round 4: the half-batch problems of the two-chain execution)
-if SMALL_CONV:
+if FUSED_SKIP:
+    _here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _src = os.environ.get("K22_TILE_TABLE") or os.path.join(_here, "kandinsky-2_amd", "tiles_gfx950.txt")
+    _tmp = "/tmp/k22_tiles_without_fused_skip.txt"
+    with open(_src) as f, open(_tmp, "w") as g:
+        kept = dropped = 0
+        for line in f:
+            v = line.split()
+            if line.startswith("#") or len(v) < 7 or not (v[1] == "9" and int(v[5]) >= 100000):
+                g.write(line); kept += 1
+            else:
+                dropped += 1
+    print(f"--fused-skip: {kept} table lines kept, {dropped} dropped for re-measurement")
+    os.environ["K22_TILE_TABLE"] = _tmp
+elif SMALL_CONV:
     _here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     _src = os.path.join(_here, "kandinsky-2_amd", "tiles_gfx950.txt")
     _tmp = "/tmp/k22_tiles_without_small_conv.txt"
@@ -37,7 +53,7 @@ if SMALL_CONV:
                 dropped += 1
     print(f"--small-conv: {kept} table lines kept, {dropped} dropped for re-measurement")
     os.environ["K22_TILE_TABLE"] = _tmp
-elif not ENC_ONLY and not X3_ONLY and not ADD_MISSING and not X2_ONLY:
+elif not ENC_ONLY and not X3_ONLY and not ADD_MISSING and not X2_ONLY and not FUSED_SKIP:
     os.environ["K22_TILE_TABLE"] = "0"      # start empty: everything below is measured here
 os.environ.setdefault("K22_TUNE_REPS", "7")
 os.environ.pop("K22_TUNE_CACHE", None)
