@@ -683,3 +683,35 @@ def test_clip_bpe_tokenizer_equals_the_transformers_implementation(tmp_path):
     n0 = 2 + len(tok.encode("a red cat"))
     assert ids[0, 0] == tok.sot_token and ids[0, n0 - 1] == tok.eot_token and (ids[0, n0:] == 0).all() and mask[0].sum() == n0
     assert ids[1, 0] == tok.sot_token and ids[1, 76] == tok.eot_token and mask[1].all()      # truncated: still ends in <|endoftext|>
+
+
+def test_x2_precision_plan_follows_the_operand_rounding_ablation(golden_dir):
+    """The K22_F16X2 plan (csrc/engine.hip: conv_dt / gemm_dt) is read off oracle/drift_ablation.py's first-forward runs (committed:
+    tests/golden/drift_ablation_x2.json).  Asserted here: (1) the error variance is ADDITIVE over operand classes - which is what lets a plan
+    be composed from per-class prices; (2) the classes the plan keeps at three MFMAs are the expensive ones; (3) the final-latent rms the GPU
+    measured for the four plans follows final_rms^2 = c * first_forward_rms^2 with the c of the all-fp16-activations run."""
+    import json
+    with open(os.path.join(golden_dir, "drift_ablation_x2.json")) as f:
+        ab = json.load(f)
+    v = {r["mode"].replace("w:x3w/", ""): r["first_forward_rms"] ** 2 for r in ab["first_forward_only"]}
+    whole = v["g+a+s:fp16"]
+    assert abs(v["g:fp16"] + v["a:fp16"] + v["s:fp16"] - whole) <= 0.02 * whole
+    assert abs(v["g@96:fp16"] + v["g@48:fp16"] + v["g@24:fp16"] + v["g@12:fp16"] - v["g:fp16"]) <= 0.02 * v["g:fp16"]
+    assert abs(v["g1:fp16"] + v["g2:fp16"] + v["gq:fp16"] + v["go:fp16"] - v["g:fp16"]) <= 0.02 * v["g:fp16"]
+    # what the plan keeps at the full split: skip inputs (half of everything), the out head, the top level (default plan 0)
+    assert v["s:fp16"] > 0.45 * whole and v["go:fp16"] > 0.12 * whole and v["g1@96:fp16"] + v["g2@96:fp16"] > 0.2 * whole
+    # what it runs at two MFMAs (one in the attention) is cheap
+    cheap = v["g@48:fp16"] + v["g@24:fp16"] + v["g@12:fp16"] + v["gq:fp16"] + v["a:fp16"]
+    assert cheap < 0.1 * whole
+    c = 0.3725   # (final rms 1.99e-4)^2 / (first-forward rms 3.26e-4)^2 of 'w:x3w/g+a+s:fp16' (drift_ablation_x3.json)
+    plans = {"0": cheap, "1": cheap + v["g1@96:fp16"], "2": cheap + v["g2@96:fp16"], "3": cheap + v["g1@96:fp16"] + v["g2@96:fp16"]}
+    for k, ff2 in plans.items():
+        pred = (c * ff2) ** 0.5
+        meas = ab["gpu_measured_plans_c2"][k]["rms"]
+        assert abs(pred - meas) <= 0.08 * meas, (k, pred, meas)
+    # fp16 WEIGHTS at the 12x12 level: cheap in one forward, but a systematic error - the 50-step run is what prices it
+    base = next(r for r in ab["first_forward_only"] if r["mode"].endswith("gq+a:fp16"))
+    w12 = next(r for r in ab["first_forward_only"] if r["mode"].endswith("/w@12:fp16"))
+    assert w12["first_forward_rms"] ** 2 < 1.1 * base["first_forward_rms"] ** 2
+    f12 = next(r for r in ab["final_runs"] if "w@12+s@12" in r["mode"] and "w@24" not in r["mode"])
+    assert f12["final_max_abs"] < 5e-4 and f12["final_rms"] ** 2 > 1.4 * ab["gpu_measured_plans_c2"]["0"]["rms"] ** 2
