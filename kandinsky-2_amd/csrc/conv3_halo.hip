@@ -23,8 +23,8 @@
 //     (sum, sum of squares) of the STORED values for the next GroupNorm (deterministic, no atomics)
 //   * split-K over channel slabs for the low-resolution levels (fp32 partials, finished by splitk_reduce)
 //   * variants selected by p.algo (measured in DESIGN.md section 9): 2 = this kernel; 7 = its LDS-DMA issued from inline asm
-//     (exact lgkmcnt for the fragment reads; the tuner's usual pick); 6 = 7 + explicit fragment pipeline; 5 = loader-wave
-//     specialisation; 3 / 4 = conv3_halo3 / conv3_halo4 below; 8 / 9 = measurement only.  gemm8_kernel (plain GEMM on the
+//     (exact lgkmcnt for the fragment reads; the tuner's usual pick); 6 = 7 + explicit fragment pipeline; 3 = conv3_halo3 below;
+//     8 / 9 = measurement only.  gemm8_kernel (plain GEMM on the
 //     same frame, qkv / proj_out) lives in this file too because it shares the epilogue (halo_tail)
 //   * optional fused 1x1 skip_connection of the ResBlock (out += x . Ws^T): a second, plain-GEMM K loop over the
 //     block input's channels (A rows = the tile's own pixels, no halo) that accumulates into the same registers,
@@ -37,12 +37,8 @@ int launch_conv3_halo_spec(const IgemmParams& p, int dtype, int bm, int nbst, in
 int launch_conv3_halo_spec_debug(const IgemmParams& p, int nbst, int splitk, hipStream_t stream);
 #endif
 
-// LW = number of waves that issue the LDS-DMA (the "loader" waves 0 .. LW-1):
-//   LW = 8: every wave loads its share right after the barrier (3 pieces per wave per tap);
-//   LW = 4: waves 0-3 load everything (6 pieces per tap), waves 4-7 go straight from the barrier into their fragments
-//           and MFMAs.  A workgroup's waves w and w+4 share a SIMD (waves are dealt to the SIMDs cyclically), so
-//           on every SIMD one wave pays the ~100-cycle-per-piece issue cost WHILE its partner owns the matrix pipe,
-//           instead of both issuing first (pipe idle) and then both wanting the pipe (p.algo == 5).
+// LW = number of waves that issue the LDS-DMA: 8 (every wave loads its share right after the barrier: 3 pieces per wave per tap).  (A
+// 4-loader form - p.algo 5 - measured 2-5 % slower in round 1 and was deleted in round 5; the parameter stays for the index arithmetic.)
 // PIPE: explicit fragment pipeline across the per-tap barrier.  The fragments of k-step ks+1 are read from LDS BEFORE
 // the MFMAs of k-step ks are issued (two register sets), and the last k-step of a tap is multiplied after the NEXT
 // tap's barrier, where it covers the LDS-DMA issue and the first fragment reads of that tap: a wave never parks on
@@ -600,215 +596,6 @@ __global__ __launch_bounds__(512) void conv3_halo3_kernel(const IgemmParams p) {
   halo_tail<T, BM>(p, acc, smem, bx, bz, img, v0, n0);
 }
 
-// ================================================================================================================
-// conv3_halo4_kernel: the halo kernel with the two waves of every SIMD in OPPOSITE phases.
-// In-kernel s_memtime stamps of conv3_halo_kernel (tools/conv_trace.py) show a tap period of ~1700 cycles for 1024 cycles
-// of MFMA work per SIMD: after each barrier BOTH waves of a SIMD spend ~300 cycles issuing LDS-DMA and waiting for their
-// first fragments (matrix pipe idle), then both want the pipe.  Here the eight waves form two groups that run the same
-// tap half a period apart, with two barriers per tap:
-//     phase A:  group 0 issues its 16 MFMAs (fragments already in registers)  |  group 1 issues the halo LDS-DMA of the
-//               next slab and reads its 16 fragments of this tap
-//     phase B:  group 0 issues the weight LDS-DMA NBST taps ahead and reads its fragments of the NEXT tap
-//               |  group 1 issues its 16 MFMAs
-// so one wave per SIMD is always in its matrix phase while its partner does the memory work.  Weight tiles are loaded by
-// group 0 only (counted vmcnt before the second barrier), halo pieces by group 1 only (drained once per slab).
-// ================================================================================================================
-template <typename T, int BM, int NBST>
-__global__ __launch_bounds__(512) void conv3_halo4_kernel(const IgemmParams p) {
-  using TR = TT<T>;
-  constexpr int BK = TR::BK, EPC = TR::EPC, KSTEPS = TR::KSTEPS;
-  constexpr int BN = HALO_BN, NW = HALO_NW, WM = 4, WN = 2;
-  constexpr int MI = BM / (WM * 32), NI = BN / (WN * 32);
-  constexpr int B_BYTES = BN * 128;
-  constexpr int B_PW = BN / 8 / 4;       // weight pieces per group-0 wave per tap (4)
-  constexpr int A_PW = 16;               // halo slots per group-1 wave per slab (2 per tap, taps 0..7)
-  constexpr int GM = 8;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2, w4 = wave & 3;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int h = lane >> 5, l31 = lane & 31;
-
-  const int W2 = p.W + 2;
-  const int VR = p.H * W2;
-  const int TPI = (VR + BM - 1) / BM;
-  const int HRp = (BM + 2 * W2 + 2 + 7) & ~7;
-  const int NP = HRp >> 3;
-  const int A_BYTES = HRp * 128;
-  const int PR_MAX = (p.H + 2) * W2 - 1;
-  const int B = p.M / (p.H * p.W);
-
-  const int gx = B * TPI, gy = (p.N + BN - 1) / BN;
-  int L = p.xcd_remap ? xcd_remap_h(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int per_z = gx * gy;
-  const int bz = L / per_z;
-  L -= bz * per_z;
-  const int grpm = L / (GM * gy);
-  const int first_m = grpm * GM;
-  const int gsz = gx - first_m < GM ? gx - first_m : GM;
-  const int lin = L - grpm * GM * gy;
-  const int bx = first_m + lin % gsz, by = lin / gsz;
-  const int img = bx / TPI, v0 = (bx - img * TPI) * BM;
-  const int n0 = by * BN;
-
-  const T* __restrict__ Aimg = reinterpret_cast<const T*>(p.A0) + (int64_t)img * (p.H + 2) * W2 * p.Kc;
-  const T* __restrict__ Wp = reinterpret_cast<const T*>(p.Wp);
-
-  const int nslab = p.Kc / BK;
-  int s0 = 0, s1 = nslab;
-  if (p.splitk > 1) {
-    const int per = (nslab + p.splitk - 1) / p.splitk;
-    s0 = bz * per;
-    s1 = s0 + per < nslab ? s0 + per : nslab;
-  }
-
-  f32x16_t acc[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-  char* const Bst = smem + 2 * A_BYTES;
-  const int abase = wm * (BM / WM) + l31;
-  int brow[NI];
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) brow[ni] = (wn * (BN / WN) + ni * 32 + l31) * 128;
-  const int bsw = (l31 >> 1) & 7;
-
-  // fragments of one whole tap (KSTEPS x (MI + NI)), loaded in one phase and consumed in the next
-  Frag<T> fa[KSTEPS][MI], fb[KSTEPS][NI];
-#define K22_READ_FRAGS(TAP, ABUF, BTILE)                                                                   \
-  {                                                                                                        \
-    const int shift_ = ((TAP) / 3) * W2 + ((TAP) % 3);                                                     \
-    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                    \
-      const int ar_ = abase + mi * 32 + shift_;                                                            \
-      const char* arow_ = (ABUF) + ar_ * 128;                                                              \
-      const int asw_ = (ar_ >> 1) & 7;                                                                     \
-      _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks) ld_frag_at(fa[ks][mi], arow_, asw_, ks, h);    \
-    }                                                                                                      \
-    _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                      \
-      _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks) ld_frag_at(fb[ks][ni], (BTILE) + brow[ni], bsw, ks, h); \
-  }
-#define K22_MFMAS()                                                                                        \
-  {                                                                                                        \
-    _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks)                                                  \
-      _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                    \
-        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], fb[ks][ni], fa[ks][mi]);   \
-  }
-
-  if (s0 < s1) {
-    if (grp == 0) {
-      // ================= group 0: weight loader, MFMAs in phase A =================
-      int boff[B_PW];
-#pragma unroll
-      for (int i = 0; i < B_PW; ++i) {
-        const int row = 8 * (w4 + 4 * i) + (lane >> 3);
-        int n = n0 + row;
-        if (n > p.Npad - 1) n = p.Npad - 1;
-        boff[i] = n * 9 * p.Kc + ((lane & 7) ^ ((row >> 1) & 7)) * EPC;
-      }
-#define K22_ISSUE_B4(SLAB, TAP, STAGE)                                                                     \
-      {                                                                                                    \
-        const int kofs_ = (TAP) * p.Kc + (SLAB) * BK;                                                      \
-        char* dst_ = Bst + (STAGE) * B_BYTES + w4 * 1024;                                                  \
-        _Pragma("unroll") for (int i = 0; i < B_PW; ++i)                                                   \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wp + boff[i] + kofs_), \
-                                             (__attribute__((address_space(3))) void*)(dst_ + i * 4 * 1024), 16, 0, 0); \
-      }
-      // prologue: weight tiles of taps 0 .. NBST-1, everything landed, fragments of tap 0
-#pragma unroll
-      for (int t = 0; t < NBST; ++t) {
-        const int sa_ = s0 + t / 9 < s1 ? s0 + t / 9 : s1 - 1;
-        K22_ISSUE_B4(sa_, t % 9, t);
-      }
-      wait_vmcnt<0>();
-      raw_barrier();                       // (P) halo of slab s0 + tiles 0..NBST-1 visible
-      K22_READ_FRAGS(0, smem, Bst);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      int nxt = 1 % NBST;    // ring slot of tap+1's weights
-      int fill = 0;          // ring slot that becomes free at the second barrier of this tap
-      for (int s = s0; s < s1; ++s) {
-        char* const Acur = smem + ((s - s0) & 1) * A_BYTES;
-        char* const Anext = smem + (((s - s0) & 1) ^ 1) * A_BYTES;
-        const int sn = s + 1 < s1 ? s + 1 : s1 - 1;
-#define K22_TAP4_G0(TAP)                                                                                   \
-        {                                                                                                  \
-          raw_barrier();                   /* barrier 1 */                                  \
-          K22_MFMAS();                                                                                     \
-          wait_vmcnt<B_PW * (NBST - 2)>();                /* my pieces of tap+1's weights have landed */   \
-          raw_barrier();                   /* barrier 2: tap+1's tile visible, this tap's tile free */ \
-          {                                                                                                \
-            constexpr int ta_ = ((TAP) + NBST) % 9;                                                        \
-            int sa_ = s + ((TAP) + NBST) / 9;                                                              \
-            if (sa_ > s1 - 1) sa_ = s1 - 1;                                                                \
-            K22_ISSUE_B4(sa_, ta_, fill);                                                                  \
-          }                                                                                                \
-          K22_READ_FRAGS(((TAP) + 1) % 9, ((TAP) == 8 ? Anext : Acur), Bst + nxt * B_BYTES);               \
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* no LDS read in flight across a barrier */  \
-          nxt = (nxt + 1 == NBST) ? 0 : nxt + 1;                                                           \
-          fill = (fill + 1 == NBST) ? 0 : fill + 1;                                                        \
-        }
-        K22_TAP4_G0(0) K22_TAP4_G0(1) K22_TAP4_G0(2) K22_TAP4_G0(3) K22_TAP4_G0(4) K22_TAP4_G0(5) K22_TAP4_G0(6) K22_TAP4_G0(7) K22_TAP4_G0(8)
-#undef K22_TAP4_G0
-      }
-#undef K22_ISSUE_B4
-    } else {
-      // ================= group 1: halo loader, MFMAs in phase B =================
-      int aoff[A_PW];
-#pragma unroll
-      for (int q = 0; q < A_PW; ++q) {
-        int j = q * 4 + w4;
-        if (j > NP - 1) j = NP - 1;
-        const int hr = 8 * j + (lane >> 3);
-        int pr = v0 + hr;
-        if (pr > PR_MAX) pr = PR_MAX;
-        aoff[q] = pr * p.Kc + ((lane & 7) ^ ((hr >> 1) & 7)) * EPC;
-      }
-#define K22_ISSUE_A4(Q, SLAB, DST)                                                                         \
-      {                                                                                                    \
-        int j_ = (Q) * 4 + w4;                                                                             \
-        if (j_ > NP - 1) j_ = NP - 1;                                                                      \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Aimg + aoff[Q] + (SLAB) * BK), \
-                                         (__attribute__((address_space(3))) void*)((DST) + j_ * 1024), 16, 0, 0); \
-      }
-#pragma unroll
-      for (int q = 0; q < A_PW; ++q) K22_ISSUE_A4(q, s0, smem);
-      wait_vmcnt<0>();
-      raw_barrier();                       // (P)
-      int cur = 0;
-      for (int s = s0; s < s1; ++s) {
-        char* const Acur = smem + ((s - s0) & 1) * A_BYTES;
-        char* const Anext = smem + (((s - s0) & 1) ^ 1) * A_BYTES;
-        const int sn = s + 1 < s1 ? s + 1 : s1 - 1;
-#define K22_TAP4_G1(TAP)                                                                                   \
-        {                                                                                                  \
-          raw_barrier();                   /* barrier 1 */                                  \
-          if constexpr ((TAP) < 8) {                                                                       \
-            K22_ISSUE_A4(2 * ((TAP) < 8 ? (TAP) : 0), sn, Anext);                                          \
-            K22_ISSUE_A4(2 * ((TAP) < 8 ? (TAP) : 0) + 1, sn, Anext);                                      \
-          }                                                                                                \
-          K22_READ_FRAGS((TAP), Acur, Bst + cur * B_BYTES);                                                \
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the tile is overwritten after barrier 2 */  \
-          if constexpr ((TAP) == 8) wait_vmcnt<0>();      /* next slab's halo complete before group 0 reads it */ \
-          raw_barrier();                   /* barrier 2 */                                  \
-          K22_MFMAS();                                                                                     \
-          cur = (cur + 1 == NBST) ? 0 : cur + 1;                                                           \
-        }
-        K22_TAP4_G1(0) K22_TAP4_G1(1) K22_TAP4_G1(2) K22_TAP4_G1(3) K22_TAP4_G1(4) K22_TAP4_G1(5) K22_TAP4_G1(6) K22_TAP4_G1(7) K22_TAP4_G1(8)
-#undef K22_TAP4_G1
-      }
-#undef K22_ISSUE_A4
-    }
-  }
-#undef K22_READ_FRAGS
-#undef K22_MFMAS
-  halo_tail<T, BM>(p, acc, smem, bx, bz, img, v0, n0);
-}
-
 // ---- host side ---------------------------------------------------------------------------------
 static int halo3_rows(const IgemmParams& p, int bm) { return (bm + 2 * (p.W + 2) + 2 + 15) & ~15; }
 static size_t halo3_smem_bytes(const IgemmParams& p, int bm, int rb) {
@@ -822,13 +609,6 @@ static int halo3_pick_rb(const IgemmParams& p, int bm) {
   if (halo3_rows(p, bm) / 16 > HALO3_ASLOTS * HALO_NW) return 0;
   for (int rb : {4, 3, 2})
     if (halo3_smem_bytes(p, bm, rb) <= 160 * 1024) return rb;
-  return 0;
-}
-
-static int halo4_pick_nbst(const IgemmParams& p, int bm) {
-  if (halo_rows(p, bm) / 8 > 64) return 0;   // 16 halo slots x 4 loader waves per slab
-  for (int nbst : {4, 3, 2})
-    if (halo_smem_bytes(p, bm, nbst) <= 160 * 1024) return nbst;
   return 0;
 }
 
@@ -901,7 +681,7 @@ bool conv3_halo_supported(const IgemmParams& p, int dtype, int bm) {
   if (p.taps != 9 || (bm != 256 && bm != 128)) return false;
   // split precision: the input is read in x3 chunks; instantiated forms = the lock-step kernel with asm LDS-DMA (algo 2 / 5 / 6 / 7 all
   // run it) and the specialised kernel (11 / 12)
-  if (k22_is_split(dtype) && (p.a_raw || p.algo == 3 || p.algo == 4)) return false;
+  if (k22_is_split(dtype) && (p.a_raw || p.algo == 3)) return false;
   if (p.gn_coeff != nullptr) {   // fused GroupNorm-apply: the specialised kernels only; slabs never straddle the two raw sources
     if (!conv3_algo_fuses_gn(p.algo) || !p.gn_x0 || p.gn_C0 <= 0 || p.gn_C0 > p.Kc || p.gn_C0 % BK || (p.gn_C0 < p.Kc && !p.gn_x1)) return false;
     if ((int64_t)p.H * p.W * p.Kc >= (1ll << 31)) return false;
@@ -913,7 +693,7 @@ bool conv3_halo_supported(const IgemmParams& p, int dtype, int bm) {
     if (!p.Ws || p.SK0 % BK || p.SK1 % BK || (p.SK1 > 0 && !p.S1) || p.SK0 <= 0) return false;
     if ((int64_t)p.M * (p.SK0 > p.SK1 ? p.SK0 : p.SK1) >= (1ll << 31) || (int64_t)p.Npad * (p.SK0 + p.SK1) >= (1ll << 31)) return false;
   }
-  if ((p.algo == 3 ? halo3_pick_rb(p, bm) : (p.algo == 4 ? halo4_pick_nbst(p, bm) : halo_pick_nbst(p, bm))) == 0) return false;
+  if ((p.algo == 3 ? halo3_pick_rb(p, bm) : halo_pick_nbst(p, bm)) == 0) return false;
   if ((int64_t)(p.H + 2) * (p.W + 2) * p.Kc >= (1ll << 31) || (int64_t)p.Npad * 9 * p.Kc >= (1ll << 31)) return false;
   return true;
 }
@@ -962,26 +742,6 @@ static int launch_halo3_rb(const IgemmParams& p, int rb, int splitk, hipStream_t
   return launch_halo3_cfg<T, BM, 4>(p, splitk, stream);
 }
 
-template <typename T, int BM, int NBST>
-static int launch_halo4_cfg(const IgemmParams& p, int splitk, hipStream_t stream) {
-  const size_t smem = halo_smem_bytes(p, BM, NBST);
-  static LdsAttrGuard attr_guard;
-  if (int rc_ = k22_ensure_lds_attr(attr_guard, reinterpret_cast<const void*>(&conv3_halo4_kernel<T, BM, NBST>), 160 * 1024, __FILE__, __LINE__)) return rc_;
-  IgemmParams q = p;
-  q.splitk = splitk;
-  const int B = p.M / (p.H * p.W);
-  const int nblocks = B * conv3_halo_tiles_per_image(p, BM) * ((p.N + HALO_BN - 1) / HALO_BN) * splitk;
-  hipLaunchKernelGGL((conv3_halo4_kernel<T, BM, NBST>), dim3(nblocks), dim3(512), smem, stream, q);
-  K22_CHECK_LAUNCH();
-  return K22_OK;
-}
-template <typename T, int BM>
-static int launch_halo4_nbst(const IgemmParams& p, int nbst, int splitk, hipStream_t stream) {
-  if (nbst == 2) return launch_halo4_cfg<T, BM, 2>(p, splitk, stream);
-  if (nbst == 3) return launch_halo4_cfg<T, BM, 3>(p, splitk, stream);
-  return launch_halo4_cfg<T, BM, 4>(p, splitk, stream);
-}
-
 // developer tool: conv3_halo_kernel<bf16, 256, NBST> with per-tap s_memtime stamps (wave 0 and wave 5 of block 0):
 // trace[w][tap][4] = (before the counted vmcnt wait, after it, after the barrier, after the last MFMA was issued)
 int launch_conv3_halo_trace(const IgemmParams& p, int dtype, hipStream_t stream) {
@@ -1004,8 +764,9 @@ int launch_conv3_halo_trace(const IgemmParams& p, int dtype, hipStream_t stream)
 }
 
 // Launches the halo kernel only (the split-K reduction, if any, is the caller's: launch_igemm).
-// p.algo == 3 selects the 64-byte-row kernel (conv3_halo3_kernel), 4 the two-phase kernel (conv3_halo4_kernel),
-// 5 the 128-byte-row kernel with loader-wave specialisation, anything else the symmetric 128-byte-row one.
+// p.algo == 3 selects the 64-byte-row kernel (conv3_halo3_kernel), anything else the 128-byte-row one (6 / 7: its pipelined / asm-DMA
+// forms; 11 / 12: the specialised kernel of conv3_spec.hip).  (Algos 4 - two wave groups in opposite phases - and 5 - loader-wave
+// specialisation - measured 12-20 % / 2-5 % slower in round 1, were never tuner candidates, and were deleted in round 5.)
 int launch_conv3_halo(const IgemmParams& p, int dtype, int bm, int splitk, hipStream_t stream) {
   if (!conv3_halo_supported(p, dtype, bm)) return k22_set_error(K22_EINVAL, "conv3_halo: unsupported problem");
   if (k22_is_split(dtype)) {
@@ -1015,12 +776,6 @@ int launch_conv3_halo(const IgemmParams& p, int dtype, int bm, int splitk, hipSt
     if (p.algo == 13 || p.algo == 14 || p.algo == 8 || p.algo == 9) return k22_set_error(K22_EINVAL, "conv3_halo: no measurement-only variants in split precision");
     if (dtype == K22_F16X2) return bm == 256 ? launch_halo_nbst<x2_t, 256, 8, 2>(p, nb, splitk, stream) : launch_halo_nbst<x2_t, 128, 8, 2>(p, nb, splitk, stream);
     return bm == 256 ? launch_halo_nbst<x3_t, 256, 8, 2>(p, nb, splitk, stream) : launch_halo_nbst<x3_t, 128, 8, 2>(p, nb, splitk, stream);
-  }
-  if (p.algo == 4 && dtype != K22_F16) {   // (fp16: not instantiated - never a tuner candidate; the default kernel below)
-    int nbst = halo4_pick_nbst(p, bm);
-    if (p.stages >= 2 && p.stages < nbst) nbst = p.stages;
-    if (dtype == K22_BF16) return bm == 256 ? launch_halo4_nbst<bf16_t, 256>(p, nbst, splitk, stream) : launch_halo4_nbst<bf16_t, 128>(p, nbst, splitk, stream);
-    return bm == 256 ? launch_halo4_nbst<float, 256>(p, nbst, splitk, stream) : launch_halo4_nbst<float, 128>(p, nbst, splitk, stream);
   }
   if (p.algo == 3) {
     int rb = halo3_pick_rb(p, bm);
@@ -1041,10 +796,6 @@ int launch_conv3_halo(const IgemmParams& p, int dtype, int bm, int splitk, hipSt
 #else
   if (p.algo == 13 || p.algo == 14 || p.algo == 8 || p.algo == 9) return k22_set_error(K22_EINVAL, "conv3_halo: measurement-only variants need a -DK22_DEBUG_VARIANTS build");
 #endif
-  if (p.algo == 5 && dtype != K22_F16) {  // loader-wave specialisation (waves 0-3 issue all LDS-DMA)
-    if (dtype == K22_BF16) return bm == 256 ? launch_halo_nbst<bf16_t, 256, 4, 0>(p, nbst, splitk, stream) : launch_halo_nbst<bf16_t, 128, 4, 0>(p, nbst, splitk, stream);
-    return bm == 256 ? launch_halo_nbst<float, 256, 4, 0>(p, nbst, splitk, stream) : launch_halo_nbst<float, 128, 4, 0>(p, nbst, splitk, stream);
-  }
   if (p.algo == 6) {  // explicit fragment pipeline across the barrier + asm LDS-DMA
     if (dtype == K22_BF16) return bm == 256 ? launch_halo_nbst<bf16_t, 256, 8, 1>(p, nbst, splitk, stream) : launch_halo_nbst<bf16_t, 128, 8, 1>(p, nbst, splitk, stream);
     else if (dtype == K22_F16) return bm == 256 ? launch_halo_nbst<f16_t, 256, 8, 1>(p, nbst, splitk, stream) : launch_halo_nbst<f16_t, 128, 8, 1>(p, nbst, splitk, stream);

@@ -453,9 +453,9 @@ static int g_conv_algo = 0;
 void igemm_set_default_stages(int v) { g_stages_override = (v >= 2 && v <= 4) ? v : -1; }
 void igemm_set_xcd_remap(int v) { g_xcd_remap = v ? 1 : 0; }
 #ifdef K22_DEBUG_VARIANTS
-void igemm_set_conv_algo(int v) { g_conv_algo = ((v >= 0 && v <= 9) || (v >= 11 && v <= 14) || v == 20) ? v : 0; }
+void igemm_set_conv_algo(int v) { g_conv_algo = ((v >= 0 && v <= 9 && v != 4 && v != 5) || (v >= 11 && v <= 14) || v == 20) ? v : 0; }
 #else   // 8, 9, 13, 14 are measurement-only kernels (wrong results): not reachable in a release build
-void igemm_set_conv_algo(int v) { g_conv_algo = ((v >= 0 && v <= 7) || v == 11 || v == 12 || v == 20) ? v : 0; }
+void igemm_set_conv_algo(int v) { g_conv_algo = ((v >= 0 && v <= 7 && v != 4 && v != 5) || v == 11 || v == 12 || v == 20) ? v : 0; }
 #endif
 static int g_gemm_algo = 0;   // 0 = generic igemm_kernel, 10 = gemm8_kernel where it applies (unit tests / kernel benches)
 void igemm_set_gemm_algo(int v) { g_gemm_algo = (v == 10 || v == 20) ? v : 0; }
@@ -499,7 +499,7 @@ static IgemmPlan igemm_plan(const IgemmParams& p, int dtype) {
   const int algo = (p.algo && p.algo != 20) ? p.algo : (g_conv_algo == 20 ? 0 : g_conv_algo);
   if (p.taps == 9 && algo != 1 && p.N >= 128 && !p.a_raw) {   // (the halo kernels read their input in x3 chunks only)
     IgemmParams ph = p;
-    ph.algo = ((algo >= 3 && algo <= 9) || (algo >= 11 && algo <= 14)) ? algo : 2;
+    ph.algo = ((algo >= 3 && algo <= 9 && algo != 4 && algo != 5) || (algo >= 11 && algo <= 14)) ? algo : 2;
     int bm = 0;
     if (p.force_bm == 256 || p.force_bm == 128) {
       if (conv3_halo_supported(ph, dtype, p.force_bm) && (algo >= 2 || p.force_bn == 0)) bm = p.force_bm;

@@ -205,7 +205,7 @@ class Kandinsky2_1HIP:
         ms = self.config["prior"]["clip_mean_std_path"]
         clip_mean, clip_std = _load(ms) if isinstance(ms, (str, os.PathLike)) else ms
         # the split-precision arithmetic ("f16x3") exists in the UNet engine only: beside it the prior (and MoVQ below) run their fp32 parity path
-        aux_dtype = torch.float32 if isinstance(backend_dtype, str) else backend_dtype
+        aux_dtype, movq_auto = aux_engine_dtypes(backend_dtype, movq_dtype)
         self.prior = PriorDiffusionModelHIP(hp, self.config["prior"]["params"]["diffusion"], clip_mean.reshape(-1), clip_std.reshape(-1),
                                             backend_dtype=aux_dtype)
         self.prior.load_state_dict(_load(prior_path), strict=False)
@@ -221,7 +221,7 @@ class Kandinsky2_1HIP:
         # parity path) decode in fp32 - uint8 image within ONE grey level of the reference's fp32 decode; 16-bit engines (the product path) decode
         # in fp16 - within 3 grey levels, 88 % of the bytes identical, at 12 ms instead of 53 (bf16 would move pixels by up to 24 levels, which
         # is why a bf16 UNet still gets an fp16 MoVQ; tests/test_movq_gpu.py, profiles/r03_movq_precision.txt).
-        self.movq_dtype = (torch.float32 if aux_dtype == torch.float32 else torch.float16) if movq_dtype is None else movq_dtype
+        self.movq_dtype = movq_auto
         self.image_encoder = _MoVQ(ie["params"], movq_sd, self.movq_dtype, device)
 
         self.model = Text2ImUNetHIP(make_arch(mcfg, inpainting=mcfg["inpainting"]), backend_dtype=backend_dtype, use_graph=use_graph,
@@ -416,14 +416,24 @@ class _MoVQ:
         return self
 
 
+def aux_engine_dtypes(backend_dtype, movq_dtype=None):
+    """(prior / towers dtype, MoVQ dtype) that go with a UNet engine of `backend_dtype` - ONE rule for the 2.1 and the 2.2 drivers
+    (pipeline22 had its own copy, which sent an fp16 MoVQ beside the "f16x3" engine).  The split-precision arithmetics are
+    strings and exist in the UNet engine only: everything beside them runs its fp32 parity path.  MoVQ: movq_dtype=None follows the
+    engines the way the reference does under use_fp16 (kandinsky2_1_model.py:92-94, 287-288): fp32 beside fp32-class engines, fp16
+    beside 16-bit engines (also beside bf16: a bf16 decode moves pixels by up to 24 grey levels)."""
+    aux = torch.float32 if isinstance(backend_dtype, str) else backend_dtype
+    movq = (torch.float32 if aux == torch.float32 else torch.float16) if movq_dtype is None else movq_dtype
+    return aux, movq
+
+
 def _conditioner_from_cache_dir(cache_dir, device, backend_dtype, tokenizer2=None):
     """The encoders Kandinsky2_1.__init__ builds (kandinsky2_1_model.py:57-66; files as kandinsky2/__init__.py:124-160 stores them):
     cache_dir/text_encoder (XLM-R tokenizer + pytorch_model.bin of MultilingualCLIP) and cache_dir/ViT-L-14.pt, on the HIP encoder
     engine.  tokenizer2 = the CLIP byte-pair tokenizer (what the reference builds as kandinsky2.model.prior.CustomizedTokenizer()):
     None = the package's own ClipBPETokenizer on the merges file found in cache_dir; an object with padded_tokens_and_mask(...) overrides
     it.  The product path imports nothing from the reference package.  Raises - never substitutes seeded noise - when a file is missing."""
-    if isinstance(backend_dtype, str):
-        backend_dtype = torch.float32   # the split-precision arithmetic exists in the UNet engine only
+    backend_dtype = aux_engine_dtypes(backend_dtype)[0]   # the split-precision arithmetics exist in the UNet engine only
     from .encoders import CLIPModelHIP, HIPConditioner, TextEncoderHIP
     te_dir, clip_pt = os.path.join(cache_dir, "text_encoder"), os.path.join(cache_dir, "ViT-L-14.pt")
     missing = [p for p in (os.path.join(te_dir, "pytorch_model.bin"), clip_pt) if not os.path.exists(p)]

@@ -272,10 +272,8 @@ class Kandinsky2_2HIP:
         self.unet.load_state_dict(unet_state_dict)
         self.unet = self.unet.to(device).eval()
         # None: fp32 engines decode in fp32, 16-bit engines in fp16 (pipeline.py: within one / three grey levels of the fp32 decode)
-        # the split-precision arithmetics ("f16x3" / "f16x2") exist in the UNet engine only: MoVQ runs its fp32 parity path beside them, as in
-        # pipeline.py (an fp16 decode there put the engine built to reproduce the fp32 images up to 3 grey levels off)
-        aux_dtype = torch.float32 if isinstance(backend_dtype, str) else backend_dtype
-        mdt = (torch.float32 if aux_dtype == torch.float32 else torch.float16) if movq_dtype is None else movq_dtype
+        from .pipeline import aux_engine_dtypes
+        mdt = aux_engine_dtypes(backend_dtype, movq_dtype)[1]     # one rule with the 2.1 driver: fp32 beside fp32 / split-precision engines
         movq = MoVQDecoderHIP(backend_dtype=mdt)
         movq.load_state_dict(movq_state_dict, strict=True)          # decoder keys; a full MOVQ checkpoint's other keys are skipped
         movq = movq.to(device)

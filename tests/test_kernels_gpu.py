@@ -78,7 +78,7 @@ def test_conv3x3(dtype, B, Cin, Cout, H, W, bm, bn, splitk):
     (2, 128, 128, 16, 16, 256, 1), (1, 64, 192, 9, 13, 128, 1), (2, 256, 128, 8, 8, 256, 3), (3, 192, 256, 6, 10, 128, 2),
     (2, 384, 384, 24, 24, 256, 1), (1, 128, 256, 96, 96, 256, 1), (2, 128, 128, 12, 12, 0, 0), (1, 128, 136, 48, 48, 128, 1),
 ])
-@pytest.mark.parametrize("algo", [2, 3, 4, 5, 6, 7, 11, 12])
+@pytest.mark.parametrize("algo", [2, 3, 6, 7, 11, 12])
 def test_conv3x3_halo(dtype, B, Cin, Cout, H, W, bm, splitk, algo):
     """LDS-resident halo kernels (conv3_halo.hip; algo 2 = 128-byte rows, 3 = 64-byte rows / filter-row iterations):
     junk columns, image boundaries, ragged last tile, split-K."""
@@ -92,7 +92,7 @@ def test_conv3x3_halo(dtype, B, Cin, Cout, H, W, bm, splitk, algo):
 @pytest.mark.parametrize("B,Cin,Cout,H,W,bm,splitk", [
     (2, 128, 128, 16, 16, 256, 1), (2, 128, 256, 24, 24, 128, 1), (2, 256, 128, 12, 12, 256, 2), (1, 128, 128, 48, 48, 256, 1),
 ])
-@pytest.mark.parametrize("algo", [2, 3, 4, 5, 6, 7, 11, 12])
+@pytest.mark.parametrize("algo", [2, 3, 6, 7, 11, 12])
 def test_conv3x3_groupnorm_partial_sums(dtype, B, Cin, Cout, H, W, bm, splitk, algo):
     """The conv epilogue's GroupNorm side output = per-image, per-channel sum / sum of squares of the STORED tensor."""
     x, w = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
@@ -111,7 +111,7 @@ def test_conv3x3_groupnorm_partial_sums(dtype, B, Cin, Cout, H, W, bm, splitk, a
     (2, 128, 128, 64, 0, 16, 16, 256, 1), (1, 128, 256, 128, 64, 24, 24, 128, 1), (2, 256, 128, 192, 128, 12, 12, 256, 2),
     (2, 128, 128, 320, 0, 8, 8, 128, 4),
 ])
-@pytest.mark.parametrize("algo", [2, 3, 4, 5, 6, 7, 11, 12])
+@pytest.mark.parametrize("algo", [2, 3, 6, 7, 11, 12])
 def test_conv3x3_with_fused_skip_connection(dtype, B, Cin, Cout, SK0, SK1, H, W, bm, splitk, algo):
     """out = conv3x3(h) + conv1x1(cat(x0, x1)): the channel-changing ResBlock tail in one halo-kernel launch."""
     import torch.nn.functional as F
