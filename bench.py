@@ -61,6 +61,7 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity_paths object (fp16 / fp32 engines + final-latent distances)")
     ap.add_argument("--parity-timed-only", action="store_true", help="parity_paths for the timed engine only (A/B runs)")
+    ap.add_argument("--no-box", action="store_true", help="skip the box-state object (rocm-smi + the 2-second calibration GEMM): profiler runs")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end images/sec pass (prior + denoise + MoVQ + uint8)")
     ap.add_argument("--e2e-images", type=int, default=2, help="images timed by the end-to-end pass (after one untimed image)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-op HIP-event pass (roofline object = null)")
@@ -321,7 +322,7 @@ def run(a):
                        "loop_graph": bool(use_loop) and f"a {Lp}-step loop replayed as ONE hipGraph ({a.steps // Lp} replay(s) = {a.steps} timed steps)"},
             "images_per_sec_denoise_only": round(world * a.bs * a.steps / el / a.sched_steps, 4),
             "finite": finite, "load_s": round(t_load, 1),
-            "gate_holding": gate, "box": box_state(dev),
+            "gate_holding": gate, "box": None if a.no_box else box_state(dev),
             "roofline": roofline, "cpu_baseline": cpu, "parity_paths": parity, "e2e": e2e,
         }
         print(json.dumps(line))

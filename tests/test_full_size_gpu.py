@@ -356,15 +356,15 @@ def test_c3_forward_1024px_batch8(golden_dir, backend):
     assert err <= (2e-4 if backend == torch.float32 else (2e-5 if backend == "f16x3" else BF16_BOUNDS["c3_forward"]["first_forward_rel"])) * scale
 
 
-@pytest.mark.parametrize("backend,tol,tol_rms", [(torch.float32, 1e-3, 1e-5), ("f16x3", 1e-4, 1e-5), ("f16x2", 5e-3, 3e-4)])
+@pytest.mark.parametrize("backend,tol,tol_rms", [(torch.float32, 1e-3, 1e-5), ("f16x3", 1e-4, 1e-5), ("f16x2", 3.5e-3, 2e-4)])
 def test_c3_shard_10_step_loop(golden_dir, backend, tol, tol_rms):
     """Round 5: the sampler at the C3 per-GPU shape (1024x1024, 4 images per GPU -> CFG batch [8,4,128,128]) pinned at LOOP
     level: 10 steps of the reference p_sampler (create_model + SpacedDiffusion.p_sample_loop_progressive with injected noise,
     oracle/make_golden.py --only c3loop), dynamic threshold over 65 536 values per image (gaussian_diffusion.py:284-294).  fp32 / f16x3: the
     north-star class bounds.  f16x2: a 10-step schedule takes steps five times coarser than the 50-step one the 5e-4 gate is stated on, and its
     first step multiplies the eps error by sqrt(1/abar - 1) = 14.5 before the clamp removes it from all but a few pixels - a heavy-tailed
-    distance (measured after step 1: 1.2e-3 max-abs at 4.6e-5 rms; the same ratio, 23, shows at C2) - so its bound here is on the rms, with a
-    max-abs bound that only catches a broken kernel."""
+    distance (measured: after step 1 1.2e-3 max-abs at 4.6e-5 rms - the same ratio, 23, shows at C2 -, after step 5 1.6e-3 / 1.0e-4, FINAL
+    5.0e-4 / 6.7e-5; fp32 engine 1.3e-5, f16x3 6.4e-6) - so its bounds here are 2x those measurements."""
     fx = _load(golden_dir, "c3_loop")
     first, traj = _loop_case(fx, backend)
     scale = fx["first_out"].abs().max().item()

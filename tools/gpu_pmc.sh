@@ -8,7 +8,7 @@ REPO=$PWD
 for CTR in FETCH_SIZE WRITE_SIZE; do
   OUT=$REPO/gpurun_out/pmc_${TAG}_$CTR
   rm -rf $OUT
-  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d $OUT -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-parity --no-e2e > $REPO/gpurun_out/bench_pmc_${TAG}_$CTR.log 2>&1 )
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d $OUT -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-parity --no-e2e --no-box > $REPO/gpurun_out/bench_pmc_${TAG}_$CTR.log 2>&1 )
   tail -2 $REPO/gpurun_out/bench_pmc_${TAG}_$CTR.log | cut -c1-300
   find $OUT -name "*.csv" | head
 done

@@ -12,7 +12,7 @@ for SET in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_ACTIVE_
   i=$((i+1))
   OUT=$REPO/gpurun_out/pmc_${TAG}_$i
   rm -rf $OUT
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-parity --no-e2e --no-loop-graph $EXTRA > $REPO/gpurun_out/pmc_${TAG}_$i.log 2>&1 )
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-parity --no-e2e --no-box --no-loop-graph $EXTRA > $REPO/gpurun_out/pmc_${TAG}_$i.log 2>&1 )
   tail -1 $REPO/gpurun_out/pmc_${TAG}_$i.log | cut -c1-160
 done
 python - "$REPO/gpurun_out" "$TAG" "$EXTRA" > gpurun_out/pmc_${TAG}_summary.txt <<'PY'

@@ -8,7 +8,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/rocprof_$TAG
 rm -rf $OUT
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python $OLDPWD/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-parity --no-e2e $EXTRA > $OLDPWD/gpurun_out/bench_prof_$TAG.log 2>&1 )
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python $OLDPWD/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-parity --no-e2e --no-box $EXTRA > $OLDPWD/gpurun_out/bench_prof_$TAG.log 2>&1 )
 tail -1 gpurun_out/bench_prof_$TAG.log | cut -c1-600
 F=$(find $OUT -name "*kernel_stats.csv" | head -1)
 echo "stats file: $F"
