@@ -56,11 +56,11 @@ const char* k22_last_error(void);
  * k22_conv3x3*, k22_groupnorm) and must not be changed while another thread is inside any k22_* call.  Leave them at their defaults
  * in a process that runs engines (k22_unet_*, k22_prior_*, k22_movq_*, k22_encoder_*): engine launches carry the configuration of their
  * tile-table line, but a line that says "generic kernel" (algo 0) is dispatched through the same switch these knobs override.
- * Everything else in this header is re-entrant per handle (one handle = one stream at a time).  What is NOT validated is two handles
- * running kernels CONCURRENTLY on two streams of one device: round 4 found one kernel pair (igemm_kernel<16-bit, 128 x 64> beside
- * linear_smallm_kernel) that returned wrong elements when co-resident and could not explain it (profiles/r04_chains_root_cause.txt);
- * the parity suite, the bench and every engine of this library run one stream at a time.  Serialise engines on one device (or give
- * each its own device) until that finding is closed - INTEGRATION.md G.
+ * Everything else in this header is re-entrant per handle (one handle = one stream at a time).  Two handles on two streams of one
+ * device: round 4 found a kernel pair (igemm_kernel<16-bit, 128 x 64> beside linear_smallm_kernel) in which the co-resident victim
+ * returned wrong elements; round 5 narrowed it to the victim's packed-fp32 VALU instructions (clean in 900 of 900 launches without
+ * them, profiles/r05_two_stream_probe.txt), and the library is built without that instruction class since (csrc/Makefile: NOPK).
+ * The parity suite and the bench still run one stream at a time: concurrent engines are exercised by that probe only - INTEGRATION.md G.
  * Knobs: "igemm_stages" = 2..4 LDS-DMA pipeline depth (-1 default);
  * "igemm_xcd_remap" = 0/1 XCD-aware workgroup renumbering; "conv_algo" = 0 auto, 1 generic implicit GEMM,
  * 2 LDS-resident halo kernel for the 3x3 convolutions (3-7: its variants, see conv3_halo.hip; 8-9: measurement only);

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libk22hip.so")
+LIB_PATH = os.environ.get("K22_LIB_PATH") or os.path.join(_HERE, "libk22hip.so")   # K22_LIB_PATH: developer knob (A/B of two builds)
 # conv / GEMM tile configurations measured once on an MI355X for the shapes of BASELINE.json's configs (csrc/tuning.h):
 # loaded when the library is opened so that those shapes run the same configurations - the same bits - on every box.
 # K22_TILE_TABLE=<file> substitutes another table, K22_TILE_TABLE=0 starts with an empty one.
