@@ -59,8 +59,9 @@ const char* k22_last_error(void);
  * Everything else in this header is re-entrant per handle (one handle = one stream at a time).  Two handles on two streams of one
  * device: round 4 found a kernel pair (igemm_kernel<16-bit, 128 x 64> beside linear_smallm_kernel) in which the co-resident victim
  * returned wrong elements; round 5 narrowed it to the victim's packed-fp32 VALU instructions (clean in 900 of 900 launches without
- * them, profiles/r05_two_stream_probe.txt), and the library is built without that instruction class since (csrc/Makefile: NOPK).
- * The parity suite and the bench still run one stream at a time: concurrent engines are exercised by that probe only - INTEGRATION.md G.
+ * them, profiles/r05_two_stream_probe.txt).  A host that overlaps engines on one device builds the library with `make NOPK=1` (no
+ * packed-fp32 instruction in any kernel; results move by an ulp or two and the step is ~2 % slower, so it is not the default); the
+ * default build, the parity suite and the bench run one stream at a time - INTEGRATION.md G.
  * Knobs: "igemm_stages" = 2..4 LDS-DMA pipeline depth (-1 default);
  * "igemm_xcd_remap" = 0/1 XCD-aware workgroup renumbering; "conv_algo" = 0 auto, 1 generic implicit GEMM,
  * 2 LDS-resident halo kernel for the 3x3 convolutions (3-7: its variants, see conv3_halo.hip; 8-9: measurement only);
