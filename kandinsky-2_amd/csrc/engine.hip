@@ -135,10 +135,9 @@ struct K22UNet {
   }
   const float* Wf(const std::string& name) { return reinterpret_cast<const float*>(W_(name)); }
 
-  // (Round 4's "two half-batch chains" mode - the CFG pair as two engines on two streams, +3.9 % - is gone: one kernel pair of it,
-  // linear_smallm_kernel beside igemm_kernel<16-bit, 128 x 64> on another stream, returned wrong elements and was never explained
-  // (profiles/r04_chains_root_cause.txt); a mode that needs a work-around for an unexplained wrong result does not ship.  See
-  // INTEGRATION.md G for what that finding means for a host that overlaps two engines itself.)
+  // (Round 4's "two half-batch chains" mode - the CFG pair as two engines on two streams, +3.9 % - is gone: it rested on a work-around for
+  // a kernel pair whose co-resident victim returned wrong elements.  Round 5 narrowed that to the victim's packed-fp32 instructions
+  // (profiles/r05_two_stream_probe.txt; `make NOPK=1` builds the library without them): INTEGRATION.md G.)
   // the [B][out_channels][HW] model output
   float* model_out() { return ptr<float>(s_out); }
   int exec(hipStream_t st) { return run_ops(st); }

@@ -715,3 +715,54 @@ def test_x2_precision_plan_follows_the_operand_rounding_ablation(golden_dir):
     assert w12["first_forward_rms"] ** 2 < 1.1 * base["first_forward_rms"] ** 2
     f12 = next(r for r in ab["final_runs"] if "w@12+s@12" in r["mode"] and "w@24" not in r["mode"])
     assert f12["final_max_abs"] < 5e-4 and f12["final_rms"] ** 2 > 1.4 * ab["gpu_measured_plans_c2"]["0"]["rms"] ** 2
+
+
+# ---- static audit of the built library (round 5): what DESIGN.md says about registers is checked on the code objects themselves ----------
+def _kernel_metadata(tmp_path):
+    """name -> {vgpr, agpr, sgpr, scratch, lds} of every kernel in libk22hip.so (the gfx950 code objects inside its fat binary, extracted with
+    llvm-objdump --offloading from a COPY of the library; metadata notes read with llvm-readelf)."""
+    import glob
+    import re
+    import shutil
+    import subprocess
+    from kandinsky2_amd import _lib
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(_lib.LIB_PATH) and os.path.exists(llvm + "/llvm-objdump")):
+        pytest.skip("library or llvm tools not present")
+    so = str(tmp_path / "lib.so")
+    shutil.copy(_lib.LIB_PATH, so)
+    subprocess.run([llvm + "/llvm-objdump", "--offloading", so], check=True, capture_output=True, cwd=str(tmp_path))
+    out = {}
+    for co in sorted(glob.glob(so + ".*gfx950")):
+        notes = subprocess.run([llvm + "/llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
+        for blk in notes.split("  - .agpr_count:")[1:]:
+            def g(key):
+                m = re.search(r"\." + key + r":\s+(\S+)", blk)
+                return m.group(1) if m else None
+            name = g("name")
+            if name:
+                out[name] = dict(agpr=int(blk.split()[0]), vgpr=int(g("vgpr_count")), sgpr=int(g("sgpr_count")),
+                                 scratch=int(g("private_segment_fixed_size")), lds=int(g("group_segment_fixed_size")))
+    return out
+
+
+def test_no_kernel_of_the_library_spills_and_the_register_claims_hold(tmp_path):
+    """A spilled MFMA kernel still passes parity and loses 2x (MI355X_MICROARCH.md: spills at 512 registers per SIMD lane, i.e. 256 per wave
+    of a 512-thread workgroup).  Asserted on the shipped binary: (1) NO kernel uses scratch; (2) the 512-thread convolution / GEMM kernels
+    fit two waves per SIMD (<= 256 VGPR + AGPR); (3) the asymmetric split's two-set fragment pipeline exists at BM = 256 (its activation
+    fragments are 4 registers) - the instantiation the x3 arithmetic cannot have; (4) attention keeps two workgroups per CU."""
+    md = _kernel_metadata(tmp_path)
+    assert len(md) > 400, len(md)
+    spilled = {k: v["scratch"] for k, v in md.items() if v["scratch"]}
+    assert not spilled, spilled
+    big = {k: v for k, v in md.items() if any(t in k for t in ("conv3_halo_spec_kernel", "conv3_halo_kernel", "conv3_halo3_kernel", "gemm8_kernel"))}
+    assert len(big) > 100
+    over = {k: v["vgpr"] + v["agpr"] for k, v in big.items() if v["vgpr"] + v["agpr"] > 256}
+    assert not over, over
+    x2_pipe_256 = [k for k in md if "conv3_halo_spec_kernelI4x2_tLi256E" in k and "Lb1E" in k]
+    x3_pipe_256 = [k for k in md if "conv3_halo_spec_kernelI4x3_tLi256E" in k and "Lb1E" in k]
+    assert len(x2_pipe_256) == 4 and not x3_pipe_256
+    for k in x2_pipe_256:
+        assert 200 <= md[k]["vgpr"] <= 256
+    att = {k: v for k, v in md.items() if "attention_kernel" in k and "enc_" not in k}
+    assert len(att) == 5 and all(v["vgpr"] + v["agpr"] <= 256 for v in att.values())
