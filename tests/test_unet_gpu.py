@@ -13,7 +13,7 @@ import pytest
 import torch
 
 import kandinsky2_amd as k22
-from oracle import diffusion_ref, unet_ref
+from oracle import unet_ref
 
 pytestmark = pytest.mark.gpu
 

@@ -1,9 +1,8 @@
-"""us per k22_sampler_step (x0 + exact 99.5th-percentile threshold + final) at the C2 latent shape, and exactness of the threshold against
-numpy on adversarial key distributions (many equal keys, one binade, tiny / huge values)."""
+"""us per k22_sampler_step (x0 + exact 99.5th-percentile threshold + final) at the C2 latent shape.  (Exactness of the threshold on
+adversarial key distributions is a test: tests/test_sampler_gpu.py.)"""
 import os
 import sys
 
-import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

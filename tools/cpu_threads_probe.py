@@ -4,7 +4,7 @@ import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import kandinsky2_amd as k22
-from oracle import diffusion_ref, unet_ref
+from oracle import unet_ref
 arch = k22.make_arch(k22.MODEL_CONFIG_2_1)
 sd = k22.init_unet_state_dict(arch, seed=0)
 B, lat = 2, 32

@@ -6,7 +6,7 @@ import os, sys, ctypes as C
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import kandinsky2_amd as k22
+import kandinsky2_amd as k22  # noqa: F401  (puts the package on the path for _lib)
 from kandinsky2_amd import _lib
 from kandinsky2_amd.pack import to_x3
 import helpers as hp
@@ -91,7 +91,6 @@ def sentinel(nbytes, name, fn):
     if n:
         recs = r[1: 1 + 4 * min(n, 255)].reshape(-1, 4)
         offs = recs[:, 1]
-        import numpy as np
         vals = recs[:12, 2].copy().view("float32")
         line += f"  offsets {int(offs.min())}..{int(offs.max())}  first (wg, off, value-as-f32/hex, spin): " + ", ".join(f"({a},{b},{v:.4g}/{c:08x},{d})" for (a, b, c, d), v in zip(recs[:12].tolist(), vals.tolist()))
     print(line, flush=True)
