@@ -716,7 +716,7 @@ struct K22UNet {
 
   // Text2ImUNet.get_text_emb (text2im_model2_1.py:57-80), pooling_type == "from_model".
   void build_cond_ops() {
-    const int mc = cfg.model_channels, ted = 4 * mc, Bn = B, dt = sdt, adt = dtype;
+    const int mc = cfg.model_channels, ted = 4 * mc, Bn = B, dt = sdt;
     const int nie = cfg.n_image_embs, cd = cfg.ctx_dim, S = cfg.ctx_len, ntext = S - nie;
     const float* w_cs = Wf("clip_to_seq.weight"); const float* b_cs = Wf("clip_to_seq.bias");
     const float* w_pn = Wf("proj_n.weight"); const float* b_pn = Wf("proj_n.bias");

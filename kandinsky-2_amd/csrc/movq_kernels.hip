@@ -266,7 +266,7 @@ int launch_movq_quant_conv(const float* h, const float* wq, const float* bq, flo
 int launch_spatialnorm_apply(const SpatialNormParams& p, int dtype, hipStream_t s) {
   const int epv = dtype == K22_F32 ? 4 : 8;
   if (p.C % epv) return k22_set_error(K22_EINVAL, "spatialnorm: channel alignment");
-  const int Hp = p.H + 2 * p.pad, Wp = p.W + 2 * p.pad;
+  const int Hp = p.H + 2 * p.pad;
   if (Hp > 65535 || p.B > 65535) return k22_set_error(K22_EINVAL, "spatialnorm: tensor too large");
   const int R = p.shift >= 3 ? 8 : (1 << p.shift);
   if (p.shift < 0 || (p.W >> p.shift) > p.w0 || (p.H >> p.shift) > p.h0 || (p.W & ((1 << p.shift) - 1)))
