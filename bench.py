@@ -15,7 +15,7 @@ packed arena before the timed region; value = images-steps per second over all r
 
 Extra objects on the JSON line: "roofline" (dominant kernel = implicit-GEMM conv3x3, MFMA-bound; measured
 with HIP events around every engine op on the launch stream), "cpu_baseline" (the CPU oracle, i.e. the
-restated reference algorithm in PyTorch fp32, timed on this box's host cores on a bounded sample),
+restated reference algorithm in PyTorch fp32, timed on this box's host cores on a bounded sample; N = 1 only),
 "parity_paths" (N = 1, default workload: steps/s of the fp16 and fp32 engines next to the timed dtype, each with the
 distance of ITS 50-step final latent from the committed reference golden tests/golden/c2_text2img.pt - the number that is
 timed and the number that has parity, side by side) and "e2e" (images/sec of Kandinsky2_1HIP.generate_text2img: prior 25
@@ -284,7 +284,7 @@ def run(a):
             except Exception as e:  # the bench line must come out whatever happens in the side measurements
                 print(f"bench: profile pass failed: {e}", file=sys.stderr)
         cpu = None
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:      # the contract: rank 0 at N = 1 only (at N > 1 the other ranks would wait in the final barrier)
             try:
                 cpu = cpu_baseline(arch, sd, a, B)
             except Exception as e:
