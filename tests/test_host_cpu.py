@@ -771,3 +771,29 @@ def test_no_kernel_of_the_library_spills_and_the_register_claims_hold(tmp_path):
         assert 200 <= md[k]["vgpr"] <= 256
     att = {k: v for k, v in md.items() if "attention_kernel" in k and "enc_" not in k}
     assert len(att) == 5 and all(v["vgpr"] + v["agpr"] <= 256 for v in att.values())
+
+
+def test_isa_mix_tool_counts_a_synthetic_loop():
+    """tools/isa_mix.py (the static instruction-mix report of profiles/r05_isa_mix.txt): loop detection through the `<kernel+0xOFF>` branch
+    targets and the cycle tables, on a hand-made body."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_mix", os.path.join(ROOT, "tools", "isa_mix.py"))
+    im = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(im)
+    body = [(0x100, "s_load_dwordx2", "s[0:1], s[4:5], 0x0"),
+            (0x108, "ds_read_b128", "v[0:3], v9"),                        # loop head
+            (0x110, "ds_read2st64_b64", "v[4:7], v9 offset1:8"),
+            (0x118, "s_waitcnt", "lgkmcnt(0)"),
+            (0x11c, "v_mfma_f32_32x32x16_bf16", "v[10:25], v[0:3], v[4:7], v[10:25]"),
+            (0x124, "v_mov_b32_e32", "v0, v4"),
+            (0x128, "v_mfma_f32_16x16x32_f16", "v[26:29], v[0:3], v[4:7], v[26:29]"),
+            (0x130, "s_barrier", ""),
+            (0x134, "s_cbranch_scc1", "65524 <k+0x8>"),
+            (0x138, "s_endpgm", "")]
+    assert im.loops_of(body) == [(1, 8)]
+    c, cyc, kinds = im.mix(body, 1, 8)
+    assert c["mfma"] == 2 and cyc["mfma"] == 32 + 16
+    assert cyc["lds"] == 4 + 8 and c["ds_read"] == 2          # ds_read_b128: 4 LDS cycles; ds_read2 of 8-byte words: 8
+    assert c["valu_mov"] == 1 and cyc["valu"] == 4 and c["s_barrier"] == 1 and c["s_waitcnt"] == 1
+    assert im.lds_cycles("ds_write_b128") == 13 and im.lds_cycles("ds_read_b64") == 2 and im.lds_cycles("ds_read_b64_tr_b16") == 2
+    assert im.classify("global_load_lds_dwordx4") == "lds_dma" and im.classify("global_load_dwordx4") == "vmem_load"

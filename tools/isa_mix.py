@@ -87,7 +87,7 @@ def lds_cycles(mn):
     m = re.search(r"_(b128|b96|b64|b32)", mn)
     tab = LDS_WRITE if ("write" in mn or "store" in mn) else LDS_READ
     w = tab.get(m.group(1), 2) if m else 2            # sub-dword and atomic forms: counted as one 4-byte access
-    if re.search(r"(read|load)2_b64", mn):
+    if re.search(r"(read|load)2(st64)?_b64", mn):
         return 8
     return 2 * w if re.search(r"(read|write|load|store)2", mn) else w
 
