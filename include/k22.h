@@ -298,6 +298,30 @@ int k22_qkv_project_stream(const void* x, const void* Wp, const float* bias, voi
 int k22_linear_smallm(const float* x, const void* W, const float* bias, const float* add, float* out, int M, int N,
                       int K, int act_in, int act_out, int wdtype, void* stream);
 
+/* ---- skinny-M weight-streaming GEMM family (round 6; csrc/skinny.hip) - unit-parity surface of the kernels the prior engine's
+ * 16-bit path is made of.  Replaces nn.Linear c_qkv / c_proj / c_fc / mlp.c_proj (kandinsky2/model/prior.py:57-83), the LayerNorm in
+ * front of each (prior.py:48-54, 105-127) and QKVMultiheadAttention (prior.py:86-102) for M = a few hundred token rows.  Both GEMM
+ * operands are FRAGMENT-MAJOR (1 KB contiguous per 32-row x 16-k MFMA fragment): weights [Npad/32][K/64][4][64][8] written by
+ * k22_stream_repack(W, out, Npad, 1, K, ...); activations [K/64][ceil(M/32)][4][64][8] written by k22_afrag_pack (row-major in), by
+ * k22_finish_ln, by k22_skinny_gemm with epi = 1, or by k22_small_attention with out_frag = 1.  dtype: K22_BF16 / K22_F16.
+ *   k22_skinny_gemm: epi 0 -> out[m*ldo + n] = act(A.W^T + bias) in T;  epi 1 -> the same values in the A-fragment order of a consumer
+ *     whose K is this N;  epi 2 -> fp32 partial[z][m][n], z < splitk (no bias / activation);  (mt, nb) = m-atoms x n-atoms of 32 per
+ *     workgroup, one of (6,1) (3,2) (3,1) (2,2) (2,1) (1,2); 0,0 = default.
+ *   k22_finish_ln: x[m][:] += bias + sum_z partial[z][m][:] (skipped when partial == NULL), then yfrag = LayerNorm(x[m][:]) * gain +
+ *     beta in T, A-fragment order (skipped when gain == NULL).  N <= 2048.
+ *   k22_small_attention: qkv [B*T][3*H*64] = [Q | K | V] x [H][64] row-major T -> softmax(q.k / 8 + mask) v, T <= 128 tokens;
+ *     mask = causal (key <= query) and key_valid [B][kv_n] (0 = padding key; keys >= kv_n are valid), as prior.py:262-263.
+ *     qkv_partial != NULL: qkv is instead T(qkv_bias + sum_s qkv_partial[s][B*T][3*H*64]), s < nsplit <= 4 - the finish of a split-K
+ *     c_qkv launch (k22_skinny_gemm epi 2) folded into the attention's staging loads. */
+size_t k22_afrag_bytes(int M, int K);
+int k22_afrag_pack(const void* A, long lda, void* out, int M, int K, int dtype, void* stream);
+int k22_skinny_gemm(const void* Afrag, const void* Wfrag, const float* bias, void* out, float* partial, int M, int N, int Npad, int K,
+                    int splitk, int epi, int act, int ldo, int mt, int nb, int dtype, void* stream);
+int k22_finish_ln(const float* partial, int splitk, const float* bias, float* x, long ldx, const float* gain, const float* beta, void* yfrag,
+                  int M, int N, float eps, int dtype, void* stream);
+int k22_small_attention(const void* qkv, const float* qkv_partial, int nsplit, const float* qkv_bias, void* out, int out_frag, int B, int H, int T,
+                        int causal, const float* key_valid, int kv_n, int dtype, void* stream);
+
 /* ---- diffusion prior ----------------------------------------------------------------------------
  * Replaces PriorTransformer.forward (kandinsky2/model/prior.py:226-270) and the per-step update of
  * PriorDiffusionModel.forward's sampling loop (prior.py:336-384; gaussian_diffusion.py:223-322, 352-382 with

@@ -94,6 +94,11 @@ SIGNATURES = {
     "k22_unet_set_autotune": (_I, [_P, _I]),
     "k22_unet_tuning_report": (_I, [_P, C.c_char_p, _Z]),
     "k22_unet_profile": (_I, [_P, _I, C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), C.POINTER(_I), _P]),
+    "k22_afrag_bytes": (_Z, [_I, _I]),
+    "k22_afrag_pack": (_I, [_P, _L, _P, _I, _I, _I, _P]),
+    "k22_skinny_gemm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "k22_finish_ln": (_I, [_P, _I, _P, _P, _L, _P, _P, _P, _I, _I, _F, _I, _P]),
+    "k22_small_attention": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
     "k22_prior_create": (_I, [C.POINTER(K22PriorConfig), C.POINTER(K22Weight), _I, C.POINTER(_P)]),
     "k22_prior_destroy": (None, [_P]),
     "k22_prior_plan": (_I, [_P, _I, C.POINTER(_Z)]),

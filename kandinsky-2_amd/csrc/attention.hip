@@ -289,6 +289,163 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttentionParams p) {
   }
 }
 
+// ---- small-T attention of the prior transformer (QKVMultiheadAttention, kandinsky2/model/prior.py:86-102) ---------------------------
+// T <= 128 tokens (the prior: 81), one workgroup per (head, image), every key in ONE tile: no online rescale, no kv_pack pass and no
+// per-score global mask loads.  q / k / v are read straight from the c_qkv output  qkv[B * T][ldq] = [Q | K | V] x [head][64]  (row-major,
+// written by the skinny GEMM); K goes to the LDS as rows, V transposed, the additive mask of prior.py:262-263 (-inf for padding keys and
+// for keys after the query) as one float per key.  Wave w owns queries 32 w .. 32 w + 31; the arithmetic is attention_kernel's (S^T = K Q^T
+// so a lane owns one query, lane-local fp32 softmax, P from the accumulator registers).  The output is written row-major or in the
+// A-fragment order of the skinny GEMM that reads it (c_proj), selected by out_frag.  16-bit storage types.
+template <typename T>
+__global__ __launch_bounds__(256) void small_attention_kernel(SmallAttnParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 16384 + 512];
+  char* Ks = smem;            // [128 keys][128 B]
+  char* Vs = smem + 16384;    // V^T: 2 sub-tiles of [64 d][64 keys]
+  float* kdead = reinterpret_cast<float*>(smem + 32768);   // 1 = padding key
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int hd = blockIdx.x, b = blockIdx.y;
+  const int C = p.H * 64;
+  const T* base = reinterpret_cast<const T*>(p.qkv) + (int64_t)b * p.T * p.ldq + hd * 64;
+  // 8 consecutive values of token `tok` (of image b) at column `col` of this head's Q / K / V plane `which`: the stored T row, or the
+  // finish of c_qkv's split-K partials done here (bias + partials in split order, ONE rounding to T - what a finish launch would store)
+  auto fetch8 = [&](int tok, int which, int col) __attribute__((always_inline)) -> u32x4_t {
+    if (p.part == nullptr) return *reinterpret_cast<const u32x4_t*>(base + (int64_t)tok * p.ldq + which * C + col);
+    const int64_t e = ((int64_t)b * p.T + tok) * p.ldq + which * C + hd * 64 + col, tot = (int64_t)p.B * p.T * p.ldq;
+    float4 q0[4], q1[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int ss = s < p.nsplit ? s : p.nsplit - 1;
+      q0[s] = *reinterpret_cast<const float4*>(p.part + ss * tot + e);
+      q1[s] = *reinterpret_cast<const float4*>(p.part + ss * tot + e + 4);
+    }
+    float4 a0 = q0[0], a1 = q1[0];
+#pragma unroll
+    for (int s = 1; s < 4; ++s)
+      if (s < p.nsplit) {
+        a0.x += q0[s].x; a0.y += q0[s].y; a0.z += q0[s].z; a0.w += q0[s].w;
+        a1.x += q1[s].x; a1.y += q1[s].y; a1.z += q1[s].z; a1.w += q1[s].w;
+      }
+    if (p.bias != nullptr) {
+      const float* bp = p.bias + which * C + hd * 64 + col;
+      const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
+      a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
+      a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+    }
+    return u32x4_t{pack2<T>(a0.x, a0.y), pack2<T>(a0.z, a0.w), pack2<T>(a1.x, a1.y), pack2<T>(a1.z, a1.w)};
+  };
+  // this wave's queries: loaded before the staging barrier so that their latency hides behind it
+  const int t = wave * 32 + l31;
+  const int tq = t < p.T ? t : p.T - 1;
+  Frag<T> qf[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) qf[a].v = fetch8(tq, 0, 16 * a + 8 * h);
+  // K rows / V^T columns: 128 keys x 8 chunks of 16 bytes; keys >= T are zero (their scores are masked; zero keeps 0 * V finite)
+  for (int i = tid; i < 128 * 8; i += 256) {
+    const int key = i >> 3, c = i & 7;
+    u32x4_t kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+    if (key < p.T) {
+      kv = fetch8(key, 1, c * 8);
+      vv = fetch8(key, 2, c * 8);
+    }
+    *reinterpret_cast<u32x4_t*>(Ks + lds_chunk_off(key, c)) = kv;
+    const unsigned short* ve = reinterpret_cast<const unsigned short*>(&vv);
+    char* vsub = Vs + (key >> 6) * 8192;
+    const int kk = key & 63;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) *reinterpret_cast<unsigned short*>(vsub + lds_chunk_off(c * 8 + e, kk >> 3) + (kk & 7) * 2) = ve[e];
+  }
+  if (tid < 128) kdead[tid] = (p.key_valid != nullptr && tid < p.kv_n && p.key_valid[(int64_t)b * p.kv_ld + tid] == 0.f) ? 1.f : 0.f;
+  __syncthreads();
+  if (wave * 32 >= p.T) return;   // uniform per wave; no barrier below
+  const int nkb = (p.T + 31) >> 5;   // 32-key blocks (<= 4)
+  f32x16_t s[4];
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+    if (kb < nkb) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        Frag<T> kf;
+        ld_frag(kf, Ks, kb * 32 + l31, a, h);
+        mma_atom(s[kb], kf, qf[a]);
+      }
+    }
+  }
+  float mloc = -INFINITY;
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kb * 32 + c_row(r, lane);
+      const bool dead = key >= p.T || (p.causal && key > t) || kdead[key & 127] != 0.f;
+      s[kb][r] = dead ? -INFINITY : s[kb][r];
+      mloc = fmaxf(mloc, s[kb][r]);
+    }
+  mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+  const float cexp = p.scale * 1.4426950408889634f;
+  const float mc = mloc * cexp;
+  float pv[4][16];
+  float l = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = exp2_t<T>(fmaf(s[kb][r], cexp, -mc));
+      pv[kb][r] = e;
+      l += e;
+    }
+  l += __shfl_xor(l, 32, 64);
+  f32x16_t o[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    if (a < 2 * nkb) {
+      Frag<T> pf;
+      make_pfrag(pf, &pv[a >> 1][8 * (a & 1)]);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        Frag<T> vf;
+        ld_frag_split(vf, Vs + (a >> 2) * 8192, db * 32 + l31, a & 3, h);
+        mma_atom(o[db], vf, pf);
+      }
+    }
+  }
+  if (t >= p.T) return;
+  const float inv = 1.f / l;
+  const int m = b * p.T + t;
+  T* out = reinterpret_cast<T*>(p.out);
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d = db * 32 + 8 * g + 4 * h;
+      uint2 w2;
+      w2.x = pack2<T>(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
+      w2.y = pack2<T>(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+      if (p.out_frag) {
+        const int k = hd * 64 + d;   // K index of the consumer GEMM: [K / 64][MA][4][64][8]
+        const int64_t off = ((((int64_t)(k >> 6) * p.MA + (m >> 5)) * 4 + ((k >> 4) & 3)) * 64 + (m & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7);
+        *reinterpret_cast<uint2*>(out + off) = w2;
+      } else {
+        *reinterpret_cast<uint2*>(out + (int64_t)m * p.ldo + hd * 64 + d) = w2;
+      }
+    }
+}
+
+int launch_small_attention(const SmallAttnParams& p, int dtype, hipStream_t s) {
+  if (p.T < 1 || p.T > 128 || p.H < 1 || p.B < 1 || (p.ldq & 7) || (!p.out_frag && (p.ldo & 3)) || (p.part != nullptr && (p.nsplit < 1 || p.nsplit > 4)))
+    return k22_set_error(K22_EINVAL, "small_attention: 1 <= T <= 128, 64 channels per head, 16-byte aligned rows");
+  dim3 grid(p.H, p.B);
+  if (dtype == K22_BF16) hipLaunchKernelGGL(small_attention_kernel<bf16_t>, grid, dim3(256), 0, s, p);
+  else if (dtype == K22_F16) hipLaunchKernelGGL(small_attention_kernel<f16_t>, grid, dim3(256), 0, s, p);
+  else return k22_set_error(K22_EINVAL, "small_attention: 16-bit storage types only");
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+
 int launch_attention(const AttentionParams& p, int dtype, hipStream_t s) {
   if (p.Tkp % 64 || p.Tkp < p.Tk) return k22_set_error(K22_EINVAL, "attention: Tkp must be roundup(Tk,64)");
   dim3 grid((p.T + 127) / 128, p.H, p.B);

@@ -3,6 +3,7 @@
 #include "elementwise.h"
 #include "../../include/k22.h"
 #include "tuning.h"
+#include "skinny.h"
 #include <dlfcn.h>
 #include <stdio.h>
 #include <string.h>
@@ -334,6 +335,34 @@ int k22_qkv_project_stream(const void* x, const void* Wp, const float* bias, voi
   if (!stream_supported(p, dtype, bm == 288 ? 9 : 5)) return k22_set_error(K22_EINVAL, "qkv_project_stream: unsupported problem");
   K22_DBG_FRAG(p);
   return launch_igemm(p, dtype, reinterpret_cast<hipStream_t>(stream));
+}
+
+// ---- skinny-M weight-streaming GEMM family (skinny.hip, small_attention_kernel): unit-parity surface -------------------------------
+size_t k22_afrag_bytes(int M, int K) { return afrag_bytes(M, K); }
+int k22_afrag_pack(const void* A, long lda, void* out, int M, int K, int dtype, void* stream) {
+  return launch_afrag_pack(A, lda, out, M, K, dtype, reinterpret_cast<hipStream_t>(stream));
+}
+int k22_skinny_gemm(const void* Afrag, const void* Wfrag, const float* bias, void* out, float* partial, int M, int N, int Npad, int K,
+                    int splitk, int epi, int act, int ldo, int mt, int nb, int dtype, void* stream) {
+  SkinnyParams q = {};
+  q.Af = Afrag; q.Wf = Wfrag; q.bias = bias; q.out = out; q.partial = partial; q.M = M; q.N = N; q.Npad = Npad; q.K = K; q.MA = (M + 31) / 32;
+  q.splitk = splitk > 0 ? splitk : 1; q.epi = epi; q.act = act; q.ldo = ldo;
+  q.trace = reinterpret_cast<unsigned long long*>(g_dbg_scratch);   // K22_SKINNY_DEBUG builds: stamps go to the debug scratch (k22_debug_set_stream_scratch)
+  return launch_skinny(q, dtype, mt, nb, reinterpret_cast<hipStream_t>(stream));
+}
+int k22_finish_ln(const float* partial, int splitk, const float* bias, float* x, long ldx, const float* gain, const float* beta, void* yfrag,
+                  int M, int N, float eps, int dtype, void* stream) {
+  FinishLnParams q = {};
+  q.partial = partial; q.splitk = splitk; q.bias = bias; q.x = x; q.ldx = ldx; q.g = gain; q.b = beta; q.yfrag = yfrag; q.M = M; q.N = N;
+  q.MA = (M + 31) / 32; q.eps = eps;
+  return launch_finish_ln(q, dtype, reinterpret_cast<hipStream_t>(stream));
+}
+int k22_small_attention(const void* qkv, const float* qkv_partial, int nsplit, const float* qkv_bias, void* out, int out_frag, int B, int H, int T,
+                        int causal, const float* key_valid, int kv_n, int dtype, void* stream) {
+  SmallAttnParams ap = {};
+  ap.qkv = qkv; ap.part = qkv_partial; ap.nsplit = nsplit; ap.bias = qkv_bias; ap.ldq = 3 * H * 64; ap.out = out; ap.ldo = H * 64; ap.out_frag = out_frag; ap.MA = (B * T + 31) / 32;
+  ap.B = B; ap.H = H; ap.T = T; ap.scale = 0.125f; ap.causal = causal; ap.key_valid = key_valid; ap.kv_ld = kv_n; ap.kv_n = kv_n;
+  return launch_small_attention(ap, dtype, reinterpret_cast<hipStream_t>(stream));
 }
 
 int k22_linear_smallm(const float* x, const void* W, const float* bias, const float* add, float* out, int M, int N,

@@ -88,6 +88,16 @@ __device__ __forceinline__ float silu_fast(float x) { return silu_f(x); }
 __device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }
 #endif
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// GELU with erfc from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute) on the native rcp / exp2: ~15 instructions where erff costs
+// ~90 with divergent branches.  GELU's error is <= 0.75e-7 |x| - three orders below the fp16 / bf16 rounding of the value it is used for
+// (the 16-bit epilogues of the skinny GEMM, skinny.hip); 1 + erf is formed without cancellation on the negative side.
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float q = poly * __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);   // erfc(z)
+  return x >= 0.f ? x * fmaf(-0.5f, q, 1.0f) : x * (0.5f * q);
+}
 __device__ __forceinline__ float apply_act(float x, int act) {
   if (act == K22_ACT_SILU) return silu_f(x);
   if (act == K22_ACT_GELU) return gelu_f(x);

@@ -67,6 +67,17 @@ struct AttentionParams {
   int kv_ld, kv_n;
   int out_x3;                   // K22_F16X3 only: write `out` in x3 chunks (common.h) - the operand format of the GEMM that reads it
 };
+// small-T attention of the prior transformer (attention.hip: small_attention_kernel)
+struct SmallAttnParams {
+  const void* qkv; int64_t ldq;   // [B * T][ldq] = [Q | K | V] x [H][64] (row-major, c_qkv output with Q | K | V planes)
+  const float* part; int nsplit; const float* bias;   // part != null: qkv = T(bias + sum_s part[s][B * T][ldq]) instead (c_qkv's fp32 split-K partials, nsplit <= 4)
+  void* out; int64_t ldo;         // row-major [B * T][ldo] (out_frag == 0) or the A-fragment order of a skinny GEMM with K = H * 64
+  int out_frag, MA;               // MA = ceil(B * T / 32) m-atoms of the fragment tensor
+  int B, H, T;
+  float scale;
+  int causal;
+  const float* key_valid; int kv_ld, kv_n;   // as AttentionParams
+};
 struct SamplerParams {
   const float* x;          // [N][4][HW] current latent (fp32 NCHW)
   const float* model_out;  // [N][8][HW] raw UNet output (before classifier-free guidance)
@@ -99,6 +110,7 @@ int launch_layernorm_f32(const float* x, const float* g, const float* b, float* 
 int launch_cast_rows(const float* x, void* y, int rows, int cols, int64_t ldx, int64_t ldy, int dtype, hipStream_t s);
 int launch_kv_pack(const KvPackParams& p, int dtype, hipStream_t s);
 int launch_attention(const AttentionParams& p, int dtype, hipStream_t s);
+int launch_small_attention(const SmallAttnParams& p, int dtype, hipStream_t s);
 int launch_sampler_step(const SamplerParams& p, hipStream_t s);
 int launch_plms_step(const float* x, const float* model_out, const float* h1, const float* h2, const float* h3, int order, const float* tab,
                      float guidance, int use_cfg, float* x_out, float* e_store, float* x0_out, int N, int HW, hipStream_t s);

@@ -14,7 +14,9 @@
 #include "elementwise.h"
 #include "../../include/k22.h"
 #include "tuning.h"
+#include "skinny.h"
 
+#include <algorithm>
 #include <deque>
 #include <functional>
 #include <string>
@@ -94,6 +96,12 @@ struct K22Prior {
   std::string err;
   PSlot *s_x, *s_t, *s_temb, *s_te1, *s_txtemb, *s_txtenc, *s_txtencT, *s_valid, *s_mask, *s_inp, *s_ln, *s_qkv, *s_att, *s_fc,
       *s_lnlast, *s_out, *s_splitk, *s_flush, *s_kall, *s_vtall;
+  // skinny path (round 6; skinny.hip): 16-bit engines run the transformer through the fragment-major weight-streaming GEMM, the fused
+  // split-K finish + LayerNorm and the small-T attention: 7 launches per layer instead of 12.  K22_PRIOR_SKINNY=0 keeps the old path.
+  bool skinny = false;
+  bool wfrag_done = false;
+  struct WFrag { const void* src; PSlot* dst; int Npad, K; };
+  std::vector<WFrag> wfrags;   // fragment-major copies of the transformer weights, written into the workspace once per bind
 
   PSlot* new_slot(size_t bytes = 0) { slots.emplace_back(); slots.back().bytes = bytes; return &slots.back(); }
   static void need(PSlot* s, size_t bytes) { if (bytes > s->bytes) s->bytes = bytes; }
@@ -142,9 +150,43 @@ struct K22Prior {
     });
   }
 
+  // fragment-major copy of a transformer weight [Npad][K] (slot in the workspace, repacked at the first forward after a bind)
+  PSlot* wfrag_of(const std::string& name, int N, int K) {
+    const int Npad = (N + 63) / 64 * 64;
+    PSlot* s = new_slot((size_t)Npad * K * esz);
+    wfrags.push_back(WFrag{W_(name), s, Npad, K});
+    return s;
+  }
+  // out = act(A . W^T + bias) through the skinny kernel; epi: SkinnyEpi; partial launches leave [splitk][M][N] in s_splitk
+  void op_skinny(PSlot* a, int M, int N, int K, const std::string& pfx, int act, int epi, int splitk, PSlot* dst, int ldo) {
+    PSlot* wf = wfrag_of(pfx + ".weight", N, K);
+    const float* bias = Wf(pfx + ".bias");
+    if (epi == SK_EPI_PARTIAL) need(s_splitk, (size_t)splitk * M * N * 4);
+    const int dt = dtype;
+    ops.push_back([=](hipStream_t st) {
+      SkinnyParams q = {};
+      q.Af = ptr(a); q.Wf = ptr(wf); q.bias = epi == SK_EPI_PARTIAL ? nullptr : bias; q.out = dst ? ptr(dst) : nullptr; q.partial = ptr<float>(s_splitk);
+      q.M = M; q.N = N; q.Npad = (N + 63) / 64 * 64; q.K = K; q.MA = (M + 31) / 32; q.splitk = splitk; q.epi = epi; q.act = act; q.ldo = ldo;
+      return launch_skinny(q, dt, 0, 0, st);
+    });
+  }
+  // x (+)= bias + sum of the split-K partials in s_splitk (splitk > 0); then LayerNorm `ln` of x into s_ln in A-fragment order (ln non-empty)
+  void op_finish_ln(int M, int N, int splitk, const std::string& bias_name, const std::string& ln) {
+    const float* bias = bias_name.empty() ? nullptr : Wf(bias_name);
+    const float* g = ln.empty() ? nullptr : Wf(ln + ".weight");
+    const float* bb = ln.empty() ? nullptr : Wf(ln + ".bias");
+    const int dt = dtype;
+    ops.push_back([=](hipStream_t st) {
+      FinishLnParams q = {};
+      q.partial = splitk > 0 ? ptr<float>(s_splitk) : nullptr; q.splitk = splitk; q.bias = bias; q.x = ptr<float>(s_inp); q.ldx = N;
+      q.g = g; q.b = bb; q.yfrag = ptr(s_ln); q.M = M; q.N = N; q.MA = (M + 31) / 32; q.eps = 1e-5f;
+      return launch_finish_ln(q, dt, st);
+    });
+  }
+
   int plan(int nB) {
     B = nB;
-    slots.clear(); ops.clear(); err.clear(); ws = nullptr; tuned.clear(); tuned_done = false;
+    slots.clear(); ops.clear(); err.clear(); ws = nullptr; tuned.clear(); tuned_done = false; wfrags.clear(); wfrag_done = false;
     if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
     const int D = cfg.xf_width, nt = cfg.text_ctx, nc = nt + 4, cd = cfg.clip_dim, cw = cfg.clip_xf_width, M = B * nc;
     if (B < 1 || B > 8) return k22_set_error(K22_EINVAL, "prior: batch (2*bs) must be in 1..8 per engine call");
@@ -153,8 +195,13 @@ struct K22Prior {
     s_temb = new_slot((size_t)B * D * 4); s_te1 = new_slot((size_t)B * D * 4);
     s_txtemb = new_slot((size_t)B * cd * 4); s_txtenc = new_slot((size_t)B * nt * cw * 4); s_txtencT = new_slot((size_t)B * nt * cw * esz);
     s_valid = new_slot((size_t)B * nt * 4); s_mask = new_slot((size_t)B * nc * nc * 4);
-    s_inp = new_slot((size_t)M * D * 4); s_ln = new_slot((size_t)M * D * esz); s_qkv = new_slot((size_t)M * 3 * D * esz);
-    s_att = new_slot((size_t)M * D * esz); s_fc = new_slot((size_t)M * 4 * D * esz);
+    {
+      const char* e = getenv("K22_PRIOR_SKINNY");
+      skinny = (!e || atoi(e) != 0) && esz == 2 && D <= 2048 && nc <= 128;
+    }
+    const size_t Mp = (size_t)(M + 31) / 32 * 32;   // the fragment-major tensors hold whole 32-row atoms
+    s_inp = new_slot((size_t)M * D * 4); s_ln = new_slot(Mp * D * esz); s_qkv = new_slot((size_t)M * 3 * D * esz);
+    s_att = new_slot(Mp * D * esz); s_fc = new_slot(Mp * 4 * D * esz);
     s_lnlast = new_slot((size_t)B * D * 4); s_out = new_slot((size_t)B * cd * 4); s_splitk = new_slot(256);
     s_flush = new_slot(autotune ? ((size_t)320 << 20) : 0);
     s_kall = new_slot(); s_vtall = new_slot();
@@ -209,6 +256,35 @@ struct K22Prior {
       });
     }
     // ---- transformer (prior.py:105-155) ------------------------------------------------------------------
+    if (skinny) {
+      // per layer: c_qkv -> attention -> c_proj (split-K partials) -> [finish + residual + ln_2] -> c_fc (+ GELU) -> mlp.c_proj (partials)
+      // -> [finish + residual + next ln_1].  Split-K only where a finish launch runs anyway (N = D: 64-wide n-tiles alone would leave
+      // three quarters of the CUs idle).
+      const int heads = cfg.xf_heads;
+      const int sk_proj = std::max(1, std::min(4, D / 512)), sk_fc2 = std::max(1, std::min(4, 4 * D / 512));
+      static const int sk_qkv_env = [] { const char* e = getenv("K22_PRIOR_QKV_SPLIT"); return e ? atoi(e) : 1; }();   // measured: 1 (profiles/r06_skinny.txt: split 2 of c_qkv 22.4 us against 18.4)
+      const int sk_qkv = std::max(1, std::min(std::min(4, sk_qkv_env), D / 512));
+      op_finish_ln(M, D, 0, "", "transformer.resblocks.0.ln_1");
+      for (int l = 0; l < cfg.xf_layers; ++l) {
+        const std::string pfx = "transformer.resblocks." + std::to_string(l);
+        // c_qkv: split-K partials whose finish (bias, one rounding) rides on the attention's staging loads (sk_qkv = 1: row-major T output)
+        const float* qkv_bias = Wf(pfx + ".attn.c_qkv.bias");
+        if (sk_qkv > 1) op_skinny(s_ln, M, 3 * D, D, pfx + ".attn.c_qkv", K22_ACT_NONE, SK_EPI_PARTIAL, sk_qkv, nullptr, 3 * D);
+        else op_skinny(s_ln, M, 3 * D, D, pfx + ".attn.c_qkv", K22_ACT_NONE, SK_EPI_ROWMAJOR, 1, s_qkv, 3 * D);
+        ops.push_back([=](hipStream_t st) {
+          SmallAttnParams ap = {};
+          ap.qkv = ptr(s_qkv); ap.ldq = 3 * D;
+          if (sk_qkv > 1) { ap.part = ptr<float>(s_splitk); ap.nsplit = sk_qkv; ap.bias = qkv_bias; } ap.out = ptr(s_att); ap.ldo = D; ap.out_frag = 1; ap.MA = (M + 31) / 32;
+          ap.B = Bn; ap.H = heads; ap.T = nc; ap.scale = 0.125f; ap.causal = 1; ap.key_valid = ptr<float>(s_valid); ap.kv_ld = nt; ap.kv_n = nt;
+          return launch_small_attention(ap, dt, st);
+        });
+        op_skinny(s_att, M, D, D, pfx + ".attn.c_proj", K22_ACT_NONE, SK_EPI_PARTIAL, sk_proj, nullptr, D);
+        op_finish_ln(M, D, sk_proj, pfx + ".attn.c_proj.bias", pfx + ".ln_2");
+        op_skinny(s_ln, M, 4 * D, D, pfx + ".mlp.c_fc", K22_ACT_GELU, SK_EPI_AFRAG, 1, s_fc, 4 * D);
+        op_skinny(s_fc, M, D, 4 * D, pfx + ".mlp.c_proj", K22_ACT_NONE, SK_EPI_PARTIAL, sk_fc2, nullptr, D);
+        op_finish_ln(M, D, sk_fc2, pfx + ".mlp.c_proj.bias", l + 1 < cfg.xf_layers ? "transformer.resblocks." + std::to_string(l + 1) + ".ln_1" : std::string());
+      }
+    } else
     for (int l = 0; l < cfg.xf_layers; ++l) {
       const std::string pfx = "transformer.resblocks." + std::to_string(l);
       op_ln(s_inp, 0, D, M, pfx + ".ln_1", s_ln, false);
@@ -297,6 +373,7 @@ int k22_prior_bind(K22Prior* m, void* workspace, size_t workspace_bytes) {
   if (workspace_bytes < m->ws_bytes) return k22_set_error(K22_ENOMEM, "prior_bind: workspace too small");
   if ((uintptr_t)workspace % 256) return k22_set_error(K22_EINVAL, "prior_bind: workspace must be 256-byte aligned");
   m->ws = reinterpret_cast<char*>(workspace);
+  m->wfrag_done = false;
   if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
   return K22_OK;
 }
@@ -315,6 +392,13 @@ int k22_prior_forward(K22Prior* m, const float* x, const float* timesteps, const
   K22_CPY(m->ptr(m->s_txtemb), text_emb, (size_t)m->B * c.clip_dim * 4);
   K22_CPY(m->ptr(m->s_txtenc), text_enc, (size_t)m->B * c.text_ctx * c.clip_xf_width * 4);
   K22_CPY(m->ptr(m->s_valid), key_valid, (size_t)m->B * c.text_ctx * 4);
+  if (m->skinny && !m->wfrag_done) {
+    for (auto& wf : m->wfrags) {
+      int rc = launch_stream_repack(wf.src, m->ptr(wf.dst), wf.Npad, 1, wf.K, m->dtype, st);
+      if (rc) return rc;
+    }
+    m->wfrag_done = true;
+  }
   if (m->autotune && !m->tuned_done) {
     // the in-place residual GEMMs make the tuning runs accumulate garbage into the sequence buffer: harmless, the
     // real forward below rebuilds it from the inputs
