@@ -51,17 +51,20 @@ extern "C" {
                       tiles on fp32 tensors. */
 
 int k22_version(void);
+/* Build flavour of this library: bit mask of K22_BUILD_*.  0 = the shipped form. */
+#define K22_BUILD_PACKED_FP32 1     /* built with NOPK=0: packed-fp32 VALU instructions present - do NOT overlap two handles on one device */
+#define K22_BUILD_DEBUG_VARIANTS 2  /* measurement-only kernel variants compiled in (K22_DEBUG_VARIANTS / K22_STREAM_DEBUG / K22_SKINNY_DEBUG) */
+int k22_build_flags(void);
 const char* k22_last_error(void);
 /* Tuning knobs.  PROCESS-WIDE MUTABLE STATE, NOT RE-ENTRANT: these exist for the kernel-level test / measurement surface (k22_gemm,
  * k22_conv3x3*, k22_groupnorm) and must not be changed while another thread is inside any k22_* call.  Leave them at their defaults
  * in a process that runs engines (k22_unet_*, k22_prior_*, k22_movq_*, k22_encoder_*): engine launches carry the configuration of their
  * tile-table line, but a line that says "generic kernel" (algo 0) is dispatched through the same switch these knobs override.
- * Everything else in this header is re-entrant per handle (one handle = one stream at a time).  Two handles on two streams of one
- * device: round 4 found a kernel pair (igemm_kernel<16-bit, 128 x 64> beside linear_smallm_kernel) in which the co-resident victim
- * returned wrong elements; round 5 narrowed it to the victim's packed-fp32 VALU instructions (clean in 900 of 900 launches without
- * them, profiles/r05_two_stream_probe.txt).  A host that overlaps engines on one device builds the library with `make NOPK=1` (no
- * packed-fp32 instruction in any kernel; results move by an ulp or two and the step is ~2 % slower, so it is not the default); the
- * default build, the parity suite and the bench run one stream at a time - INTEGRATION.md G.
+ * Everything else in this header is re-entrant per handle (one handle = one stream at a time), and handles may run CONCURRENTLY on
+ * different streams of one device: since round 6 the library is built without packed-fp32 VALU instructions (csrc/Makefile NOPK = 1), the
+ * instruction class behind the one wrong-result kernel pair rounds 4-5 found under concurrency (0 of 900 victim launches wrong with every
+ * offender, against 148-227 of 900 in a packed build on the same box: profiles/r06_two_stream_probe.txt).  k22_build_flags() lets a
+ * host assert it: a library built with NOPK=0 reports K22_BUILD_PACKED_FP32 and must be driven one stream at a time.
  * Knobs: "igemm_stages" = 2..4 LDS-DMA pipeline depth (-1 default);
  * "igemm_xcd_remap" = 0/1 XCD-aware workgroup renumbering; "conv_algo" = 0 auto, 1 generic implicit GEMM,
  * 2 LDS-resident halo kernel for the 3x3 convolutions (3-7: its variants, see conv3_halo.hip; 8-9: measurement only);

@@ -74,6 +74,7 @@ _P, _I, _L, _F, _D, _Z = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C
 # name -> (restype, argtypes); every symbol here is declared in include/k22.h
 SIGNATURES = {
     "k22_version": (_I, []),
+    "k22_build_flags": (_I, []),
     "k22_last_error": (C.c_char_p, []),
     "k22_set_option": (_I, [C.c_char_p, _I]),
     "k22_comm_broadcast_weights": (_I, [_P, _Z, _I, _P, _P]),

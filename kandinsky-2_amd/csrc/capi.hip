@@ -22,6 +22,16 @@ int k22_set_error_hip(hipError_t e, const char* file, int line) {
 extern "C" {
 
 int k22_version(void) { return 100; }
+int k22_build_flags(void) {
+  int f = 0;
+#ifndef K22_NOPK
+  f |= K22_BUILD_PACKED_FP32;
+#endif
+#if defined(K22_DEBUG_VARIANTS) || defined(K22_STREAM_DEBUG) || defined(K22_SKINNY_DEBUG)
+  f |= K22_BUILD_DEBUG_VARIANTS;
+#endif
+  return f;
+}
 
 int k22_set_option(const char* name, int value) {
   if (name && !strcmp(name, "igemm_stages")) { igemm_set_default_stages(value); return K22_OK; }

@@ -171,7 +171,7 @@ class Kandinsky2_1HIP:
 
     def __init__(self, config, model_path, prior_path, device="cuda", task_type="text2img", *, conditioner=None,
                  backend_dtype: torch.dtype = torch.bfloat16, use_graph: bool = True, whole_loop_graph: Optional[bool] = None,
-                 movq_dtype: Optional[torch.dtype] = None):
+                 movq_dtype: Optional[torch.dtype] = None, chains: Optional[int] = None):
         if task_type not in ("text2img", "inpainting"):
             raise ValueError("Only text2img and inpainting is available")
         if torch.device(device).type != "cuda":
@@ -224,8 +224,9 @@ class Kandinsky2_1HIP:
         self.movq_dtype = movq_auto
         self.image_encoder = _MoVQ(ie["params"], movq_sd, self.movq_dtype, device)
 
+        # chains: Text2ImUNetHIP(chains=...) - 2 = the CFG pair as two half-batch engines side by side (None: env K22_CHAINS, else 1)
         self.model = Text2ImUNetHIP(make_arch(mcfg, inpainting=mcfg["inpainting"]), backend_dtype=backend_dtype, use_graph=use_graph,
-                                    cache_text_emb=True)
+                                    cache_text_emb=True, chains=chains)
         self.model.load_state_dict(_load(model_path))
         self.model = self.model.to(device).eval()
 

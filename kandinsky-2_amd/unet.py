@@ -10,6 +10,7 @@ Everything inside forward() runs in libk22hip.so; there is no PyTorch fallback.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -38,10 +39,15 @@ class Text2ImUNetHIP(nn.Module):
     "f16x3" (kandinsky2_amd.F16X3, split precision: fp32 tensors, every MFMA operand as an fp16 (hi, lo) pair, three fp16 MFMAs per
     product - within 1e-3 of the reference p_sampler's final latent, BASELINE.json's gate, at several times the fp32 engine's speed).
     use_graph: replay each forward as one captured hipGraph.
+    chains: 2 = an even batch runs as TWO half-batch engines (same arena, own workspaces and graphs) on two streams of the device - the two
+    halves of the classifier-free-guidance pair never interact inside the UNet (GroupNorm and attention are per sample), so one chain's
+    latency-bound stretches (GroupNorm coefficient / apply launches, the 20-us GEMMs of the AttentionBlocks, split-K finishes) overlap
+    the other's MFMA-bound ones.  Default: env K22_CHAINS, else 1.  Each half runs the tile-table lines of ITS problem sizes, so the bits of a
+    two-chain run differ from a one-chain run of the same inputs (other split-K factors); the distances from the reference do not.
     """
 
     def __init__(self, arch: UNetArch, backend_dtype: torch.dtype = torch.bfloat16, use_graph: bool = True,
-                 cache_text_emb: bool = True, meta_params: bool = False):
+                 cache_text_emb: bool = True, meta_params: bool = False, chains: Optional[int] = None):
         super().__init__()
         if backend_dtype not in (torch.bfloat16, torch.float16, torch.float32, _lib.F16X3, _lib.F16X2):
             raise ValueError('backend_dtype must be torch.bfloat16, torch.float16, torch.float32, "f16x3" (split precision) or "f16x2" '
@@ -55,7 +61,13 @@ class Text2ImUNetHIP(nn.Module):
         for name, shape in param_shapes(arch).items():
             t = torch.empty(shape, device="meta") if meta_params else torch.zeros(shape)
             _register(self, name, nn.Parameter(t, requires_grad=False))
+        self.chains = int(os.environ.get("K22_CHAINS", "1")) if chains is None else int(chains)
+        if self.chains not in (1, 2):
+            raise ValueError("chains must be 1 or 2")
         self._handle: Optional[C.c_void_p] = None
+        self._handle2: Optional[C.c_void_p] = None      # second half-batch engine of the two-chain mode
+        self._ws2 = None
+        self._side = None                               # its stream
         self._arena = None
         self._weights_keepalive = None
         self._ws = None
@@ -100,8 +112,12 @@ class Text2ImUNetHIP(nn.Module):
         if self._handle is not None:
             _lib.lib().k22_unet_destroy(self._handle)
             self._handle = None
+        if getattr(self, "_handle2", None) is not None:
+            _lib.lib().k22_unet_destroy(self._handle2)
+            self._handle2 = None
         self._arena = None
         self._ws = None
+        self._ws2 = None
         self._loop_bufs = None
         self._plan_key = None
         self._cond_key = None
@@ -180,6 +196,12 @@ class Text2ImUNetHIP(nn.Module):
         h = C.c_void_p()
         _lib.check(L.k22_unet_create(C.byref(cfg), arr, len(table), C.byref(h)))
         self._handle = h
+        if self.chains == 2:
+            if L.k22_build_flags() & 1:
+                raise RuntimeError("chains=2 overlaps two engines on one device: this libk22hip.so was built with packed-fp32 instructions (NOPK=0)")
+            h2 = C.c_void_p()
+            _lib.check(L.k22_unet_create(C.byref(cfg), arr, len(table), C.byref(h2)))
+            self._handle2 = h2
         if free_params:
             for p in self.parameters():
                 p.data = torch.empty(0, device=dev)
@@ -195,24 +217,53 @@ class Text2ImUNetHIP(nn.Module):
             self._cond_key = None
             L = _lib.lib()
             nbytes = C.c_size_t()
-            _lib.check(L.k22_unet_plan(self._handle, B, H, W, C.byref(nbytes)))
+            pb = B // 2 if self._chained(B) else B
+            _lib.check(L.k22_unet_plan(self._handle, pb, H, W, C.byref(nbytes)))
             self._ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=self._arena.device)
             p = self._ws.data_ptr()
             al = (p + 255) // 256 * 256
             _lib.check(L.k22_unet_bind(self._handle, al, nbytes.value))
+            if self._chained(B):
+                _lib.check(L.k22_unet_plan(self._handle2, pb, H, W, C.byref(nbytes)))
+                self._ws2 = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=self._arena.device)
+                _lib.check(L.k22_unet_bind(self._handle2, (self._ws2.data_ptr() + 255) // 256 * 256, nbytes.value))
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=self._arena.device)
             self._plan_key = key
             self._cond_key = None
+
+    def _chained(self, B: int) -> bool:
+        return self.chains == 2 and self._handle2 is not None and B >= 2 and B % 2 == 0
+
+    def _parts(self, B: int):
+        """(handle, first row, rows, stream handle) of every chain of a batch of B; the side stream is ordered behind the caller's first"""
+        cur = torch.cuda.current_stream()
+        if not self._chained(B):
+            return [(self._handle, 0, B, cur.cuda_stream)]
+        self._side.wait_stream(cur)
+        return [(self._handle, 0, B // 2, cur.cuda_stream), (self._handle2, B // 2, B // 2, self._side.cuda_stream)]
+
+    def _join(self, B: int):
+        if self._chained(B):
+            torch.cuda.current_stream().wait_stream(self._side)
 
     def num_ops(self) -> int:
         return _lib.lib().k22_unet_num_ops(self._handle) if self._handle is not None else 0
 
     def profile(self, reps: int = 3):
         """Per-op-class device time of one forward (HIP events around every op, eager replay)."""
-        ms, fl, by = (C.c_double * 5)(), (C.c_double * 5)(), (C.c_double * 5)()
-        ln = (C.c_int * 5)()
-        _lib.check(_lib.lib().k22_unet_profile(self._handle, reps, ms, fl, by, ln, _lib.current_stream()))
         kinds = ["conv3x3", "gemm", "groupnorm", "attention", "other"]
-        return {k: dict(ms=ms[i], flops=fl[i], bytes=by[i], launches=ln[i]) for i, k in enumerate(kinds)}
+        tot = {k: dict(ms=0.0, flops=0.0, bytes=0.0, launches=0) for k in kinds}
+        # two chains: the halves are timed one after the other, op by op - ISOLATED device times of both, summed (the step itself overlaps
+        # them, so the class times then add up to more than the step)
+        handles = [self._handle] + ([self._handle2] if self._plan_key is not None and self._chained(self._plan_key[0]) else [])
+        for h in handles:
+            ms, fl, by = (C.c_double * 5)(), (C.c_double * 5)(), (C.c_double * 5)()
+            ln = (C.c_int * 5)()
+            _lib.check(_lib.lib().k22_unet_profile(h, reps, ms, fl, by, ln, _lib.current_stream()))
+            for i, k in enumerate(kinds):
+                tot[k]["ms"] += ms[i]; tot[k]["flops"] += fl[i]; tot[k]["bytes"] += by[i]; tot[k]["launches"] += ln[i]
+        return tot
 
     def tuning_report(self) -> str:
         """Tile configuration chosen (by measurement at the first forward) for every distinct conv / GEMM problem."""
@@ -239,7 +290,9 @@ class Text2ImUNetHIP(nn.Module):
         f = full_emb.detach().float().contiguous()
         p = pooled_emb.detach().float().contiguous()
         i = image_emb.detach().float().contiguous()
-        _lib.check(L.k22_unet_set_condition(self._handle, f.data_ptr(), p.data_ptr(), i.data_ptr(), _lib.current_stream()))
+        for h, r0, n, st in self._parts(B):
+            _lib.check(L.k22_unet_set_condition(h, f[r0:r0 + n].data_ptr(), p[r0:r0 + n].data_ptr(), i[r0:r0 + n].data_ptr(), st))
+        self._join(B)
         return self
 
     @torch.no_grad()
@@ -273,9 +326,11 @@ class Text2ImUNetHIP(nn.Module):
         elif inpaint_image is not None or inpaint_mask is not None:
             raise ValueError("inpaint_image / inpaint_mask given to a text2img UNet (create it with inpainting=True)")
         out = torch.empty(B, self.arch.out_channels, H, W, dtype=torch.float32, device=x.device)
-        _lib.check(_lib.lib().k22_unet_forward(
-            self._handle, xf.data_ptr(), tf.data_ptr(), _lib.ptr(img), _lib.ptr(msk), out.data_ptr(),
-            1 if self.use_graph else 0, _lib.current_stream()))
+        for h, r0, n, st in self._parts(B):      # one chain, or the two half-batch chains side by side (each replays its own graph on its stream)
+            _lib.check(_lib.lib().k22_unet_forward(
+                h, xf[r0:r0 + n].data_ptr(), tf[r0:r0 + n].data_ptr(), _lib.ptr(None if img is None else img[r0:r0 + n]),
+                _lib.ptr(None if msk is None else msk[r0:r0 + n]), out[r0:r0 + n].data_ptr(), 1 if self.use_graph else 0, st))
+        self._join(B)
         return out
 
 
@@ -302,6 +357,23 @@ class Text2ImUNetHIP(nn.Module):
         if not self.arch.inpainting and (inpaint_image is not None or inpaint_mask is not None):
             raise ValueError("inpaint_image / inpaint_mask given to a text2img UNet (create it with inpainting=True)")
         dev = x.device
+        if self._chained(B):
+            # two chains: the loop is driven from the host - per step the two half-batch graphs side by side, a join, the sampler kernels (one
+            # captured graph with two branches runs them back to back: measured in round 4).  Same step arithmetic as k22_unet_sample_loop.
+            L = _lib.lib()
+            cur, nxt = x.detach().float().clone(), torch.empty(B, 4, H, W, dtype=torch.float32, device=dev)
+            scratch = torch.empty(L.k22_sampler_scratch_bytes(B, H * W), dtype=torch.uint8, device=dev)
+            tbl = table.float().contiguous()
+            ii = None if init_img is None else init_img.float().expand(B, 4, H, W).contiguous()
+            mm = None if init_img is None else img_mask.float().expand(B, 1, H, W).contiguous()
+            for k in range(n_steps):
+                half = cur[: B // 2]
+                out = self.forward(torch.cat([half, half], 0), ts_rows[k], inpaint_image=inpaint_image, inpaint_mask=inpaint_mask)
+                _lib.check(L.k22_sampler_step(cur.data_ptr(), out.data_ptr(), noise_seq[k].contiguous().data_ptr(), _lib.ptr(ii), _lib.ptr(mm), tbl.data_ptr(),
+                                              int(table_rows[k]), float(guidance_scale), 1, float(clamp[0]), float(clamp[1]), int(pct[0]), float(pct[1]),
+                                              scratch.data_ptr(), nxt.data_ptr(), None, B, H * W, _lib.current_stream()))
+                cur, nxt = nxt, cur
+            return cur
         key = (B, H, W, n_steps, tuple(table.shape), init_img is not None, str(dev))
         bufs = getattr(self, "_loop_bufs", None)
         if bufs is None or bufs["key"] != key:

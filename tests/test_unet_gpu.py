@@ -307,3 +307,55 @@ def test_bf16_engine_against_the_reference_fp16_yardstick(golden_dir):
     print(f"C1 10-step final latent: bf16 engine {err:.3e} / rms {rms:.3e};  reference fp16 mode {ref_last['max_abs']:.3e} / rms {ref_last['rms']:.3e} "
           f"(worst step {ref_worst:.3e})")
     assert err <= 8 * ref_worst and rms <= 8 * ref_last["rms"]
+
+
+# ---- two half-batch chains on two streams (round 6: Text2ImUNetHIP(chains=2)) ------------------------------------------------------------
+@pytest.mark.parametrize("name", ["tiny_text2img", "tiny_inpaint", "full_c1_text2img"])
+@pytest.mark.parametrize("backend,tol", [(torch.float32, 2e-4), (torch.bfloat16, 2e-2), (k22.F16X3, 2e-4)])
+def test_two_chains_forward_vs_reference_golden(golden_dir, name, backend, tol):
+    """The CFG pair as two half-batch engines side by side (kandinsky2_1_model.py:222-225: the halves never interact inside the UNet): the same
+    bounds against the reference golden as the one-chain forward, equal bits run to run (two graphs racing on two streams must not change
+    anything), and - fp32 / split precision - the one-chain output to summation-order accuracy."""
+    if name == "full_c1_text2img" and backend == torch.bfloat16 and os.environ.get("K22_RUN_SLOW", "0") in ("", "0"):
+        pytest.skip("the 1.23 B UNet under two chains: fp32 and f16x3 by default")
+    fx = _load(golden_dir, name)
+    arch = k22.make_arch(fx["model_config"], inpainting=fx["inpainting"])
+    _a, sd, m1, x, img, mask, kw = _setup(fx, backend, use_graph=True)
+    m2 = k22.Text2ImUNetHIP(arch, backend_dtype=backend, use_graph=True, chains=2)
+    m2.load_state_dict(sd)
+    m2 = m2.to("cuda").eval()
+    ref = fx["forward_out"]
+    scale = ref.abs().max().item()
+    outs = [m2(x.cuda(), fx["t"].cuda(), **kw).cpu() for _ in range(4)]
+    err = (outs[0] - ref).abs().max().item()
+    print(f"{name} {backend} two chains: max|d|={err:.3e} scale={scale:.3f}")
+    assert err <= tol * scale
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    one = m1(x.cuda(), fx["t"].cuda(), **kw).cpu()
+    assert (one - outs[0]).abs().max().item() <= (2e-5 if backend != torch.bfloat16 else 2e-2) * scale
+
+
+@pytest.mark.parametrize("name", ["tiny_text2img", "tiny_inpaint"])
+def test_two_chains_p_sampler_final_latent_vs_reference_golden(golden_dir, name):
+    """north-star gate under two chains (host-driven loop: two graphs side by side + sampler step per step): fp32 engine <= 1e-3, repeatable bits."""
+    fx = _load(golden_dir, name)
+    arch = k22.make_arch(fx["model_config"], inpainting=fx["inpainting"])
+    _a, sd, _m, _x, img, mask, kw = _setup(fx, torch.float32, use_graph=True)
+    m = k22.Text2ImUNetHIP(arch, backend_dtype=torch.float32, use_graph=True, chains=2)
+    m.load_state_dict(sd)
+    m = m.to("cuda").eval()
+    g = torch.Generator().manual_seed(42)
+    x_T = torch.randn(fx["B"], 4, fx["h"], fx["w"], generator=g)
+    noise_seq = torch.randn(fx["steps"], fx["B"], 4, fx["h"], fx["w"], generator=g)
+    d = k22.create_gaussian_diffusion(**dict(k22.DIFFUSION_CONFIG_2_1, timestep_respacing=str(fx["steps"])))
+    ii, mm = (img.cuda(), mask.cuda()) if fx["inpainting"] else (None, None)
+    finals = []
+    for whole in (False, True, True):
+        m.del_cache()
+        finals.append(d.p_sample_loop(m, (fx["B"], 4, fx["h"], fx["w"]), model_kwargs=kw, guidance_scale=fx["guidance"], noise=x_T.cuda(),
+                                      noise_seq=noise_seq.cuda(), init_img=ii, img_mask=mm, whole_loop_graph=whole).cpu())
+    err = (finals[0] - fx["final"]).abs().max().item()
+    print(f"{name}: fp32 engine, two chains, vs reference p_sampler final latent max|d| = {err:.3e}")
+    assert err <= 1e-3
+    assert torch.equal(finals[0], finals[1]) and torch.equal(finals[1], finals[2])
