@@ -41,8 +41,14 @@ __device__ __forceinline__ void ld_frag_split(Frag<float>& f, const char* tile, 
 __device__ __forceinline__ void ld_frag_split(Frag<x3_t>& f, const char* tile, int r, int a, int h) {
   const char* sub = tile + (a >> 1) * 8192;
   const int al = a & 1;
-  x3_frag_from_chunks(f, *reinterpret_cast<const u32x4_t*>(sub + lds_chunk_off(r, 4 * al + h)),
-                      *reinterpret_cast<const u32x4_t*>(sub + lds_chunk_off(r, 4 * al + 2 + h)));
+  // keys 16 a + 4 h + {0..3} = elements 4 h .. of group 2 al, keys 16 a + 8 + 4 h + {0..3} = the same elements of group 2 al + 1: 8-byte
+  // halves of the groups' hi pieces (chunks 4 al, 4 al + 2) and lo pieces (4 al + 1, 4 al + 3)
+  const u32x2_t h0 = *reinterpret_cast<const u32x2_t*>(sub + lds_chunk_off(r, 4 * al) + 8 * h);
+  const u32x2_t l0 = *reinterpret_cast<const u32x2_t*>(sub + lds_chunk_off(r, 4 * al + 1) + 8 * h);
+  const u32x2_t h1 = *reinterpret_cast<const u32x2_t*>(sub + lds_chunk_off(r, 4 * al + 2) + 8 * h);
+  const u32x2_t l1 = *reinterpret_cast<const u32x2_t*>(sub + lds_chunk_off(r, 4 * al + 3) + 8 * h);
+  f.hi = u32x4_t{h0.x, h0.y, h1.x, h1.y};
+  f.lo = u32x4_t{l0.x, l0.y, l1.x, l1.y};
 }
 __device__ __forceinline__ void make_pfrag(Frag<x3_t>& f, const float* p) {
   x3_frag_from_f32(f, make_float4(p[0], p[1], p[2], p[3]), make_float4(p[4], p[5], p[6], p[7]));
@@ -169,8 +175,11 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttentionParams p) {
         *reinterpret_cast<u32x4_t*>(Ks + off) = f16x8_from_f32(kreg[2 * i], kreg[2 * i + 1]);            \
         *reinterpret_cast<u32x4_t*>(Vs + off) = f16x8_from_f32(vreg[2 * i], vreg[2 * i + 1]);            \
       } else if constexpr (is_x3<T>::value) {   /* fp32 K / V^T rows -> x3 chunks, once per workgroup */    \
-        *reinterpret_cast<u32x4_t*>(Ks + off) = x3_split4(__builtin_bit_cast(float4, kreg[i]));           \
-        *reinterpret_cast<u32x4_t*>(Vs + off) = x3_split4(__builtin_bit_cast(float4, vreg[i]));           \
+        /* groups of eight: logical chunks 2g / 2g + 1 = hi / lo pieces; this thread's four values own bytes 8 (cc & 1) .. of each */ \
+        const u32x4_t ks_ = x3_split4(__builtin_bit_cast(float4, kreg[i])), vs_ = x3_split4(__builtin_bit_cast(float4, vreg[i])); \
+        const int ohi_ = (cc >> 3) * 8192 + lds_chunk_off(row, (cc & 7) & ~1) + 8 * (cc & 1), olo_ = (cc >> 3) * 8192 + lds_chunk_off(row, (cc & 7) | 1) + 8 * (cc & 1); \
+        *reinterpret_cast<u32x2_t*>(Ks + ohi_) = u32x2_t{ks_.x, ks_.y}; *reinterpret_cast<u32x2_t*>(Ks + olo_) = u32x2_t{ks_.z, ks_.w}; \
+        *reinterpret_cast<u32x2_t*>(Vs + ohi_) = u32x2_t{vs_.x, vs_.y}; *reinterpret_cast<u32x2_t*>(Vs + olo_) = u32x2_t{vs_.z, vs_.w}; \
       } else {                                                                                           \
       *reinterpret_cast<u32x4_t*>(Ks + off) = kreg[i];                                                   \
       *reinterpret_cast<u32x4_t*>(Vs + off) = vreg[i];                                                   \
@@ -272,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttentionParams p) {
       for (int g = 0; g < 4; ++g) {
         const int d = db * 32 + 8 * g + 4 * h;
         if constexpr (MIX) {
-          if (p.out_x3) *reinterpret_cast<u32x4_t*>(orow + d) = x3_split4(o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+          if (p.out_x3) x3_store4(orow + d, x3_split4(o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv));
           else *reinterpret_cast<float4*>(orow + d) = make_float4(o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
         } else if constexpr (sizeof(T) == 2) {
           uint2 w;
@@ -280,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttentionParams p) {
           w.y = pack2<T>(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
           *reinterpret_cast<uint2*>(orow + d) = w;
         } else if (is_x3<T>::value && p.out_x3) {   // the proj_out GEMM reads this tensor as its A operand: x3 chunks
-          *reinterpret_cast<u32x4_t*>(orow + d) = x3_split4(o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+          x3_store4(orow + d, x3_split4(o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv));
         } else {
           *reinterpret_cast<float4*>(orow + d) =
               make_float4(o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);

@@ -110,23 +110,38 @@ template <bool FAST> __device__ __forceinline__ float apply_act_sel(float x, int
 }
 
 // ---- split-precision operand format ("x3 chunk") ------------------------------------------------------------------------------
-// An MFMA operand tensor of the K22_F16X3 arithmetic occupies 4 bytes per element like fp32, but every aligned group of FOUR
-// consecutive K elements (16 bytes) is stored as [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] in fp16, hi = rne_f16(x), lo = rne_f16(x - hi)
+// An MFMA operand tensor of the K22_F16X3 arithmetic occupies 4 bytes per element like fp32, but every aligned group of EIGHT
+// consecutive K elements (32 bytes) is stored as [hi0 .. hi7 | lo0 .. lo7] in fp16, hi = rne_f16(x), lo = rne_f16(x - hi)
 // (x - hi is exact in fp32).  fp16 subnormals are kept (the kernel mode never flushes them), so |x| >= 2^-2 is carried to 2^-23
-// relative and anything smaller to 2^-25 absolute.  A fragment of a 32x32x16 atom (8 consecutive K of one row) is two chunks:
-// two ds_read_b128, no conversion instruction.  WEIGHTS are packed in this format once (pack.py), pre-multiplied by the exact
-// power of two K22_X3_WSCALE so that their lo halves stay normal; the epilogues multiply the accumulators by 1 / K22_X3_WSCALE.
-// ACTIVATIONS are written in it by their producers (GroupNorm-apply, the attention epilogue) or converted from fp32 rows at
-// fragment-read time where the producer is not one of ours (`a_raw` operands: 1x1 skip connections, the conditioning GEMMs).
+// relative and anything smaller to 2^-25 absolute.  A fragment of a 32x32x16 atom (8 consecutive K of one row) is ONE group: its hi
+// halves are one 16-byte piece, its lo halves the next - two conflict-free ds_read_b128 straight into the registers the MFMAs read,
+// and the activation fragment of the asymmetric split (hi halves only) is ONE.  (Rounds 4-5 used groups of four, [hi x4 | lo x4]: a
+// fragment then had to be gathered out of two pieces with register moves - 1.5 v_mov per MFMA in the x2 / x3 tap loops,
+// profiles/r05_isa_mix.txt - and the x2 activation reads were 8-byte halves with a 3.4x LDS bank-conflict ratio.)
+// WEIGHTS are packed in this format once (pack.py), pre-multiplied by the exact power of two K22_X3_WSCALE so that their lo halves
+// stay normal; the epilogues multiply the accumulators by 1 / K22_X3_WSCALE.  ACTIVATIONS are written in it by their producers
+// (GroupNorm-apply, the attention epilogue: x3_store4 below) or converted from fp32 rows at fragment-read time where the producer is
+// not one of ours (`a_raw` operands: 1x1 skip connections, the conditioning GEMMs).  Tensors are 32-byte aligned with K % 8 == 0.
 struct x3_t { float f; };   // storage tag: sizeof == 4; as a STORED tensor type it behaves as float (epilogue outputs are fp32)
 constexpr float K22_X3_WSCALE = 256.0f;
 constexpr float K22_X3_WSCALE_INV = 1.0f / 256.0f;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+// four consecutive K elements -> their (hi, lo) fp16 halves: .x .y = hi0..hi3, .z .w = lo0..lo3
 __device__ __forceinline__ u32x4_t x3_split4(float x0, float x1, float x2, float x3) {
   const uint32_t h01 = pack2_f16(x0, x1), h23 = pack2_f16(x2, x3);
   const f16x2_t a = __builtin_bit_cast(f16x2_t, h01), b = __builtin_bit_cast(f16x2_t, h23);
   return u32x4_t{h01, h23, pack2_f16(x0 - (float)a[0], x1 - (float)a[1]), pack2_f16(x2 - (float)b[0], x3 - (float)b[1])};
 }
 __device__ __forceinline__ u32x4_t x3_split4(const float4 v) { return x3_split4(v.x, v.y, v.z, v.w); }
+// stores four consecutive K elements (element index % 4 == 0) of an x3-chunk tensor: `at` = the address the fp32 values would have
+// (generic or LDS pointer).  Their group of eight starts at the enclosing 32-byte boundary; elements 0-3 / 4-7 of the group own bytes
+// 0-7 / 8-15 of its hi piece and of its lo piece.
+__device__ __forceinline__ void x3_store4(void* at, const u32x4_t s) {
+  char* g = reinterpret_cast<char*>(reinterpret_cast<uintptr_t>(at) & ~(uintptr_t)31);
+  const int half = (int)((reinterpret_cast<uintptr_t>(at) >> 4) & 1);
+  *reinterpret_cast<u32x2_t*>(g + 8 * half) = u32x2_t{s.x, s.y};
+  *reinterpret_cast<u32x2_t*>(g + 16 + 8 * half) = u32x2_t{s.z, s.w};
+}
 __device__ __forceinline__ float to_f32(x3_t v) { return v.f; }
 template <> __device__ __forceinline__ x3_t from_f32<x3_t>(float f) { return x3_t{f}; }
 // K22_F16X2: the same storage and operand formats (is_x3 is true for it: everything that concerns the FORMAT is shared), two MFMAs per
@@ -161,7 +176,7 @@ template <> struct TT<x2_t> : TT<float> {};
 // LDS reads per fragment / MFMA instructions per 32x32x16 atom (the consumers' interleave of conv3_halo_spec_kernel)
 template <typename T> struct FragCost { static constexpr int READS = sizeof(T) == 2 ? 1 : 2, MFMAS = sizeof(T) == 2 ? 1 : 8; };
 template <> struct FragCost<x3_t> { static constexpr int READS = 2, MFMAS = 3; };
-template <> struct FragCost<x2_t> { static constexpr int READS = 2, MFMAS = 2; };
+template <> struct FragCost<x2_t> { static constexpr int READS = 2, MFMAS = 2; };   // (reads per A + B fragment pair average 1.5: priced at the weight fragment's two)
 
 // A/B fragment of one 32x32x16 atom: 8 consecutive K elements of one row.
 template <typename T> struct Frag;
@@ -175,19 +190,20 @@ struct FragHi { u32x4_t hi; };                       // its ACTIVATION fragment:
 template <typename T> struct FragAT { using type = Frag<T>; };
 template <> struct FragAT<x2_t> { using type = FragHi; };
 template <typename T> using FragA = typename FragAT<T>::type;
-typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
-// two x3 chunks (K elements 0-3 and 4-7 of the fragment) -> fragment: register renaming only
+// the two 16-byte pieces of a group (hi x8, lo x8) ARE the fragment
 __device__ __forceinline__ void x3_frag_from_chunks(Frag<x3_t>& f, const u32x4_t c0, const u32x4_t c1) {
-  f.hi = u32x4_t{c0.x, c0.y, c1.x, c1.y};
-  f.lo = u32x4_t{c0.z, c0.w, c1.z, c1.w};
+  f.hi = c0;
+  f.lo = c1;
 }
 // eight fp32 values -> fragment (the `a_raw` operands: 20 VALU per fragment)
 __device__ __forceinline__ void x3_frag_from_f32(Frag<x3_t>& f, const float4 a, const float4 b) {
-  x3_frag_from_chunks(f, x3_split4(a), x3_split4(b));
+  const u32x4_t s0 = x3_split4(a), s1 = x3_split4(b);
+  f.hi = u32x4_t{s0.x, s0.y, s1.x, s1.y};
+  f.lo = u32x4_t{s0.z, s0.w, s1.z, s1.w};
 }
 __device__ __forceinline__ void x3_frag_from_chunks(Frag<x2_t>& f, const u32x4_t c0, const u32x4_t c1) {
-  f.hi = u32x4_t{c0.x, c0.y, c1.x, c1.y};
-  f.lo = u32x4_t{c0.z, c0.w, c1.z, c1.w};
+  f.hi = c0;
+  f.lo = c1;
 }
 // activation fragment of the asymmetric split from plain fp32 values: four conversions
 __device__ __forceinline__ void x3_frag_from_f32(FragHi& f, const float4 a, const float4 b) {
@@ -223,11 +239,9 @@ __device__ __forceinline__ void ld_frag(Frag<x2_t>& f, const char* tile, int r, 
   x3_frag_from_chunks(f, *reinterpret_cast<const u32x4_t*>(tile + lds_chunk_off(r, 4 * ks + 2 * h)),
                       *reinterpret_cast<const u32x4_t*>(tile + lds_chunk_off(r, 4 * ks + 2 * h + 1)));
 }
-// asymmetric split, activation operand in x3 chunks: the hi halves (first 8 bytes) of the same two chunks
+// asymmetric split, activation operand in x3 chunks: the hi piece of the group, one ds_read_b128
 __device__ __forceinline__ void ld_frag(FragHi& f, const char* tile, int r, int ks, int h) {
-  const u32x2_t a = *reinterpret_cast<const u32x2_t*>(tile + lds_chunk_off(r, 4 * ks + 2 * h));
-  const u32x2_t b = *reinterpret_cast<const u32x2_t*>(tile + lds_chunk_off(r, 4 * ks + 2 * h + 1));
-  f.hi = u32x4_t{a.x, a.y, b.x, b.y};
+  f.hi = *reinterpret_cast<const u32x4_t*>(tile + lds_chunk_off(r, 4 * ks + 2 * h));
 }
 // RAW = the LDS image holds plain fp32 rows (split arithmetics only): convert while reading.  Every other type: ld_frag.
 template <bool RAW, typename T, typename F> __device__ __forceinline__ void ld_frag_a(F& f, const char* tile, int r, int ks, int h) {

@@ -31,11 +31,9 @@ __device__ __forceinline__ void ld_frag_at(Frag<x2_t>& f, const char* rowp, int 
   x3_frag_from_chunks(f, *reinterpret_cast<const u32x4_t*>(rowp + (((4 * ks + 2 * h) ^ sw) << 4)),
                       *reinterpret_cast<const u32x4_t*>(rowp + (((4 * ks + 2 * h + 1) ^ sw) << 4)));
 }
-// asymmetric split, activation operand: the hi halves (first 8 bytes) of the two chunks
+// asymmetric split, activation operand: the hi piece of the group (one conflict-free ds_read_b128)
 __device__ __forceinline__ void ld_frag_at(FragHi& f, const char* rowp, int sw, int ks, int h) {
-  const u32x2_t a = *reinterpret_cast<const u32x2_t*>(rowp + (((4 * ks + 2 * h) ^ sw) << 4));
-  const u32x2_t b = *reinterpret_cast<const u32x2_t*>(rowp + (((4 * ks + 2 * h + 1) ^ sw) << 4));
-  f.hi = u32x4_t{a.x, a.y, b.x, b.y};
+  f.hi = *reinterpret_cast<const u32x4_t*>(rowp + (((4 * ks + 2 * h) ^ sw) << 4));
 }
 // RAW operands (split arithmetics only): plain fp32 rows in the LDS, split while they are read; every other type = ld_frag_at
 template <bool RAW, typename T, typename F> __device__ __forceinline__ void ld_frag_at_a(F& f, const char* rowp, int sw, int ks, int h) {
@@ -162,6 +160,18 @@ template <int N> __device__ __forceinline__ void gn_wait(u32x4_t (&c)[2]) {
   asm volatile("s_waitcnt vmcnt(%2)" : "+v"(c[0]), "+v"(c[1]) : "n"(N) : "memory");
 }
 
+// the same for a WEIGHT piece.  K22_W_NT (measurement build): non-temporal hint - each weight byte is read by the few workgroups of one
+// n-tile column, once (MI355X_MICROARCH.md "nt-weights": issued -> landed -18 % for read-once streams, -6 % end to end when every CU re-reads)
+__device__ __forceinline__ void glds16w_asm(const void* g, unsigned lds_dst) {
+#ifdef K22_W_NT
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
+#else
+  glds16_asm(g, lds_dst);
+#endif
+}
+
 constexpr int HALO_BN = 128;
 constexpr int HALO_NW = 8;        // waves per workgroup
 constexpr int HALO_MAXA = 8;      // halo LDS-DMA slots per wave per slab: taps 0 .. 9-NBST carry one each
@@ -266,7 +276,7 @@ __device__ __forceinline__ void halo_tail(const IgemmParams& p, f32x16_t (&acc)[
         _Pragma("unroll") for (int i = 0; i < SA_SLOTS; ++i)                                               \
             glds16_asm(xs_ + (int64_t)spix[i] * ldx_ + kk_ + schunk[i], __builtin_amdgcn_readfirstlane(dA_ + i * NW * 1024)); \
         _Pragma("unroll") for (int i = 0; i < B_SLOTS; ++i)                                                \
-            glds16_asm(Ws + wsoff[i] + k0_, __builtin_amdgcn_readfirstlane(dA_ + BM * 128 + i * NW * 1024)); \
+            glds16w_asm(Ws + wsoff[i] + k0_, __builtin_amdgcn_readfirstlane(dA_ + BM * 128 + i * NW * 1024)); \
       }
 #pragma unroll
       for (int t = 0; t < NSK - 1; ++t) K22_ISSUE_SKIP(q0 + t, t);

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(const IgemmParams p) {
     char* dst_ = Bst + (STAGE) * B_BYTES + wave * 1024;                                                    \
     _Pragma("unroll") for (int i = 0; i < B_SLOTS; ++i) {                                                  \
       if constexpr (GASM)                                                                                  \
-        glds16_asm(Wp + boff[i] + kofs_, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(dst_ - smem) + i * NW * 1024)); \
+        glds16w_asm(Wp + boff[i] + kofs_, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(dst_ - smem) + i * NW * 1024)); \
       else                                                                                                 \
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wp + boff[i] + kofs_), \
                                          (__attribute__((address_space(3))) void*)(dst_ + i * NW * 1024), 16, 0, 0); \
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const IgemmParams p) {
     _Pragma("unroll") for (int i = 0; i < A_SLOTS; ++i)                                                    \
         glds16_asm(A + aoff[i] + sl_ * BK, __builtin_amdgcn_readfirstlane(d_ + i * NW * 1024));            \
     _Pragma("unroll") for (int i = 0; i < B_SLOTS; ++i)                                                    \
-        glds16_asm(Wp + boff[i] + sl_ * BK, __builtin_amdgcn_readfirstlane(d_ + A_BYTES + i * NW * 1024)); \
+        glds16w_asm(Wp + boff[i] + sl_ * BK, __builtin_amdgcn_readfirstlane(d_ + A_BYTES + i * NW * 1024)); \
   }
   int arow[MI], brow[NI];
 #pragma unroll

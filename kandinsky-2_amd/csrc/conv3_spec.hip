@@ -152,7 +152,7 @@ __global__ __launch_bounds__(512) void conv3_halo_spec_kernel(const IgemmParams 
         const int kofs_ = (TAP) * p.Kc + (SLAB) * BK;                                                      \
         const unsigned d_ = lds0 + 2 * A_BYTES + (STAGE) * B_BYTES + lw * 1024;                            \
         _Pragma("unroll") for (int i = 0; i < B_SLOTS; ++i)                                                \
-            glds16_asm(Wp + boff[i] + kofs_, __builtin_amdgcn_readfirstlane(d_ + i * NWL * 1024));         \
+            glds16w_asm(Wp + boff[i] + kofs_, __builtin_amdgcn_readfirstlane(d_ + i * NWL * 1024));         \
       }
 #define K22_GN_COEF(SLAB)                                                                                  \
       {                                                                                                    \
@@ -168,6 +168,13 @@ __global__ __launch_bounds__(512) void conv3_halo_spec_kernel(const IgemmParams 
             cf_[4 * k] = __uint_as_float(cfr[k].x); cf_[4 * k + 1] = __uint_as_float(cfr[k].y);            \
             cf_[4 * k + 2] = __uint_as_float(cfr[k].z); cf_[4 * k + 3] = __uint_as_float(cfr[k].w);        \
           }                                                                                                \
+          if constexpr (is_x3<T>::value) {   /* groups of eight: this lane's four values own one half of the hi piece and of the lo piece   \
+                                                 (logical chunks 2g, 2g + 1 = this lane's and its neighbour's 16 bytes; both lanes read before they write) */ \
+            const u32x4_t s_ = gn_rewrite16(T{}, *a_, cf_, p.gn_act, ((bmask >> (Q)) & 1u) != 0u);        \
+            const int od_ = gchunk & 1, o_ = (DSTOFF) + jn_ * 1024 + lane * 16;                            \
+            *reinterpret_cast<u32x2_t*>(smem + (o_ ^ (od_ << 4)) + 8 * od_) = u32x2_t{s_.x, s_.y};         \
+            *reinterpret_cast<u32x2_t*>(smem + (o_ ^ (od_ << 4) ^ 16) + 8 * od_) = u32x2_t{s_.z, s_.w};    \
+          } else                                                                                           \
           *a_ = gn_rewrite16(T{}, *a_, cf_, p.gn_act, ((bmask >> (Q)) & 1u) != 0u);                        \
         }                                                                                                  \
       }
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(512) void conv3_halo_spec_kernel(const IgemmParams 
         const int kofs_ = (TAP) * p.Kc + (SLAB) * BK;                                                      \
         const unsigned d_ = lds0 + 2 * A_BYTES + (STAGE) * B_BYTES + lw * 1024;                            \
         _Pragma("unroll") for (int i = 0; i < B_SLOTS; ++i)                                                \
-            glds16_asm(Wp + boff[i] + kofs_, __builtin_amdgcn_readfirstlane(d_ + i * NWL * 1024));         \
+            glds16w_asm(Wp + boff[i] + kofs_, __builtin_amdgcn_readfirstlane(d_ + i * NWL * 1024));         \
       }
 #pragma unroll
       for (int q = 0; q < A_SLOTS; ++q) K22_SP_A(q, s0, 0);
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(512) void conv3_halo_spec_kernel(const IgemmParams 
       // One block of the pipeline = NRD fragment reads (of the NEXT group) + NMF MFMAs (of the group read one block ago), which
       // are independent of each other: one read is scheduled behind every MPR MFMAs (0x008 = MFMA, 0x100 = DS read), so that
       // each ds_read_b128 issues under the 32 cycles the MFMA before it occupies the pipe.
-      constexpr int NRD = (MI + NI) * FragCost<T>::READS;
+      constexpr int NRD = is_x2<T>::value ? MI + 2 * NI : (MI + NI) * FragCost<T>::READS;   // x2: the activation fragment is ONE read (hi piece only)
       constexpr int NMF = MI * NI * FragCost<T>::MFMAS;
       constexpr int MPR = NMF / NRD;
 #define K22_SP_INTERLEAVE()                                                                                \

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyParams p) {
   }
   if constexpr (sizeof(T) == 4) {
     // split-precision engine: the consumer is an MFMA kernel that reads its A operand in x3 chunks (common.h); a zero stays zero
-    if (p.out_x3) { *reinterpret_cast<u32x4_t*>(out) = x3_split4(o.raw); return; }
+    if (p.out_x3) { x3_store4(out, x3_split4(o.raw)); return; }
   }
   *reinterpret_cast<decltype(o.raw)*>(out) = o.raw;
 }
@@ -507,11 +507,11 @@ __global__ __launch_bounds__(256) void kv_pack_kernel(KvPackParams p) {
 __global__ __launch_bounds__(256) void x3_pack_kernel(const float4* __restrict__ in, u32x4_t* __restrict__ out, int64_t n4, float scale) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     const float4 v = in[i];
-    out[i] = x3_split4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+    x3_store4(out + i, x3_split4(v.x * scale, v.y * scale, v.z * scale, v.w * scale));
   }
 }
 int launch_x3_pack(const float* in, void* out, int64_t n, float scale, hipStream_t s) {
-  if (n % 4 || ((uintptr_t)in | (uintptr_t)out) % 16) return k22_set_error(K22_EINVAL, "x3_pack: n % 4 == 0 and 16-byte aligned buffers");
+  if (n % 8 || (uintptr_t)in % 16 || (uintptr_t)out % 32) return k22_set_error(K22_EINVAL, "x3_pack: n % 8 == 0, 16-byte aligned input, 32-byte aligned output (groups of eight)");
   const int64_t n4 = n / 4;
   int nb = (int)((n4 + 255) / 256);
   if (nb > 4096) nb = 4096;

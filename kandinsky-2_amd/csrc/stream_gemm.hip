@@ -99,8 +99,13 @@ __device__ __forceinline__ void stream_phase(f32x16_t (&acc)[MB][NB], char* smem
     if (sl > nslab - 1) sl = nslab - 1;
     // FRAG: wl{j} point at this lane's 16 bytes of the fragment of (n-block j, item 0 of the op, k quarter w); items are 4 x 1 KB apart
     const int64_t off = FRAG ? (int64_t)((s0 + sl) * TAPS + tap) * 2048 : (int64_t)tap * wtap + (int64_t)(s0 + sl) * 64;
+#ifdef K22_W_NT   // measurement build: non-temporal weight stream
+    f[0].v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wl0 + off));
+    if (NB > 1) f[NB - 1].v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wl1 + off));
+#else
     f[0] = *reinterpret_cast<const Frag<T>*>(wl0 + off);
     if (NB > 1) f[NB - 1] = *reinterpret_cast<const Frag<T>*>(wl1 + off);
+#endif
   };
 
   fill_load(0);

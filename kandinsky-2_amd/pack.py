@@ -36,16 +36,16 @@ def _pad_rows(w: torch.Tensor, mult: int = 64) -> torch.Tensor:
 
 
 def to_x3(w: torch.Tensor, scale: float = 256.0) -> torch.Tensor:
-    """fp32 [..., K] (K % 4 == 0) -> the split-precision operand format of the K22_F16X3 arithmetic (csrc/common.h, "x3 chunks"):
-    every group of 4 consecutive K elements becomes [hi0..hi3 | lo0..lo3] in fp16 with hi = rne(x * scale), lo = rne(x * scale - hi);
+    """fp32 [..., K] (K % 8 == 0) -> the split-precision operand format of the K22_F16X3 arithmetic (csrc/common.h, "x3 chunks"):
+    every group of 8 consecutive K elements becomes [hi0..hi7 | lo0..lo7] in fp16 with hi = rne(x * scale), lo = rne(x * scale - hi);
     returned as a float32-typed tensor of the SAME shape (4 bytes per element, bit pattern = the fp16 pairs)."""
-    if w.shape[-1] % 4:
-        raise ValueError("to_x3: the K dimension must be a multiple of 4")
+    if w.shape[-1] % 8:
+        raise ValueError("to_x3: the K dimension must be a multiple of 8")
     ws = w.float() * scale
     hi = ws.to(torch.float16)
     lo = (ws - hi.float()).to(torch.float16)
     sh = tuple(w.shape)
-    g = sh[:-1] + (sh[-1] // 4, 4)
+    g = sh[:-1] + (sh[-1] // 8, 8)
     return torch.stack([hi.reshape(g), lo.reshape(g)], dim=-2).reshape(sh[:-1] + (sh[-1] * 2,)).contiguous().view(torch.float32)
 
 

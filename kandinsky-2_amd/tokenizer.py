@@ -4,8 +4,9 @@ The reference builds `kandinsky2.model.prior.CustomizedTokenizer()` (prior.py:38
 merges file that ships inside that package (`bpe_simple_vocab_16e6.txt.gz`) plus `padded_tokens_and_mask`.  `clip` is an un-vendored,
 un-pinned dependency that is not installed here, so the published algorithm of its `simple_tokenizer.py` is restated:
 
-  text -> html-unescape twice, strip, collapse whitespace, lower-case            (the reference also runs ftfy.fix_text first: a no-op
-                                                                                  on well-formed text; ftfy is not a dependency here)
+  text -> ftfy.fix_text (ftfy itself when importable, else the fixes of its default configuration that touch well-encoded text,
+          restated in fix_text: uncurled quotes, fullwidth -> ASCII, ligatures, control characters, line breaks, NFC)
+       -> html-unescape twice, strip, collapse whitespace, lower-case
        -> regex split: the two specials | 's 't 're 've 'm 'll 'd | letters+ | ONE digit | other non-space runs
        -> UTF-8 bytes of each piece mapped to 256 printable unicode characters (GPT-2's byte table)
        -> byte-pair merges, lowest rank first, the last symbol of a piece carrying "</w>"
@@ -115,8 +116,47 @@ class ClipBPETokenizer:
         return out
 
     @staticmethod
-    def clean(text: str) -> str:
-        text = html.unescape(html.unescape(text)).strip()
+    def fix_text(text: str) -> str:
+        """The reference's basic_clean starts with ftfy.fix_text.  With ftfy installed that is what runs; without it (this image) the
+        fixes of ftfy's DEFAULT configuration that change the tokens of well-encoded text are restated: curly quotes -> straight ones
+        (uncurl_quotes), fullwidth Latin letters / digits / punctuation -> ASCII and halfwidth katakana -> standard (fix_character_width),
+        Latin ligatures -> letters (fix_latin_ligatures), C0 / C1 control characters except tab, newline and carriage return removed
+        (remove_control_chars), line breaks \r\n, \r, U+2028, U+2029, U+0085 -> \n (fix_line_breaks), then NFC.  ftfy's mojibake repair
+        (text that was decoded with the wrong codec) is NOT restated: such prompts tokenize as they are."""
+        try:
+            import ftfy
+            return ftfy.fix_text(text)
+        except ImportError:
+            pass
+        import unicodedata
+        quotes = {0x2018: "'", 0x2019: "'", 0x201a: "'", 0x201b: "'", 0x2032: "'", 0x201c: '"', 0x201d: '"', 0x201e: '"', 0x201f: '"', 0x2033: '"'}
+        ligatures = {0xfb00: "ff", 0xfb01: "fi", 0xfb02: "fl", 0xfb03: "ffi", 0xfb04: "ffl", 0xfb05: "ſt", 0xfb06: "st", 0x0132: "IJ", 0x0133: "ij",
+                     0x01c4: "DŽ", 0x01c5: "Dž", 0x01c6: "dž", 0x01c7: "LJ", 0x01c8: "Lj", 0x01c9: "lj", 0x01ca: "NJ", 0x01cb: "Nj", 0x01cc: "nj"}
+        text = text.replace("\r\n", "\n").replace("\r", "\n").replace("\u2028", "\n").replace("\u2029", "\n").replace("\u0085", "\n")
+        out = []
+        for ch in text:
+            o = ord(ch)
+            if o in quotes:
+                out.append(quotes[o])
+            elif o in ligatures:
+                out.append(ligatures[o])
+            elif 0xff01 <= o <= 0xff5e:                  # fullwidth ASCII block
+                out.append(chr(o - 0xfee0))
+            elif o == 0x3000:                            # ideographic space
+                out.append(" ")
+            elif 0xff61 <= o <= 0xffdc or 0xffe0 <= o <= 0xffee:   # halfwidth CJK punctuation / katakana / hangul, fullwidth signs
+                out.append(unicodedata.normalize("NFKC", ch))
+            elif (o < 0x20 and ch not in "\t\n") or 0x7f <= o <= 0x9f or o == 0xfeff:
+                continue
+            else:
+                out.append(ch)
+        return unicodedata.normalize("NFC", "".join(out))
+
+    @classmethod
+    def clean(cls, text: str) -> str:
+        """basic_clean + whitespace_clean + lower of the reference's tokenizer (OpenAI CLIP simple_tokenizer, used through
+        kandinsky2/model/prior.py:394-416 and the text encoders)."""
+        text = html.unescape(html.unescape(cls.fix_text(text))).strip()
         return " ".join(text.split()).lower()       # \s+ -> one space, strip (str.split() splits on the same unicode whitespace)
 
     def encode(self, text: str) -> List[int]:

@@ -148,21 +148,8 @@ class Text2ImUNetHIP(nn.Module):
         last_off, last_n = list(t.values())[-1]
         return (last_off + (last_n + 255) // 256 * 256) + 256
 
-    def prepare(self, arena: Optional[torch.Tensor] = None, free_params: bool = False):
-        """Packs the weights (or adopts a broadcast arena) and creates the native engine."""
-        dev = arena.device if arena is not None else next(self.parameters()).device
-        if dev.type != "cuda":
-            raise RuntimeError("Text2ImUNetHIP runs on the GPU only (no CPU fallback): move it with .to('cuda')")
-        L = _lib.lib()
-        self._release()
-        self._arena_adopted = arena is not None
-        if arena is None:
-            arena, table = pack_arena(self.arch, self.state_dict(), self.backend_dtype, dev)
-        else:
-            table = self.arena_table()
-            if arena.numel() < self.arena_bytes() or arena.dtype != torch.uint8:
-                raise ValueError("arena does not match this architecture/dtype")
-        self._arena = arena
+    def _engine_config(self):
+        """K22UNetConfig of this architecture / dtype (host-side only: no device is touched)"""
         a = self.arch
         cfg = _lib.K22UNetConfig()
         cfg.dtype = _lib.dtype_code(self.backend_dtype)
@@ -185,6 +172,24 @@ class Text2ImUNetHIP(nn.Module):
         cfg.image_dim = a.image_dim
         cfg.head_type = 1 if a.head == "2.2" else 0
         cfg.hint_channels = a.hint_channels
+        return cfg
+
+    def prepare(self, arena: Optional[torch.Tensor] = None, free_params: bool = False):
+        """Packs the weights (or adopts a broadcast arena) and creates the native engine."""
+        dev = arena.device if arena is not None else next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("Text2ImUNetHIP runs on the GPU only (no CPU fallback): move it with .to('cuda')")
+        L = _lib.lib()
+        self._release()
+        self._arena_adopted = arena is not None
+        if arena is None:
+            arena, table = pack_arena(self.arch, self.state_dict(), self.backend_dtype, dev)
+        else:
+            table = self.arena_table()
+            if arena.numel() < self.arena_bytes() or arena.dtype != torch.uint8:
+                raise ValueError("arena does not match this architecture/dtype")
+        self._arena = arena
+        cfg = self._engine_config()
         base = arena.data_ptr()
         arr = (_lib.K22Weight * len(table))()
         names = []

@@ -508,15 +508,15 @@ def test_movq_oracle_matches_reference_golden_256px(golden_dir):
 
 # ---- split-precision engine (K22_F16X3, round 4): host side ---------------------------------------------------------------------------
 def test_x3_chunk_packer_carries_23_bits_and_keeps_the_shape():
-    """pack.to_x3 (what the arena holds for the split-precision engine; csrc/common.h "x3 chunk"): every 4 consecutive K elements ->
-    [hi x4 | lo x4] fp16, hi = rne(x * scale), lo = rne(x * scale - hi); 4 bytes per element, same shape."""
+    """pack.to_x3 (what the arena holds for the split-precision engine; csrc/common.h "x3 chunk"): every 8 consecutive K elements ->
+    [hi x8 | lo x8] fp16, hi = rne(x * scale), lo = rne(x * scale - hi); 4 bytes per element, same shape."""
     from kandinsky2_amd.pack import to_x3
     g = torch.Generator().manual_seed(0)
     x = torch.cat([torch.randn(2048, generator=g), torch.randn(2048, generator=g) * 1e-3, torch.randn(2048, generator=g) * 50]).view(48, 128)
     for scale in (1.0, 256.0):
         p = to_x3(x, scale)
         assert p.shape == x.shape and p.dtype == torch.float32
-        h = p.view(torch.float16).double().view(48, 32, 2, 4)
+        h = p.view(torch.float16).double().view(48, 16, 2, 8)
         rec = (h[:, :, 0] + h[:, :, 1]).reshape(48, 128) / scale
         err = (rec - x.double()).abs()
         assert (err <= torch.maximum(x.double().abs() * 2.0 ** -22, torch.full_like(err, 2.0 ** -24 / scale))).all()
@@ -675,6 +675,11 @@ def test_clip_bpe_tokenizer_equals_the_transformers_implementation(tmp_path):
         assert tok.encode(tok.decode(tok.encode(ptxt))) == want      # decode separates the word-final symbols by spaces, as OpenAI's does
     # html entities are unescaped (twice) before anything else, as OpenAI's basic_clean does (transformers' fallback cleaner does not)
     assert tok.encode("cats &amp;amp; dogs") == tok.encode("cats & dogs")
+    # ftfy.fix_text (the first step of the reference's basic_clean): typographic quotes, decomposed accents, fullwidth letters,
+    # ligatures and control characters tokenize like their plain forms - the fixes of ftfy's default configuration, restated where ftfy is absent
+    for fancy, plain in (("the cat\u2019s \u201cwhiskers\u201d", "the cat's \"whiskers\""), ("cafe\u0301 nai\u0308ve", "caf\u00e9 na\u00efve"),
+                         ("\uff52\uff45\uff44 \uff43\uff41\uff54", "red cat"), ("\ufb01ne \ufb02oor", "fine floor"), ("a red\x07 cat\u0085photo", "a red cat photo")):
+        assert tok.encode(fancy) == tok.encode(plain), fancy
     # the plain-text merges.txt form reads the same
     assert ClipBPETokenizer(str(tmp_path / "merges.txt")).encode(prompts[1]) == tok.encode(prompts[1])
     # padded_tokens_and_mask: prior.py:394-416

@@ -93,3 +93,61 @@ def test_self_launcher_fails_loudly():
         launch_ranks(_launched_rank, 4, args=("/tmp",), devices_visible=1)       # never a quiet single-rank run
     with pytest.raises(RuntimeError, match="ranks failed"):
         launch_ranks(_failing_rank, 2)
+
+
+def _plan_worker(rank, world, port, q):
+    """a rank that RECEIVES the arena builds the same engine as rank 0 - same bytes, same plan, same tile configuration
+    (= same fp32 summation orders = same bits) - because the configuration is a function of the problem shapes and the shipped tile table
+    only.  k22_unet_create / k22_unet_plan / k22_unet_tuning_report are host code: they run here without a GPU."""
+    import ctypes as C
+    import kandinsky2_amd as k22
+    from kandinsky2_amd import _lib
+    from kandinsky2_amd.pack import pack_arena
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        arch = k22.make_arch(k22.tiny_model_config())
+        m = k22.Text2ImUNetHIP(arch, backend_dtype=torch.bfloat16, meta_params=rank != 0)
+        table = m.arena_table()
+        mine = None
+        if rank == 0:
+            mine, t0 = pack_arena(arch, k22.init_unet_state_dict(arch, seed=0), torch.bfloat16, "cpu")
+            assert list(t0.items()) == list(table.items())          # the layout derived from shapes only is the layout rank 0 packed
+        arena = broadcast_arena(mine, m.arena_bytes() if rank else mine.numel(), "cpu", src=0, chunk_bytes=1 << 22)
+        L = _lib.lib()
+        cfg = m._engine_config()
+        arr = (_lib.K22Weight * len(table))()
+        names = [n.encode() for n in table]
+        for i, (name, (off, _n)) in enumerate(table.items()):
+            arr[i].name = names[i]
+            arr[i].ptr = arena.data_ptr() + off
+        h = C.c_void_p()
+        _lib.check(L.k22_unet_create(C.byref(cfg), arr, len(table), C.byref(h)))
+        nbytes = C.c_size_t()
+        _lib.check(L.k22_unet_plan(h, 2, 16, 16, C.byref(nbytes)))
+        buf = C.create_string_buffer(1 << 16)
+        _lib.check(L.k22_unet_tuning_report(h, buf, len(buf)))
+        L.k22_unet_destroy(h)
+        import hashlib
+        digest = hashlib.sha256(arena.numpy().tobytes()).hexdigest()
+        got = [None] * world
+        dist.all_gather_object(got, (digest, nbytes.value, buf.value.decode()))
+        q.put((rank, got))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_rank_that_receives_the_arena_plans_the_same_engine_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_plan_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for _rank, got in res:
+        assert got[0] == got[1], "arena bytes, workspace size and tile configurations must be equal on every rank"
+        assert "taps" in got[0][2] and got[0][1] > 0

@@ -256,7 +256,9 @@ def test_plms_step_kernel_matches_the_oracle_arithmetic():
         pred_x0 = (x - s1m * ep) / a_t.sqrt()
         ref = a_prev.sqrt() * pred_x0 + (1.0 - a_prev - torch.tensor(0.0) ** 2).sqrt() * ep
         assert torch.equal(e_out.cpu(), e), f"eps order {order}"
-        assert torch.allclose(x_out.cpu(), ref, rtol=2e-6, atol=2e-6), f"x_prev order {order}: {(x_out.cpu() - ref).abs().max().item():.3e}"
+        # a few ulp of the two products that are added (|sqrt(a_prev) x0| reaches ~10 here: 1 ulp = 9.5e-7): 3.8e-6 measured on the round-6
+        # build (no packed-fp32 instructions; rounds 3-5: 1.9e-6)
+        assert torch.allclose(x_out.cpu(), ref, rtol=2e-6, atol=6e-6), f"x_prev order {order}: {(x_out.cpu() - ref).abs().max().item():.3e}"
 
 
 def test_rank_nonzero_path_adopts_a_broadcast_arena():

@@ -43,7 +43,7 @@ def x3_pack(t, scale=1.0):
 def x3_unpack(t):
     """x3 chunks -> the value the MFMAs see (hi + lo), float64"""
     h = t.contiguous().view(torch.float16).double()
-    g = h.view(*t.shape[:-1], t.shape[-1] // 4, 2, 4)
+    g = h.view(*t.shape[:-1], t.shape[-1] // 8, 2, 8)      # groups of eight: [hi x8 | lo x8]
     return (g[..., 0, :] + g[..., 1, :]).reshape(t.shape)
 
 
