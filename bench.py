@@ -130,7 +130,7 @@ def run(a):
     v22 = a.head == "2.2" or a.controlnet
     if world != 1 or v22 or a.tiny:
         a.no_traffic = True     # the PMC self-run covers the 2.1-head workloads at N = 1
-    chains = a.chains or (2 if (a.bs == 1 and not v22 and not a.no_graph) else 1)
+    chains = a.chains or 1
     if v22:
         chains = 1
     mkw = {} if v22 else {"chains": chains}
@@ -351,6 +351,23 @@ def run(a):
                         print(f"bench: gate-holding timed region failed: {e}", file=sys.stderr)
                 else:
                     gate["steps_per_s"], gate["protocol"] = round(value, 3), "the headline itself"
+        # the same workload as two half-batch chains (Text2ImUNetHIP(chains=2)): a second engine, the headline's protocol
+        two = None
+        if chains == 1 and default_21 and world == 1 and a.bs == 1 and not a.no_graph and not a.no_parity:
+            try:
+                m2c = Model(arch, backend_dtype=tdt, use_graph=True, chains=2)
+                m2c.load_state_dict(sd)
+                m2c = m2c.to(dev)
+                m2c.prepare(free_params=True)
+                x2c = torch.randn(B, 4, lat, lat, generator=torch.Generator().manual_seed(42)).to(dev)
+                el2, _ = timed_region(m2c, x2c, torch.empty_like(x2c), False)
+                two = {"value": round(a.steps / el2, 3), "ms_per_step": round(el2 / a.steps * 1e3, 3), "vs_one_chain": round(el / el2, 4),
+                       "what": "the CFG pair as two half-batch engines side by side on two streams (per step two forward graphs + the sampler step, "
+                               "host-driven); same protocol, same box, right after the headline; opt-in: --chains 2 / K22_CHAINS=2"}
+                del m2c
+                torch.cuda.empty_cache()
+            except Exception as e:
+                print(f"bench: two-chain pass failed: {e}", file=sys.stderr)
         line = {
             "metric": "UNet denoise steps/sec @ 768x768 bs=1, 50 steps" if (a.size == 768 and a.bs == 1) else
                       f"UNet denoise steps/sec @ {a.size}x{a.size} bs={a.bs}" + (" inpainting" if a.inpaint else ""),
@@ -371,7 +388,7 @@ def run(a):
                                                          f"two half-batch chains: per step two forward graphs replayed side by side on two streams + the sampler step, host-driven ({a.steps} timed steps)")},
             "images_per_sec_denoise_only": round(world * a.bs * a.steps / el / a.sched_steps, 4),
             "finite": finite, "load_s": round(t_load, 1),
-            "gate_holding": gate, "box": None if a.no_box else box_state(dev),
+            "gate_holding": gate, "two_chains": two, "box": None if a.no_box else box_state(dev),
             "roofline": roofline, "cpu_baseline": cpu, "parity_paths": parity, "e2e": e2e,
         }
         print(json.dumps(line))
@@ -393,7 +410,7 @@ def _seeded_pipeline(a, arch, sd, dev, tdt):
     marc = k22.MoVQArch(k22.MOVQ_CONFIG_2_1["ddconfig"])
     cfg["image_enc_params"]["ckpt_path"] = dict(k22.init_movq_state_dict(marc, seed=0))
     return k22.Kandinsky2_1HIP(cfg, sd, k22.init_prior_state_dict(hp, seed=0), str(dev), task_type="text2img", conditioner="seeded",
-                               backend_dtype=tdt, chains=(a.chains or (2 if a.bs == 1 else 1)))
+                               backend_dtype=tdt, chains=(a.chains or 1))
 
 
 def e2e_pass(a, arch, sd, dev, tdt, dist_on, world):

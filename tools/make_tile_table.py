@@ -192,6 +192,9 @@ def main():
         unet22(t22, True, [(4, 16, 24), (4, 16, 16)])
         unet(k22.MODEL_CONFIG_2_1, False, [(2, 32, 32), (2, 96, 96), (2, 64, 64), (4, 96, 96), (8, 96, 96), (2, 128, 128), (8, 128, 128)], dtypes=(torch.bfloat16,))
         unet(k22.MODEL_CONFIG_2_1, False, [(2, 32, 32), (2, 96, 96), (8, 128, 128)], dtypes=(torch.float32, k22.F16X3))
+        unet(k22.MODEL_CONFIG_2_1, False, [(1, 96, 96), (1, 32, 32)], dtypes=(torch.bfloat16, torch.float32))   # the half-batch chains of Text2ImUNetHIP(chains=2)
+        unet(tiny, False, [(1, 16, 16), (2, 8, 24)], dtypes=every + (k22.F16X2,))
+        unet(tiny, True, [(2, 16, 24), (1, 16, 16)], dtypes=every + (k22.F16X2,))
         unet(k22.MODEL_CONFIG_2_1, True, [(8, 96, 96), (2, 96, 96)], dtypes=(torch.bfloat16,))
         unet(k22.MODEL_CONFIG_2_1, True, [(8, 96, 96)], dtypes=(torch.float32, k22.F16X3))
         unet22(k22.UNET_CONFIG_2_2, False, [(2, 96, 96), (2, 32, 32)], dtypes=(torch.bfloat16,))
@@ -205,7 +208,7 @@ def main():
         n0 = _lib.lib().k22_tile_table_size()
         unet(tiny, False, [(2, 16, 16), (4, 8, 24), (4, 16, 16)], dtypes=x2)
         unet(tiny, True, [(4, 16, 24), (2, 16, 16), (4, 16, 16)], dtypes=x2)
-        unet(k22.MODEL_CONFIG_2_1, False, [(2, 96, 96), (2, 32, 32), (8, 128, 128)], dtypes=x2)
+        unet(k22.MODEL_CONFIG_2_1, False, [(2, 96, 96), (2, 32, 32), (8, 128, 128), (1, 96, 96)], dtypes=x2)   # (1, ...): the half-batch chains
         unet(k22.MODEL_CONFIG_2_1, True, [(8, 96, 96)], dtypes=x2)
         n = _lib.lib().k22_tile_table_save(out.encode())
         print(f"{n0} shipped + {n - n0} new = {n} entries -> {out}")
@@ -215,7 +218,7 @@ def main():
         n0 = _lib.lib().k22_tile_table_size()
         unet(tiny, False, [(2, 16, 16), (4, 8, 24), (4, 16, 16)], dtypes=x3)
         unet(tiny, True, [(4, 16, 24), (2, 16, 16), (4, 16, 16)], dtypes=x3)
-        unet(k22.MODEL_CONFIG_2_1, False, [(2, 32, 32), (2, 96, 96), (8, 128, 128)], dtypes=x3)
+        unet(k22.MODEL_CONFIG_2_1, False, [(2, 32, 32), (2, 96, 96), (8, 128, 128), (1, 96, 96), (4, 96, 96)], dtypes=x3)
         unet(k22.MODEL_CONFIG_2_1, True, [(8, 96, 96)], dtypes=x3)
         n = _lib.lib().k22_tile_table_save(out.encode())
         print(f"{n0} shipped + {n - n0} new = {n} entries -> {out}")
