@@ -31,6 +31,7 @@ from typing import Optional, Sequence
 import numpy as np
 import torch
 
+from . import _lib
 from .arch import DIFFUSION_CONFIG_2_1, MODEL_CONFIG_2_1, make_arch
 from .diffusion import DDIMSamplerHIP, PLMSSamplerHIP, create_gaussian_diffusion
 from .movq import MOVQ_CONFIG_2_1, MoVQDecoderHIP, MoVQEncoderHIP
@@ -420,10 +421,17 @@ class _MoVQ:
 def aux_engine_dtypes(backend_dtype, movq_dtype=None):
     """(prior / towers dtype, MoVQ dtype) that go with a UNet engine of `backend_dtype` - ONE rule for the 2.1 and the 2.2 drivers
     (pipeline22 had its own copy, which sent an fp16 MoVQ beside the "f16x3" engine).  The split-precision arithmetics are
-    strings and exist in the UNet engine only: everything beside them runs its fp32 parity path.  MoVQ: movq_dtype=None follows the
+    strings and exist in the UNet engine only: beside "f16x3" everything runs its fp32 parity path, beside "f16x2" fp16 (below).  MoVQ: movq_dtype=None follows the
     engines the way the reference does under use_fp16 (kandinsky2_1_model.py:92-94, 287-288): fp32 beside fp32-class engines, fp16
     beside 16-bit engines (also beside bf16: a bf16 decode moves pixels by up to 24 grey levels)."""
-    aux = torch.float32 if isinstance(backend_dtype, str) else backend_dtype
+    # round 6: beside the ASYMMETRIC split ("f16x2": weights at ~22 bits, activation operands at fp16) the prior, the towers and the MoVQ decode run
+    # in fp16, the reference's own use_fp16 practice - its activations are fp16-class anyway, and fp32 aux engines cost more than its whole
+    # denoise loop (e2e 1004 -> 67x ms per image; image-level distance measured: tests/test_pipeline_gpu.py::test_generate_text2img_f16x2_*).
+    # "f16x3" (the 1e-6-class engine) keeps everything beside it in fp32.
+    if backend_dtype == _lib.F16X2:
+        aux = torch.float16
+    else:
+        aux = torch.float32 if isinstance(backend_dtype, str) else backend_dtype
     movq = (torch.float32 if aux == torch.float32 else torch.float16) if movq_dtype is None else movq_dtype
     return aux, movq
 

@@ -259,3 +259,24 @@ def test_generate_img2img_and_mix_images_compose_the_same_pieces():
     assert torch.equal(emb_used[0], emb_used[1]) and torch.equal(emb_used[2], emb_used[3])
     assert torch.allclose(emb_used[2], pipe.create_zero_img_emb(1)[0])
     assert (emb_used[0] - want_img_part[0]).abs().max().item() > 0      # the prior's part is in there too
+
+
+def test_generate_text2img_f16x2_chain_with_fp16_aux_engines_stays_at_the_fp32_image():
+    """The gate-holding engine end to end (round 6: beside "f16x2" the prior, the towers and the MoVQ decode run in fp16 - pipeline.py:
+    aux_engine_dtypes): prompt -> image with injected noise against the all-fp32 chain.  Bounds = 3x what MI355X measured; the same chain with
+    fp32 aux engines (movq_dtype / the old rule) is printed beside it."""
+    p32, px2 = _pipe("text2img", torch.float32), _pipe("text2img", k22.F16X2)
+    assert px2.movq_dtype == torch.float16 and px2.prior.backend_dtype == torch.float16
+    g = torch.Generator().manual_seed(9)
+    x_T = torch.randn(2, 4, H // 8, W // 8, generator=g).cuda()
+    nz = torch.randn(6, 2, 4, H // 8, W // 8, generator=g).cuda()
+    pn, pz = torch.randn(2, 768, generator=g).cuda(), torch.randn(PRIOR_STEPS, 2, 768, generator=g).cuda()
+    kw = dict(num_steps=6, batch_size=1, guidance_scale=4.0, h=H, w=W, sampler="p_sampler", prior_steps=str(PRIOR_STEPS), noise=x_T,
+              noise_seq=nz, prior_noise=pn, prior_noise_seq=pz, output_type="uint8")
+    a, b = p32.generate_text2img("green tree", **kw), px2.generate_text2img("green tree", **kw)
+    d = np.abs(a.astype(np.int32) - b.astype(np.int32))
+    lat = (p32.last_latent - px2.last_latent).abs()
+    emb = (p32._last_image_emb - px2._last_image_emb).abs().max().item() / p32._last_image_emb.abs().max().item()
+    print(f"f16x2 chain (fp16 prior / MoVQ) vs fp32 chain: image_emb {emb:.3e} of scale; latent max|d| {lat.max().item():.3e} rms {lat.pow(2).mean().sqrt().item():.3e}; "
+          f"uint8 mean |d| {d.mean():.3f}, max {d.max()}, {100 * (d > 1).mean():.3f} % off by more than one level")
+    assert np.isfinite(lat.max().item()) and emb <= 5e-3 and d.mean() < 1.0
