@@ -449,6 +449,27 @@ def e2e_pass(a, arch, sd, dev, tdt, dist_on, world):
             fn()
         torch.cuda.synchronize()
         return (time.perf_counter() - t) / n * 1e3
+    # the same images as a pipeline over prompts (generate_text2img_many: prior of prompt i + 1 beside the denoise loop of prompt i beside the
+    # MoVQ decode of prompt i - 1, three streams): images per second of a prompt batch
+    piped = None
+    try:
+        n_p = max(4, a.e2e_images)
+
+        def many():
+            return pipe.generate_text2img_many([prompt] * n_p, num_steps=a.sched_steps, batch_size=a.bs, guidance_scale=4, h=a.size, w=a.size,
+                                               sampler="p_sampler", prior_cf_scale=4, prior_steps="25", output_type="tensor")
+        many()
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        outs = many()
+        torch.cuda.synchronize()
+        elp = time.perf_counter() - tp
+        piped = {"images_per_sec": round(a.bs * n_p / elp, 4), "ms_per_image": round(elp / n_p * 1e3, 2), "prompts": n_p,
+                 "ok": bool(all(tuple(o.shape) == (a.bs, a.size, a.size, 3) for o in outs)),
+                 "what": "Kandinsky2_1HIP.generate_text2img_many: the same generation for a list of prompts as a three-stage pipeline on three streams "
+                         "(per GPU; every image equals the sequential call's bit for bit: tests/test_pipeline_gpu.py)"}
+    except Exception as e:
+        print(f"bench: pipelined e2e pass failed: {e}", file=sys.stderr)
     prior_ms = timed(lambda: pipe.generate_clip_emb(prompt, batch_size=a.bs, prior_cf_scale=4, prior_steps="25"))
     lat = pipe.last_latent
     movq_ms = timed(lambda: pipe.image_encoder.decode(lat, return_uint8=True))
@@ -459,6 +480,7 @@ def e2e_pass(a, arch, sd, dev, tdt, dist_on, world):
     prior_bytes = 25 * hp_["xf_layers"] * 12 * hp_["xf_width"] ** 2 * esz
     return {"images_per_sec": round(world * a.bs * a.e2e_images / el, 4), "ms_per_call": round(per_image_ms, 2),
             "prior_weight_stream_tb_per_s": round(prior_bytes / (prior_ms * 1e-3) / 1e12, 3), "prior_ms_per_forward": round(prior_ms / 25, 3),
+            "pipelined_over_prompts": piped,
             "images_timed_per_gpu": a.e2e_images * a.bs, "ok": bool(tuple(img.shape) == (a.bs, a.size, a.size, 3)),
             "phases_ms": {"prior_25_steps": round(prior_ms, 2), "movq_decode_uint8": round(movq_ms, 2),
                           "denoise_and_host": round(per_image_ms - prior_ms - movq_ms, 2)},

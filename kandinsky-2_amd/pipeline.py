@@ -261,7 +261,9 @@ class Kandinsky2_1HIP:
     @torch.no_grad()
     def generate_img(self, prompt, img_prompt, batch_size=1, diffusion=None, guidance_scale=7, init_step=None, noise=None,
                      init_img=None, img_mask=None, h=512, w=512, sampler="ddim_sampler", num_steps=50,
-                     noise_seq: Optional[torch.Tensor] = None, output_type: str = "pil"):
+                     noise_seq: Optional[torch.Tensor] = None, output_type: str = "pil", *, text_embs=None, decode: bool = True):
+        """text_embs = (full_emb, pooled_emb) computed by the caller (generate_text2img_many computes them beside the prior, on its stream);
+        decode=False returns the final latents [batch_size, 4, h/8, w/8] and leaves the MoVQ decode to the caller."""
         new_h, new_w = self.get_new_h_w(h, w)
         full_batch_size = batch_size * 2
         if full_batch_size > 8:
@@ -271,7 +273,7 @@ class Kandinsky2_1HIP:
             # kandinsky2_amd.parallel.shard_range) are the supported way to a large batch.
             raise ValueError("batch_size must be <= 4 per call (CFG batch <= 8); shard larger batches over calls / ranks")
         model_kwargs = {}
-        model_kwargs["full_emb"], model_kwargs["pooled_emb"] = self.encode_text(prompt, batch_size)
+        model_kwargs["full_emb"], model_kwargs["pooled_emb"] = self.encode_text(prompt, batch_size) if text_embs is None else text_embs
         model_kwargs["image_emb"] = img_prompt.to(self.device).float()
         self._last_image_emb = model_kwargs["image_emb"]
         if self.task_type == "inpainting":
@@ -298,8 +300,67 @@ class Kandinsky2_1HIP:
             raise ValueError("Only ddim_sampler and plms_sampler is available")
         self.model.del_cache()
         self.last_latent = samples
+        if not decode:
+            return samples
+        return self._decode_images(samples, h, w, output_type)
+
+    def _decode_images(self, samples, h, w, output_type):
         _, u8 = self.image_encoder.decode(samples / self.scale, return_uint8=True)
         return process_images(u8[:, :h, :w].contiguous(), output_type)
+
+    # ---- a batch of prompts as a three-stage pipeline (BASELINE north star: "batch-of-prompts generation") -----------------------------
+    @torch.no_grad()
+    def generate_text2img_many(self, prompts, num_steps=100, batch_size=1, guidance_scale=7, h=512, w=512, sampler="ddim_sampler",
+                               prior_cf_scale=4, prior_steps="25", negative_prior_prompt="", negative_decoder_prompt="", *,
+                               noises=None, noise_seqs=None, prior_noises=None, prior_noise_seqs=None, output_type="pil"):
+        """generate_text2img for a LIST of prompts -> list of results, each equal to what generate_text2img(prompt, ...) returns for the same
+        noise.  The three engines of a generation (conditioning + prior | denoise loop | MoVQ decode) are independent between prompts, so they
+        run as a pipeline on three streams of the device: while the UNet denoises prompt i, the prior (a weight stream that leaves the matrix
+        cores idle) already samples the embedding of prompt i + 1 and the decoder finishes prompt i - 1.  The reference generates one prompt
+        after the other (kandinsky2_1_model.py:299-351); images per second of a prompt batch are bounded by the slowest stage instead of the
+        sum.  noises / noise_seqs / prior_noises / prior_noise_seqs: optional per-prompt lists (parity tests)."""
+        prompts = list(prompts)
+        n = len(prompts)
+        pick = lambda lst, i: None if lst is None else lst[i]          # noqa: E731
+        cur = torch.cuda.current_stream()
+        if getattr(self, "_pipe_streams", None) is None:
+            self._pipe_streams = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+        s_prior, s_dec = self._pipe_streams
+        s_prior.wait_stream(cur)
+        s_dec.wait_stream(cur)
+        _, diffusion = self._diffusion(sampler, num_steps)
+
+        def stage_a(i):
+            with torch.cuda.stream(s_prior):
+                emb = self._image_embs(prompts[i], batch_size, prior_cf_scale, prior_steps, negative_prior_prompt, negative_decoder_prompt,
+                                       noise=pick(prior_noises, i), noise_seq=pick(prior_noise_seqs, i))
+                txt = self.encode_text(prompts[i], batch_size)
+                ev = torch.cuda.Event()
+                ev.record(s_prior)
+            return emb, txt, ev
+
+        results, pending = [], stage_a(0) if n else None
+        for i in range(n):
+            emb, txt, ev = pending
+            cur.wait_event(ev)
+            for t in (emb,) + tuple(txt):
+                if torch.is_tensor(t):
+                    t.record_stream(cur)
+            pending = stage_a(i + 1) if i + 1 < n else None          # enqueued BEFORE this prompt's denoise loop: it overlaps it
+            lat = self.generate_img(prompt=prompts[i], img_prompt=emb, batch_size=batch_size, guidance_scale=guidance_scale, h=h, w=w,
+                                    sampler=sampler, num_steps=num_steps, diffusion=diffusion, noise=pick(noises, i), noise_seq=pick(noise_seqs, i),
+                                    output_type=output_type, text_embs=txt, decode=False)
+            ev_u = torch.cuda.Event()
+            ev_u.record(cur)
+            with torch.cuda.stream(s_dec):
+                s_dec.wait_event(ev_u)
+                lat.record_stream(s_dec)
+                results.append(self._decode_images(lat, h, w, "tensor"))
+        cur.wait_stream(s_dec)
+        cur.wait_stream(s_prior)
+        for r in results:
+            r.record_stream(cur)
+        return [process_images(r, output_type) if output_type != "tensor" else r for r in results]
 
     def _image_embs(self, prompt, batch_size, prior_cf_scale, prior_steps, negative_prior_prompt, negative_decoder_prompt, **prior_noise):
         image_emb = self.generate_clip_emb(prompt, batch_size=batch_size, prior_cf_scale=prior_cf_scale, prior_steps=prior_steps,

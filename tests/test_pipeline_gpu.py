@@ -280,3 +280,29 @@ def test_generate_text2img_f16x2_chain_with_fp16_aux_engines_stays_at_the_fp32_i
     print(f"f16x2 chain (fp16 prior / MoVQ) vs fp32 chain: image_emb {emb:.3e} of scale; latent max|d| {lat.max().item():.3e} rms {lat.pow(2).mean().sqrt().item():.3e}; "
           f"uint8 mean |d| {d.mean():.3f}, max {d.max()}, {100 * (d > 1).mean():.3f} % off by more than one level")
     assert np.isfinite(lat.max().item()) and emb <= 5e-3 and d.mean() < 1.0
+
+
+def test_generate_text2img_many_pipelines_prompts_and_equals_the_sequential_calls():
+    """generate_text2img_many: prior of prompt i + 1 | denoise loop of prompt i | MoVQ decode of prompt i - 1 on three streams.  Same engines, same
+    operands, same order inside each engine: every image and final latent equals the sequential generate_text2img call bit for bit - also on a
+    second pass (graphs replayed) and for the 16-bit engines."""
+    for backend in (torch.float32, torch.bfloat16):
+        pipe = _pipe("text2img", backend)
+        prompts = ["green tree", "a red cat", "blue bird on a wire", "green tree"]
+        g = torch.Generator().manual_seed(21)
+        mk = lambda *sh: [torch.randn(*sh, generator=g).cuda() for _ in prompts]   # noqa: E731
+        x_T, nz = mk(2, 4, H // 8, W // 8), mk(6, 2, 4, H // 8, W // 8)
+        pn, pz = mk(2, 768), mk(PRIOR_STEPS, 2, 768)
+        kw = dict(num_steps=6, batch_size=1, guidance_scale=4.0, h=H, w=W, sampler="p_sampler", prior_steps=str(PRIOR_STEPS))
+        seq, lats = [], []
+        for i, p in enumerate(prompts):
+            seq.append(pipe.generate_text2img(p, noise=x_T[i], noise_seq=nz[i], prior_noise=pn[i], prior_noise_seq=pz[i], output_type="tensor", **kw))
+            lats.append(pipe.last_latent.clone())
+        for _ in range(2):
+            many = pipe.generate_text2img_many(prompts, noises=x_T, noise_seqs=nz, prior_noises=pn, prior_noise_seqs=pz, output_type="tensor", **kw)
+            torch.cuda.synchronize()
+            assert len(many) == len(prompts)
+            for i in range(len(prompts)):
+                assert torch.equal(many[i], seq[i]), (backend, i, (many[i].int() - seq[i].int()).abs().max().item())
+        assert not torch.equal(many[0], many[1])          # different prompts / noise: different images
+        del pipe
