@@ -14,20 +14,27 @@
 #include "kernels.h"
 #include "elementwise.h"
 #include <type_traits>
+#include <stdlib.h>
 
 // V^T fragment whose K (= key) order matches the S^T accumulator registers:
 // element j<4 -> key 16a + 4h + j ; j>=4 -> key 16a + 8 + 4h + (j-4).
+// 16-bit tiles (round 6): the V^T tile is stored KEY-PERMUTED within every block of 16 keys - piece 2a + h' of a row holds
+// [keys 16a + 4h' .. + 3 | keys 16a + 8 + 4h' .. + 3] (vt_store16 below) - so that the fragment is ONE conflict-free ds_read_b128.  With the
+// natural key order it was two 8-byte reads gathered by six register moves per PV atom: 24 v_mov per 64-key tile, and the LDS array - not the
+// matrix pipe and not VALU issue - was what the tile loop waited for (ds_read2st64_b64: 8+ LDS cycles per wave-instruction against 4;
+// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 1.64 on this kernel, profiles/r05_pmc_mfma_bf16.txt).
 __device__ __forceinline__ void ld_frag_split(Frag<bf16_t>& f, const char* tile, int r, int a, int h) {
-  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
-  const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(tile + lds_chunk_off(r, 2 * a) + 8 * h);
-  const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(tile + lds_chunk_off(r, 2 * a + 1) + 8 * h);
-  f.v = u32x4_t{lo.x, lo.y, hi.x, hi.y};
+  f.v = *reinterpret_cast<const u32x4_t*>(tile + lds_chunk_off(r, 2 * a + h));
 }
 __device__ __forceinline__ void ld_frag_split(Frag<f16_t>& f, const char* tile, int r, int a, int h) {
+  f.v = *reinterpret_cast<const u32x4_t*>(tile + lds_chunk_off(r, 2 * a + h));
+}
+// stores keys 8 cc .. 8 cc + 7 (one 16-byte register, natural order) of V^T row `row` into the key-permuted 16-bit tile: keys +0..3 go to
+// piece 2 (cc >> 1), keys +4..7 to piece 2 (cc >> 1) + 1, both at byte 8 (cc & 1)
+__device__ __forceinline__ void vt_store16(char* tile, int row, int cc, const u32x4_t v) {
   typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
-  const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(tile + lds_chunk_off(r, 2 * a) + 8 * h);
-  const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(tile + lds_chunk_off(r, 2 * a + 1) + 8 * h);
-  f.v = u32x4_t{lo.x, lo.y, hi.x, hi.y};
+  *reinterpret_cast<u32x2_t*>(tile + lds_chunk_off(row, cc & ~1) + 8 * (cc & 1)) = u32x2_t{v.x, v.y};
+  *reinterpret_cast<u32x2_t*>(tile + lds_chunk_off(row, cc | 1) + 8 * (cc & 1)) = u32x2_t{v.z, v.w};
 }
 __device__ __forceinline__ void ld_frag_split(Frag<float>& f, const char* tile, int r, int a, int h) {
   const char* sub = tile + (a >> 1) * 8192;
@@ -118,7 +125,9 @@ __device__ __forceinline__ float max2f(float a, float b) {
   return r;
 }
 
-template <typename TS>
+// DBG (K22_ATT_PROBE builds only, wrong results; 32 = attention_pipe_kernel without its sched_group_barrier pins): 1 = the K / V^T tiles are staged once (no barriers, stores or global loads inside the loop),
+// 2 = no v_exp (p = the fma result), 4 = no S MFMAs, 8 = no PV MFMAs, 16 = no max / rescale.  tools/micro/attn_probe.hip
+template <typename TS, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void attention_kernel(AttentionParams p) {
   using T = typename AttC<TS>::type;          // arithmetic / LDS type
   constexpr bool MIX = AttC<TS>::MIX;         // fp32 tensors in memory, fp16 tiles and MFMAs (xh_t)
@@ -173,13 +182,16 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttentionParams p) {
       const int off = (cc >> 3) * 8192 + lds_chunk_off(row, cc & 7);                                     \
       if constexpr (MIX) {                                                                               \
         *reinterpret_cast<u32x4_t*>(Ks + off) = f16x8_from_f32(kreg[2 * i], kreg[2 * i + 1]);            \
-        *reinterpret_cast<u32x4_t*>(Vs + off) = f16x8_from_f32(vreg[2 * i], vreg[2 * i + 1]);            \
+        vt_store16(Vs, row, cc, f16x8_from_f32(vreg[2 * i], vreg[2 * i + 1]));                           \
       } else if constexpr (is_x3<T>::value) {   /* fp32 K / V^T rows -> x3 chunks, once per workgroup */    \
         /* groups of eight: logical chunks 2g / 2g + 1 = hi / lo pieces; this thread's four values own bytes 8 (cc & 1) .. of each */ \
         const u32x4_t ks_ = x3_split4(__builtin_bit_cast(float4, kreg[i])), vs_ = x3_split4(__builtin_bit_cast(float4, vreg[i])); \
         const int ohi_ = (cc >> 3) * 8192 + lds_chunk_off(row, (cc & 7) & ~1) + 8 * (cc & 1), olo_ = (cc >> 3) * 8192 + lds_chunk_off(row, (cc & 7) | 1) + 8 * (cc & 1); \
         *reinterpret_cast<u32x2_t*>(Ks + ohi_) = u32x2_t{ks_.x, ks_.y}; *reinterpret_cast<u32x2_t*>(Ks + olo_) = u32x2_t{ks_.z, ks_.w}; \
         *reinterpret_cast<u32x2_t*>(Vs + ohi_) = u32x2_t{vs_.x, vs_.y}; *reinterpret_cast<u32x2_t*>(Vs + olo_) = u32x2_t{vs_.z, vs_.w}; \
+      } else if constexpr (sizeof(T) == 2) {                                                             \
+        *reinterpret_cast<u32x4_t*>(Ks + off) = kreg[i];                                                 \
+        vt_store16(Vs, row, cc, vreg[i]);                                                                \
       } else {                                                                                           \
       *reinterpret_cast<u32x4_t*>(Ks + off) = kreg[i];                                                   \
       *reinterpret_cast<u32x4_t*>(Vs + off) = vreg[i];                                                   \
@@ -195,10 +207,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttentionParams p) {
 
   K22_ATT_GLOAD(0);
   for (int kt = 0; kt < nkt; ++kt) {
+    if (!(DBG & 1) || kt == 0) {
     __syncthreads();  // every wave finished reading the previous tile
     K22_ATT_LSTORE();
     __syncthreads();
     K22_ATT_GLOAD(kt + 1 < nkt ? kt + 1 : nkt - 1);
+    }
 
     f32x16_t s[2];
 #pragma unroll
@@ -209,7 +223,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttentionParams p) {
       for (int a = 0; a < 4; ++a) {
         Frag<T> kf;
         ld_frag(kf, Ks + (a / KSTEPS) * 8192, kb * 32 + l31, a % KSTEPS, h);
-        mma_atom(s[kb], kf, qf[a]);
+        if constexpr (DBG & 4) { if constexpr (sizeof(T) == 2) { s[kb][a] += __uint_as_float(kf.v.x); s[kb][a + 4] += __uint_as_float(qf[a].v.y); } }
+        else mma_atom(s[kb], kf, qf[a]);
       }
 
     // ---- online softmax, lane-local: p = exp2(s*c - m*c) with c = scale*log2(e) folded into ONE fma per
@@ -235,6 +250,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttentionParams p) {
     for (int r = 4; r < 16; ++r) mq[r & 3] = max3f(mq[r & 3], s[0][r], s[1][r]);
     float mloc = max2f(max3f(mq[0], mq[1], mq[2]), mq[3]);
     mloc = max2f(mloc, __shfl_xor(mloc, 32, 64));
+    if constexpr (DBG & 16) mloc = s[0][0];
     if (__any(mloc > m_run)) {
       const float m_new = max2f(m_run, mloc);
       const float alpha = exp2_t<T>((m_run - m_new) * cexp);
@@ -250,8 +266,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttentionParams p) {
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        const float e0 = exp2_t<T>(fmaf(s[kb][r], cexp, -mc));
-        const float e1 = exp2_t<T>(fmaf(s[kb][r + 1], cexp, -mc));
+        const float e0 = (DBG & 2) ? fmaf(s[kb][r], cexp, -mc) : exp2_t<T>(fmaf(s[kb][r], cexp, -mc));
+        const float e1 = (DBG & 2) ? fmaf(s[kb][r + 1], cexp, -mc) : exp2_t<T>(fmaf(s[kb][r + 1], cexp, -mc));
         pv[kb][r] = e0;
         pv[kb][r + 1] = e1;
         lsum2 += f32x2_t{e0, e1};
@@ -266,7 +282,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttentionParams p) {
       for (int db = 0; db < 2; ++db) {
         Frag<T> vf;
         ld_frag_split(vf, Vs, db * 32 + l31, a, h);
-        mma_atom(o[db], vf, pf);
+        if constexpr (DBG & 8) { if constexpr (sizeof(T) == 2) { o[db][a] += __uint_as_float(vf.v.x); o[db][a + 4] += __uint_as_float(pf.v.y); } }
+        else mma_atom(o[db], vf, pf);
       }
     }
   }
@@ -293,6 +310,257 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttentionParams p) {
         } else {
           *reinterpret_cast<float4*>(orow + d) =
               make_float4(o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+        }
+      }
+  }
+}
+
+// ---- attention_pipe_kernel (round 6): the same arithmetic for the UNet's unmasked 16-bit attention, SOFTWARE-PIPELINED ----------------------
+// What tools/micro/attn_probe.hip measured on attention_kernel at T = 2304 (12 heads, batch 2; profiles/r06_attention.txt): with ONE
+// workgroup per CU (one wave per SIMD) a 64-key tile takes ~2600 cycles of which the matrix pipe is busy 512 - 27 % of it is the two barriers
+// + tile stores of the single-buffered staging, 15 % the 32 v_exp_f32 (~12 cycles each), 15 % the max chain with its ds_bpermute round trip
+// and rescale branch, and the MFMAs of a tile are strictly serial with its softmax (S -> max -> exp -> P V); a second workgroup on the CU
+// recovers only a quarter of that.  This kernel removes the serialisation instead of adding waves:
+//   * K and V^T tiles DOUBLE-BUFFERED in the LDS (32 KB): ONE barrier per tile; the tile stores of iteration kt (K of tile kt + 2, V^T of
+//     tile kt + 1, prefetched into registers one iteration earlier) are issued right behind the barrier and have the whole iteration to land;
+//   * the S MFMAs of tile kt + 1 are issued in the same instruction stream as the softmax of tile kt (two score register sets, the loop is
+//     unrolled by two so that they swap roles without moves): the matrix pipe works under the VALU-bound part of the tile;
+//     (the issue order is pinned with sched_group_barrier: one MFMA, eight VALU, ... - the maxima are plain fmaxf here, not the inline-asm
+//     v_max3 of attention_kernel: inline asm is invisible to the instruction-group scheduler; and no DS-read groups: with them the group
+//     solver drops the whole pipeline - the address adds of the reads are VALU that would have to sit in a later group);
+//   * the cross-half maximum is ONE v_permlane32_swap (no LDS round trip), the accumulator rescale stays a wave-uniform branch but sits
+//     between the two MFMA phases;
+//   * only the last tile can be partial: its key mask is applied once, outside the common path (no causal / key_valid forms here -
+//     launch_attention keeps attention_kernel for those and for the 4-byte types).
+// Bit-identical to attention_kernel: the same operands in the same MFMA order, the same online-softmax decisions.
+__device__ __forceinline__ float xhalf_max(float v) {
+#if __has_builtin(__builtin_amdgcn_permlane32_swap)
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __builtin_fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+#else
+  return __builtin_fmaxf(v, __shfl_xor(v, 32, 64));
+#endif
+}
+
+template <typename TS, int DBG = 0>
+__global__ __launch_bounds__(256, 2) void attention_pipe_kernel(AttentionParams p) {
+  using T = typename AttC<TS>::type;
+  constexpr bool MIX = AttC<TS>::MIX;
+  using TG = typename std::conditional<MIX, float, T>::type;
+  static_assert(sizeof(T) == 2, "attention_pipe_kernel: 16-bit tiles");
+  constexpr int EPC = 8, CPR = 8, LCH = 2;
+  constexpr int GCH = MIX ? 2 * LCH : LCH;
+  __shared__ __attribute__((aligned(16))) char smem[4 * 8192];
+  char* const Kb = smem;           // K tile i at Kb + (i & 1) * 8192
+  char* const Vb = smem + 16384;   // V^T tile i (key-permuted, vt_store16) at Vb + (i & 1) * 8192
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int hd = blockIdx.y, b = blockIdx.z;
+  const int t = blockIdx.x * 128 + wave * 32 + l31;
+  const int tq = t < p.T ? t : p.T - 1;
+  const TG* qrow = reinterpret_cast<const TG*>(p.q) + (int64_t)(b * p.T + tq) * p.ldq + hd * 64;
+  Frag<T> qf[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) ld_qfrag(qf[a], qrow + 16 * a + 8 * h);
+  const TG* Kg = reinterpret_cast<const TG*>(p.kall) + (int64_t)(b * p.H + hd) * p.Tkp * 64;
+  const TG* Vg = reinterpret_cast<const TG*>(p.vtall) + (int64_t)(b * p.H + hd) * 64 * p.Tkp;
+  const int nkt = (p.Tk + 63) / 64;
+
+  u32x4_t kreg[GCH], vreg[GCH];
+#define K22_AP_KLOAD(KT)                                                                                 \
+  {                                                                                                      \
+    const int kt_ = (KT) < nkt ? (KT) : nkt - 1;                                                         \
+    _Pragma("unroll") for (int i = 0; i < LCH; ++i) {                                                    \
+      const int q = tid + i * 256, row = q / CPR, cc = q - row * CPR;                                    \
+      if constexpr (MIX) {                                                                               \
+        const float* kp_ = reinterpret_cast<const float*>(Kg) + (int64_t)(kt_ * 64 + row) * 64 + cc * EPC; \
+        kreg[2 * i] = *reinterpret_cast<const u32x4_t*>(kp_); kreg[2 * i + 1] = *reinterpret_cast<const u32x4_t*>(kp_ + 4); \
+      } else {                                                                                           \
+        kreg[i] = *reinterpret_cast<const u32x4_t*>(Kg + (int64_t)(kt_ * 64 + row) * 64 + cc * EPC);     \
+      }                                                                                                  \
+    }                                                                                                    \
+  }
+#define K22_AP_VLOAD(KT)                                                                                 \
+  {                                                                                                      \
+    const int kt_ = (KT) < nkt ? (KT) : nkt - 1;                                                         \
+    _Pragma("unroll") for (int i = 0; i < LCH; ++i) {                                                    \
+      const int q = tid + i * 256, row = q / CPR, cc = q - row * CPR;                                    \
+      if constexpr (MIX) {                                                                               \
+        const float* vp_ = reinterpret_cast<const float*>(Vg) + (int64_t)row * p.Tkp + kt_ * 64 + cc * EPC; \
+        vreg[2 * i] = *reinterpret_cast<const u32x4_t*>(vp_); vreg[2 * i + 1] = *reinterpret_cast<const u32x4_t*>(vp_ + 4); \
+      } else {                                                                                           \
+        vreg[i] = *reinterpret_cast<const u32x4_t*>(Vg + (int64_t)row * p.Tkp + kt_ * 64 + cc * EPC);    \
+      }                                                                                                  \
+    }                                                                                                    \
+  }
+#define K22_AP_KSTORE(DST)                                                                               \
+  {                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < LCH; ++i) {                                                    \
+      const int q = tid + i * 256, row = q / CPR, cc = q - row * CPR;                                    \
+      if constexpr (MIX) *reinterpret_cast<u32x4_t*>((DST) + lds_chunk_off(row, cc)) = f16x8_from_f32(kreg[2 * i], kreg[2 * i + 1]); \
+      else *reinterpret_cast<u32x4_t*>((DST) + lds_chunk_off(row, cc)) = kreg[i];                        \
+    }                                                                                                    \
+  }
+#define K22_AP_VSTORE(DST)                                                                               \
+  {                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < LCH; ++i) {                                                    \
+      const int q = tid + i * 256, row = q / CPR, cc = q - row * CPR;                                    \
+      if constexpr (MIX) vt_store16((DST), row, cc, f16x8_from_f32(vreg[2 * i], vreg[2 * i + 1]));       \
+      else vt_store16((DST), row, cc, vreg[i]);                                                          \
+    }                                                                                                    \
+  }
+  // the eight K fragments of a tile (KF[2 * 4]: key block kb, k-step a) / its eight V^T fragments (VF[4 * 2]: 16-key block a, d block db)
+#define K22_AP_KREAD(KF, KT_BUF)                                                                         \
+  {                                                                                                      \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                     \
+      _Pragma("unroll") for (int a = 0; a < 4; ++a) ld_frag(KF[kb * 4 + a], (KT_BUF), kb * 32 + l31, a, h); \
+  }
+#define K22_AP_VREAD(VF, VT_BUF)                                                                         \
+  {                                                                                                      \
+    _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                        \
+      _Pragma("unroll") for (int db = 0; db < 2; ++db) ld_frag_split(VF[a * 2 + db], (VT_BUF), db * 32 + l31, a, h); \
+  }
+  // S^T tile = K tile . Q^T into SC (zeroed here)
+#define K22_AP_S(SC, KF)                                                                                 \
+  {                                                                                                      \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                   \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) SC[kb][r] = 0.f;                                    \
+      _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                                    \
+        if constexpr (DBG & 4) { SC[kb][a] += __uint_as_float(KF[kb * 4 + a].v.x); SC[kb][a + 4] += __uint_as_float(qf[a].v.y); } \
+        else mma_atom(SC[kb], KF[kb * 4 + a], qf[a]);                                                    \
+      }                                                                                                  \
+    }                                                                                                    \
+  }
+
+  f32x16_t o[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+  float m_run = -1e30f, l_run = 0.f;
+  const float cexp = p.scale * 1.4426950408889634f;
+
+  // prologue: K tiles 0 and 1 and V^T tile 0 in the LDS, K tile 2 and V^T tile 1 on their way into the registers, S of tile 0
+  K22_AP_KLOAD(0);
+  K22_AP_VLOAD(0);
+  K22_AP_KSTORE(Kb);
+  K22_AP_VSTORE(Vb);
+  K22_AP_KLOAD(1);
+  K22_AP_KSTORE(Kb + 8192);
+  K22_AP_KLOAD(2);
+  K22_AP_VLOAD(1);
+  __syncthreads();
+  f32x16_t s0[2], s1[2];
+  {
+    Frag<T> kf0[8];
+    K22_AP_KREAD(kf0, Kb);
+    K22_AP_S(s0, kf0);
+  }
+
+  // one tile: SC = its scores (complete), SN = the next tile's (issued here); PAR = kt & 1 (compile time)
+#define K22_AP_TILE(SC, SN, PAR, KT)                                                                     \
+  {                                                                                                      \
+    if constexpr (!(DBG & 1)) {                                                                          \
+    __syncthreads();   /* K tile kt + 1 / V^T tile kt visible; every wave is done with K tile kt and V^T tile kt - 1 */ \
+    K22_AP_KSTORE(Kb + (PAR) * 8192);          /* K tile kt + 2 */                                       \
+    K22_AP_VSTORE(Vb + (1 - (PAR)) * 8192);    /* V^T tile kt + 1 */                                     \
+    K22_AP_KLOAD((KT) + 3);                                                                              \
+    K22_AP_VLOAD((KT) + 2);                                                                              \
+    }                                                                                                    \
+    if ((KT) == nkt - 1 && (p.Tk & 63)) {      /* the one partial tile */                                \
+      _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                   \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                   \
+          if ((KT) * 64 + kb * 32 + c_row(r, lane) >= p.Tk) SC[kb][r] = -INFINITY;                       \
+    }                                                                                                    \
+    /* every fragment read of the tile is issued HERE, ahead of the arithmetic (sched_barrier: nothing moves across): behind the MFMA that   \
+       uses it a ds_read_b128 costs its full LDS latency per MFMA - the first form of this kernel waited ~100 cycles in front of each */    \
+    Frag<T> kf_[8], vf_[8];                                                                              \
+    K22_AP_KREAD(kf_, Kb + (1 - (PAR)) * 8192);                                                          \
+    K22_AP_VREAD(vf_, Vb + (PAR) * 8192);                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    /* phase A: S of the next tile (matrix pipe) under the softmax of this one (VALU).  One basic block, issue order pinned:        \
+       four K-fragment reads and the max chain first (the chain covers the read latency), then one MFMA + one read + a share of the    \
+       fma / v_exp pairs, eight times - an MFMA occupies the pipe for 32 cycles, during which the wave issues the VALU behind it. */   \
+    K22_AP_S(SN, kf_);                                                                                   \
+    float mq[4];                                                                                         \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) mq[c] = __builtin_fmaxf(SC[0][c], SC[1][c]);           \
+    _Pragma("unroll") for (int r = 4; r < 16; ++r) mq[r & 3] = __builtin_fmaxf(__builtin_fmaxf(mq[r & 3], SC[0][r]), SC[1][r]); \
+    const float mloc = xhalf_max(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(mq[0], mq[1]), mq[2]), mq[3])); \
+    const float m_old = m_run;                                                                           \
+    m_run = (DBG & 16) ? SC[0][0] : __builtin_fmaxf(m_run, mloc);                                        \
+    const float mc = m_run * cexp;                                                                       \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                     \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                     \
+        SC[kb][r] = (DBG & 2) ? fmaf(SC[kb][r], cexp, -mc) : __builtin_amdgcn_exp2f(fmaf(SC[kb][r], cexp, -mc)); \
+    if constexpr (!(DBG & 32)) {                                                                         \
+    __builtin_amdgcn_sched_group_barrier(0x002, 30, 0);                                                  \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                   \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                 \
+      __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                                                 \
+    }                                                                                                    \
+    }                                                                                                    \
+    /* everything above belongs in front of the rescale branch (the compiler would otherwise sink the v_exp block behind it) */        \
+    asm volatile("" : "+v"(SC[0]), "+v"(SC[1]), "+v"(SN[0]), "+v"(SN[1]));                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    /* rescale where a maximum rose (wave-uniform; rare after the first tiles) */                        \
+    if (__any(m_run > m_old)) {                                                                          \
+      const float alpha = __builtin_amdgcn_exp2f((m_old - m_run) * cexp);                                \
+      l_run *= alpha;                                                                                    \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }             \
+    }                                                                                                    \
+    /* phase B: P V (matrix pipe) under the row sums and the P conversions (VALU) */                     \
+    _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                                      \
+      Frag<T> pf;                                                                                        \
+      float pv_[8];                                                                                      \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) pv_[j] = SC[a >> 1][8 * (a & 1) + j];                \
+      make_pfrag(pf, pv_);                                                                               \
+      _Pragma("unroll") for (int db = 0; db < 2; ++db) {                                                 \
+        if constexpr (DBG & 8) { o[db][a] += __uint_as_float(vf_[a * 2 + db].v.x); o[db][a + 4] += __uint_as_float(pf.v.y); } \
+        else mma_atom(o[db], vf_[a * 2 + db], pf);                                                       \
+      }                                                                                                  \
+    }                                                                                                    \
+    float lsa = 0.f, lsb = 0.f;                                                                          \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                     \
+      _Pragma("unroll") for (int r = 0; r < 16; r += 2) { lsa += SC[kb][r]; lsb += SC[kb][r + 1]; }      \
+    l_run += lsa + lsb;                                                                                  \
+    if constexpr (!(DBG & 32)) {                                                                         \
+    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                   \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                 \
+      __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                                                 \
+    }                                                                                                    \
+    }                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+  }
+  for (int kt = 0; kt < nkt; kt += 2) {
+    K22_AP_TILE(s0, s1, 0, kt);
+    if (kt + 1 < nkt) K22_AP_TILE(s1, s0, 1, kt + 1);
+  }
+#undef K22_AP_TILE
+#undef K22_AP_S
+#undef K22_AP_KREAD
+#undef K22_AP_VREAD
+#undef K22_AP_KLOAD
+#undef K22_AP_VLOAD
+#undef K22_AP_KSTORE
+#undef K22_AP_VSTORE
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.f / l_tot;
+  if (t < p.T) {
+    TG* orow = reinterpret_cast<TG*>(p.out) + (int64_t)(b * p.T + t) * p.ldo + hd * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = db * 32 + 8 * g + 4 * h;
+        if constexpr (MIX) {
+          if (p.out_x3) x3_store4(orow + d, x3_split4(o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv));
+          else *reinterpret_cast<float4*>(orow + d) = make_float4(o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+        } else {
+          uint2 w;
+          w.x = pack2<T>(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
+          w.y = pack2<T>(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+          *reinterpret_cast<uint2*>(orow + d) = w;
         }
       }
   }
@@ -362,7 +630,8 @@ __global__ __launch_bounds__(256) void small_attention_kernel(SmallAttnParams p)
     char* vsub = Vs + (key >> 6) * 8192;
     const int kk = key & 63;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) *reinterpret_cast<unsigned short*>(vsub + lds_chunk_off(c * 8 + e, kk >> 3) + (kk & 7) * 2) = ve[e];
+    for (int e = 0; e < 8; ++e)   // key-permuted V^T tile (vt_store16's layout): key kk -> piece 2 (kk >> 4) + ((kk >> 2) & 1), byte 8 ((kk >> 3) & 1) + 2 (kk & 3)
+      *reinterpret_cast<unsigned short*>(vsub + lds_chunk_off(c * 8 + e, 2 * (kk >> 4) + ((kk >> 2) & 1)) + 8 * ((kk >> 3) & 1) + 2 * (kk & 3)) = ve[e];
   }
   if (tid < 128) kdead[tid] = (p.key_valid != nullptr && tid < p.kv_n && p.key_valid[(int64_t)b * p.kv_ld + tid] == 0.f) ? 1.f : 0.f;
   __syncthreads();
@@ -458,6 +727,15 @@ int launch_small_attention(const SmallAttnParams& p, int dtype, hipStream_t s) {
 int launch_attention(const AttentionParams& p, int dtype, hipStream_t s) {
   if (p.Tkp % 64 || p.Tkp < p.Tk) return k22_set_error(K22_EINVAL, "attention: Tkp must be roundup(Tk,64)");
   dim3 grid((p.T + 127) / 128, p.H, p.B);
+  // the UNet's / MoVQ-free unmasked attention on 16-bit tiles: the software-pipelined kernel (K22_ATT_PIPE=0: attention_kernel, for A/B runs)
+  static const bool pipe = [] { const char* e = getenv("K22_ATT_PIPE"); return !(e && e[0] == '0'); }();
+  if (pipe && !p.causal && p.key_valid == nullptr && (dtype == K22_BF16 || dtype == K22_F16 || dtype == K22_F16X2)) {
+    if (dtype == K22_BF16) hipLaunchKernelGGL(attention_pipe_kernel<bf16_t>, grid, dim3(256), 0, s, p);
+    else if (dtype == K22_F16) hipLaunchKernelGGL(attention_pipe_kernel<f16_t>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(attention_pipe_kernel<xh_t>, grid, dim3(256), 0, s, p);
+    K22_CHECK_LAUNCH();
+    return K22_OK;
+  }
   if (dtype == K22_BF16) hipLaunchKernelGGL(attention_kernel<bf16_t>, grid, dim3(256), 0, s, p);
   else if (dtype == K22_F16) hipLaunchKernelGGL(attention_kernel<f16_t>, grid, dim3(256), 0, s, p);
   else if (dtype == K22_F32) hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(256), 0, s, p);
