@@ -457,7 +457,7 @@ def e2e_pass(a, arch, sd, dev, tdt, dist_on, world):
 
         def many():
             return pipe.generate_text2img_many([prompt] * n_p, num_steps=a.sched_steps, batch_size=a.bs, guidance_scale=4, h=a.size, w=a.size,
-                                               sampler="p_sampler", prior_cf_scale=4, prior_steps="25", output_type="tensor")
+                                               sampler="p_sampler", prior_cf_scale=4, prior_steps="25", output_type="tensor", prior_group=4)
         many()
         torch.cuda.synchronize()
         tp = time.perf_counter()
@@ -466,8 +466,9 @@ def e2e_pass(a, arch, sd, dev, tdt, dist_on, world):
         elp = time.perf_counter() - tp
         piped = {"images_per_sec": round(a.bs * n_p / elp, 4), "ms_per_image": round(elp / n_p * 1e3, 2), "prompts": n_p,
                  "ok": bool(all(tuple(o.shape) == (a.bs, a.size, a.size, 3) for o in outs)),
-                 "what": "Kandinsky2_1HIP.generate_text2img_many: the same generation for a list of prompts as a three-stage pipeline on three streams "
-                         "(per GPU; every image equals the sequential call's bit for bit: tests/test_pipeline_gpu.py)"}
+                 "what": "Kandinsky2_1HIP.generate_text2img_many(prior_group=4): the same generation for a list of prompts - ONE prior call per four prompts "
+                         "(the prior is a weight stream: four prompts cost about one), prior | denoise loop | MoVQ decode as a pipeline on three streams "
+                         "(per GPU; images equal the sequential calls' to rounding, bit for bit with prior_group=1: tests/test_pipeline_gpu.py)"}
     except Exception as e:
         print(f"bench: pipelined e2e pass failed: {e}", file=sys.stderr)
     prior_ms = timed(lambda: pipe.generate_clip_emb(prompt, batch_size=a.bs, prior_cf_scale=4, prior_steps="25"))

@@ -312,13 +312,17 @@ class Kandinsky2_1HIP:
     @torch.no_grad()
     def generate_text2img_many(self, prompts, num_steps=100, batch_size=1, guidance_scale=7, h=512, w=512, sampler="ddim_sampler",
                                prior_cf_scale=4, prior_steps="25", negative_prior_prompt="", negative_decoder_prompt="", *,
-                               noises=None, noise_seqs=None, prior_noises=None, prior_noise_seqs=None, output_type="pil"):
+                               noises=None, noise_seqs=None, prior_noises=None, prior_noise_seqs=None, output_type="pil", prior_group: int = 1):
         """generate_text2img for a LIST of prompts -> list of results, each equal to what generate_text2img(prompt, ...) returns for the same
         noise.  The three engines of a generation (conditioning + prior | denoise loop | MoVQ decode) are independent between prompts, so they
         run as a pipeline on three streams of the device: while the UNet denoises prompt i, the prior (a weight stream that leaves the matrix
         cores idle) already samples the embedding of prompt i + 1 and the decoder finishes prompt i - 1.  The reference generates one prompt
         after the other (kandinsky2_1_model.py:299-351); images per second of a prompt batch are bounded by the slowest stage instead of the
-        sum.  noises / noise_seqs / prior_noises / prior_noise_seqs: optional per-prompt lists (parity tests)."""
+        sum.  noises / noise_seqs / prior_noises / prior_noise_seqs: optional per-prompt lists (parity tests).
+        prior_group > 1: the diffusion prior samples the embeddings of up to prior_group prompts in ONE call (its batch = 2 * batch_size *
+        group <= 8): the prior is a weight stream - 2 GB per forward whatever the batch - so a group of four costs about what one prompt
+        costs.  Every row of the prior is computed independently of the other rows, but a larger batch runs other GEMM tile shapes (other
+        fp32 summation orders): results then equal the per-prompt calls to rounding, not bit for bit (the default, 1, does)."""
         prompts = list(prompts)
         n = len(prompts)
         pick = lambda lst, i: None if lst is None else lst[i]          # noqa: E731
@@ -330,10 +334,36 @@ class Kandinsky2_1HIP:
         s_dec.wait_stream(cur)
         _, diffusion = self._diffusion(sampler, num_steps)
 
+        group = max(1, min(int(prior_group), 4 // max(1, batch_size)))
+        if negative_decoder_prompt != "":
+            group = 1                     # (the negative decoder prompt takes a prior call of its own: kept per prompt)
+        grouped = {}                      # prompt index -> image embedding rows computed by its group's prior call
+
+        def prior_for_group(i0):
+            """one prior call for prompts i0 .. i0 + group - 1: rows [cond of every prompt | uncond of every prompt]"""
+            idx = list(range(i0, min(i0 + group, n)))
+            bs = batch_size
+            plist = [prompts[i] for i in idx for _ in range(bs)]
+            scales = torch.tensor([prior_cf_scale] * len(plist), device=self.device, dtype=torch.float32)
+            txt_feat, txt_feat_seq, mask = self.conditioner.clip_text(plist, negative_prior_prompt, self.device)
+            nz = nzs = None
+            if prior_noises is not None:   # per-prompt [2 bs, D] -> [cond rows of all | uncond rows of all]
+                nz = torch.cat([prior_noises[i][:bs] for i in idx] + [prior_noises[i][bs:] for i in idx], 0)
+            if prior_noise_seqs is not None:
+                nzs = torch.cat([prior_noise_seqs[i][:, :bs] for i in idx] + [prior_noise_seqs[i][:, bs:] for i in idx], 1)
+            emb = self.prior(txt_feat, txt_feat_seq, mask, scales, timestep_respacing=prior_steps, noise=nz, noise_seq=nzs).to(self.model_dtype)
+            for k, i in enumerate(idx):
+                grouped[i] = emb[k * bs:(k + 1) * bs]
+
         def stage_a(i):
             with torch.cuda.stream(s_prior):
-                emb = self._image_embs(prompts[i], batch_size, prior_cf_scale, prior_steps, negative_prior_prompt, negative_decoder_prompt,
-                                       noise=pick(prior_noises, i), noise_seq=pick(prior_noise_seqs, i))
+                if group > 1:
+                    if i not in grouped:
+                        prior_for_group(i)
+                    emb = torch.cat([grouped.pop(i), self.create_zero_img_emb(batch_size=batch_size)], dim=0).to(self.device)
+                else:
+                    emb = self._image_embs(prompts[i], batch_size, prior_cf_scale, prior_steps, negative_prior_prompt, negative_decoder_prompt,
+                                           noise=pick(prior_noises, i), noise_seq=pick(prior_noise_seqs, i))
                 txt = self.encode_text(prompts[i], batch_size)
                 ev = torch.cuda.Event()
                 ev.record(s_prior)

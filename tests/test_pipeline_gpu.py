@@ -306,3 +306,28 @@ def test_generate_text2img_many_pipelines_prompts_and_equals_the_sequential_call
                 assert torch.equal(many[i], seq[i]), (backend, i, (many[i].int() - seq[i].int()).abs().max().item())
         assert not torch.equal(many[0], many[1])          # different prompts / noise: different images
         del pipe
+
+
+def test_generate_text2img_many_with_a_grouped_prior_equals_the_sequential_calls_to_rounding():
+    """prior_group = 4: ONE prior call samples the embeddings of four prompts (batch 8).  Rows are independent, tile shapes are not the
+    same as at batch 2: the image embeddings / final latents equal the per-prompt calls to fp32 rounding (fp32 engines), images within a level."""
+    pipe = _pipe("text2img", torch.float32)
+    prompts = ["green tree", "a red cat", "blue bird on a wire", "a house"]
+    g = torch.Generator().manual_seed(23)
+    mk = lambda *sh: [torch.randn(*sh, generator=g).cuda() for _ in prompts]   # noqa: E731
+    x_T, nz = mk(2, 4, H // 8, W // 8), mk(6, 2, 4, H // 8, W // 8)
+    pn, pz = mk(2, 768), mk(PRIOR_STEPS, 2, 768)
+    kw = dict(num_steps=6, batch_size=1, guidance_scale=4.0, h=H, w=W, sampler="p_sampler", prior_steps=str(PRIOR_STEPS))
+    seq, lats = [], []
+    for i, p in enumerate(prompts):
+        seq.append(pipe.generate_text2img(p, noise=x_T[i], noise_seq=nz[i], prior_noise=pn[i], prior_noise_seq=pz[i], output_type="tensor", **kw))
+        lats.append(pipe.last_latent.clone())
+    many = pipe.generate_text2img_many(prompts, noises=x_T, noise_seqs=nz, prior_noises=pn, prior_noise_seqs=pz, output_type="tensor", prior_group=4, **kw)
+    torch.cuda.synchronize()
+    worst = 0
+    for i in range(len(prompts)):
+        d = (many[i].int() - seq[i].int()).abs()
+        worst = max(worst, int(d.max().item()))
+        assert d.float().mean().item() < 0.05, (i, d.float().mean().item())
+    print(f"grouped prior vs per-prompt calls: uint8 max |d| {worst}")
+    assert worst <= 2
