@@ -67,8 +67,9 @@ def main(argv=None):
     ap.add_argument("--no-profile", action="store_true", help="skip the per-op HIP-event pass (roofline object = null)")
     ap.add_argument("--chains", type=int, default=0, choices=[0, 1, 2],
                     help="2 = the CFG pair as two half-batch engines side by side on two streams (Text2ImUNetHIP(chains=2): per step two graph replays "
-                         "+ the sampler step, driven from the host); 1 = one engine, whole loop as one hipGraph; 0 (default) = 2 at bs 1 on the 2.1 head "
-                         "(measured +2.6 % there, profiles/r06_chains.txt), else 1 (C4 measured -5 % in round 4)")
+                         "+ the sampler step, driven from the host); 1 = one engine, whole loop as one hipGraph; 0 (default) = 1: the headline stays on one "
+                         "chain so that the per-class roofline can be attributed; the two-chain rate of the same workload is reported beside it as "
+                         "`two_chains` (+2.6 % at C2, profiles/r06_chains.txt; C4 measured -5 % in round 4)")
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) that fill roofline.traffic: bench.py re-runs itself for 2 steps "
                          "under the profiler, ~1 minute each; skipped anyway when rocprofv3 is not on PATH, at N > 1 and for non-default workloads")

@@ -380,6 +380,7 @@ def test_c3_shard_10_step_loop(golden_dir, backend, tol, tol_rms):
     print(f"c3_loop {backend}: FINAL latent ({fx['steps']} steps): max|d| {ma:.3e} rms {rms:.3e}")
     _record("c3_loop", f"{backend}_final".replace("torch.", ""), max_abs=ma, rms=rms)
     assert ma <= tol and rms <= tol_rms
+    assert ma <= 1e-3   # the north star's gate is stated on the FINAL latent: it holds for every gate-carrying engine here too (f16x2 measured 5.0e-4)
 
 
 def test_bf16_bits_do_not_depend_on_the_tuner(golden_dir):
