@@ -774,8 +774,11 @@ def test_no_kernel_of_the_library_spills_and_the_register_claims_hold(tmp_path):
     assert len(x2_pipe_256) == 4 and not x3_pipe_256
     for k in x2_pipe_256:
         assert 200 <= md[k]["vgpr"] <= 256
-    att = {k: v for k, v in md.items() if "attention_kernel" in k and "enc_" not in k}
+    att = {k: v for k, v in md.items() if k.startswith("_Z16attention_kernel")}
     assert len(att) == 5 and all(v["vgpr"] + v["agpr"] <= 256 for v in att.values())
+    # round 6: the software-pipelined kernel holds two score sets + all 16 fragments of a tile and still fits two workgroups per CU
+    pipe = {k: v for k, v in md.items() if k.startswith("_Z21attention_pipe_kernel")}
+    assert len(pipe) == 3 and all(v["vgpr"] + v["agpr"] <= 256 and v["lds"] == 32768 for v in pipe.values()), pipe
 
 
 def test_isa_mix_tool_counts_a_synthetic_loop():
