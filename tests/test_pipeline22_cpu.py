@@ -108,13 +108,16 @@ def test_scheduler_and_unet_configs_are_config_driven():
 
 
 def test_aux_engine_dtypes_one_rule_for_both_drivers():
-    """the engine built to reproduce the reference's fp32 images ("f16x3", and round 5's "f16x2") gets an fp32 prior and an fp32 MoVQ
-    in BOTH drivers; 16-bit engines get an fp16 MoVQ (also bf16: a bf16 decode is 24 grey levels off); an explicit movq_dtype wins."""
+    """the engine built to reproduce the reference's fp32 images ("f16x3") gets an fp32 prior and an fp32 MoVQ in BOTH drivers; round 6:
+    beside "f16x2" (activation operands at fp16 anyway) the prior and the MoVQ run in fp16 like the reference under use_fp16 (image-level bound
+    measured on the GPU: tests/test_pipeline_gpu.py); 16-bit engines get an fp16 MoVQ (also bf16: a bf16 decode is 24 grey levels off); an
+    explicit movq_dtype wins."""
     import inspect
     import torch
     from kandinsky2_amd import pipeline, pipeline22
     f = pipeline.aux_engine_dtypes
-    assert f("f16x3") == (torch.float32, torch.float32) and f("f16x2") == (torch.float32, torch.float32)
+    assert f("f16x3") == (torch.float32, torch.float32) and f("f16x2") == (torch.float16, torch.float16)
+    assert f("f16x2", torch.float32) == (torch.float16, torch.float32)
     assert f(torch.float32) == (torch.float32, torch.float32)
     assert f(torch.bfloat16) == (torch.bfloat16, torch.float16) and f(torch.float16) == (torch.float16, torch.float16)
     assert f("f16x3", torch.float16) == (torch.float32, torch.float16) and f(torch.bfloat16, torch.float32)[1] == torch.float32
