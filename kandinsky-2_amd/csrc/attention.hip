@@ -356,8 +356,16 @@ __global__ __launch_bounds__(256, 2) void attention_pipe_kernel(AttentionParams 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
-  const int hd = blockIdx.y, b = blockIdx.z;
-  const int t = blockIdx.x * 128 + wave * 32 + l31;
+  // 1-D grid, XCD-aware (workgroup i runs on XCD i % 8; per-XCD L2s): every XCD gets a CONTIGUOUS range of (image, head, query block)
+  // triples, query blocks fastest - the K / V^T of one (image, head) are then fetched into ONE L2 (two at a range boundary) instead of
+  // all eight (FETCH_SIZE of the launch at T = 2304: 8 x 14.7 MB of K / V^T before; profiles/r06_attention.txt)
+  const int nqb = (p.T + 127) / 128;
+  const int nblk = (int)gridDim.x;
+  int L = (int)blockIdx.x;
+  if (!(DBG & 64)) { const int q8 = nblk >> 3, r8 = nblk & 7, x8 = L & 7; L = (x8 < r8 ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8) + (L >> 3); }
+  const int pair = L / nqb, qb = L - pair * nqb;
+  const int b = pair / p.H, hd = pair - b * p.H;
+  const int t = qb * 128 + wave * 32 + l31;
   const int tq = t < p.T ? t : p.T - 1;
   const TG* qrow = reinterpret_cast<const TG*>(p.q) + (int64_t)(b * p.T + tq) * p.ldq + hd * 64;
   Frag<T> qf[4];
@@ -730,9 +738,10 @@ int launch_attention(const AttentionParams& p, int dtype, hipStream_t s) {
   // the UNet's / MoVQ-free unmasked attention on 16-bit tiles: the software-pipelined kernel (K22_ATT_PIPE=0: attention_kernel, for A/B runs)
   static const bool pipe = [] { const char* e = getenv("K22_ATT_PIPE"); return !(e && e[0] == '0'); }();
   if (pipe && !p.causal && p.key_valid == nullptr && (dtype == K22_BF16 || dtype == K22_F16 || dtype == K22_F16X2)) {
-    if (dtype == K22_BF16) hipLaunchKernelGGL(attention_pipe_kernel<bf16_t>, grid, dim3(256), 0, s, p);
-    else if (dtype == K22_F16) hipLaunchKernelGGL(attention_pipe_kernel<f16_t>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(attention_pipe_kernel<xh_t>, grid, dim3(256), 0, s, p);
+    const dim3 g1(grid.x * grid.y * grid.z);   // 1-D: the kernel maps workgroups to (image, head, query block) itself (XCD-aware)
+    if (dtype == K22_BF16) hipLaunchKernelGGL(attention_pipe_kernel<bf16_t>, g1, dim3(256), 0, s, p);
+    else if (dtype == K22_F16) hipLaunchKernelGGL(attention_pipe_kernel<f16_t>, g1, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(attention_pipe_kernel<xh_t>, g1, dim3(256), 0, s, p);
     K22_CHECK_LAUNCH();
     return K22_OK;
   }

@@ -12,3 +12,5 @@ print('K22_X2_PLAN=$plan: %.2f steps/s (graph replay), final latent max-abs %s r
 done
 K22_CHAINS=2 K22_X2_PLAN=0 timeout 300 python bench.py --dtype f16x2 --chains 2 --steps 50 --warmup 5 --no-cpu-baseline --no-e2e --no-box --no-traffic --no-parity --no-profile 2>/dev/null | tail -1 | grep -o '"value": [0-9.]*'
 echo "[done t=$SECONDS s]"
+timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_x2_gpu.py tests/test_unet_gpu.py -m gpu -x -q -p no:cacheprovider -k "attention or attn or tiny" 2>&1 | tail -3
+echo "[tests done t=$SECONDS s]"

@@ -49,6 +49,7 @@ int main(int argc, char** argv) {
     ap.q = q; ap.ldq = 3 * C; ap.kall = k; ap.vtall = v; ap.out = o; ap.ldo = C;
     ap.B = c.B; ap.H = c.H; ap.T = c.T; ap.Tk = Tk; ap.Tkp = Tkp; ap.scale = 0.125f;
     const dim3 grid((c.T + 127) / 128, c.H, c.B);
+    const dim3 grid1(grid.x * grid.y * grid.z);   // attention_pipe_kernel: 1-D, XCD-aware mapping inside
     const double fl = 4.0 * c.B * c.H * c.T * (double)Tk * 64;
     printf("B=%d H=%d T=%d Tk=%d: %d workgroups of 256\n", c.B, c.H, c.T, Tk, grid.x * grid.y * grid.z);
 #define RUN(NAME, ...)                                                                      \
@@ -65,22 +66,23 @@ int main(int argc, char** argv) {
     RUN("  no max / rescale", hipLaunchKernelGGL((attention_kernel<bf16_t, 16>), grid, dim3(256), 0, st, ap));
     RUN("  staged once + no exp + no max", hipLaunchKernelGGL((attention_kernel<bf16_t, 19>), grid, dim3(256), 0, st, ap));
     RUN("  staged once + no MFMAs", hipLaunchKernelGGL((attention_kernel<bf16_t, 13>), grid, dim3(256), 0, st, ap));
-    RUN("attention_pipe_kernel", hipLaunchKernelGGL((attention_pipe_kernel<bf16_t, 0>), grid, dim3(256), 0, st, ap));
-    RUN("  no v_exp", hipLaunchKernelGGL((attention_pipe_kernel<bf16_t, 2>), grid, dim3(256), 0, st, ap));
-    RUN("  tiles staged once", hipLaunchKernelGGL((attention_pipe_kernel<bf16_t, 1>), grid, dim3(256), 0, st, ap));
-    RUN("  no MFMAs", hipLaunchKernelGGL((attention_pipe_kernel<bf16_t, 12>), grid, dim3(256), 0, st, ap));
-    RUN("  no max", hipLaunchKernelGGL((attention_pipe_kernel<bf16_t, 16>), grid, dim3(256), 0, st, ap));
-    RUN("  no sched_group_barrier pins", hipLaunchKernelGGL((attention_pipe_kernel<bf16_t, 32>), grid, dim3(256), 0, st, ap));
-    RUN("  staged once + no exp + no max", hipLaunchKernelGGL((attention_pipe_kernel<bf16_t, 19>), grid, dim3(256), 0, st, ap));
-    RUN("  staged once + no MFMAs", hipLaunchKernelGGL((attention_pipe_kernel<bf16_t, 13>), grid, dim3(256), 0, st, ap));
-    RUN("  staged once + no MFMAs + no exp + no max", hipLaunchKernelGGL((attention_pipe_kernel<bf16_t, 31>), grid, dim3(256), 0, st, ap));
+    RUN("attention_pipe_kernel", hipLaunchKernelGGL((attention_pipe_kernel<bf16_t, 0>), grid1, dim3(256), 0, st, ap));
+    RUN("  no v_exp", hipLaunchKernelGGL((attention_pipe_kernel<bf16_t, 2>), grid1, dim3(256), 0, st, ap));
+    RUN("  tiles staged once", hipLaunchKernelGGL((attention_pipe_kernel<bf16_t, 1>), grid1, dim3(256), 0, st, ap));
+    RUN("  no MFMAs", hipLaunchKernelGGL((attention_pipe_kernel<bf16_t, 12>), grid1, dim3(256), 0, st, ap));
+    RUN("  no max", hipLaunchKernelGGL((attention_pipe_kernel<bf16_t, 16>), grid1, dim3(256), 0, st, ap));
+    RUN("  workgroups in launch order (no XCD-aware mapping)", hipLaunchKernelGGL((attention_pipe_kernel<bf16_t, 64>), grid1, dim3(256), 0, st, ap));
+    RUN("  no sched_group_barrier pins", hipLaunchKernelGGL((attention_pipe_kernel<bf16_t, 32>), grid1, dim3(256), 0, st, ap));
+    RUN("  staged once + no exp + no max", hipLaunchKernelGGL((attention_pipe_kernel<bf16_t, 19>), grid1, dim3(256), 0, st, ap));
+    RUN("  staged once + no MFMAs", hipLaunchKernelGGL((attention_pipe_kernel<bf16_t, 13>), grid1, dim3(256), 0, st, ap));
+    RUN("  staged once + no MFMAs + no exp + no max", hipLaunchKernelGGL((attention_pipe_kernel<bf16_t, 31>), grid1, dim3(256), 0, st, ap));
     {   // same bits as the shipped kernel?
       const size_t no = (size_t)c.B * c.T * C;
       std::vector<unsigned short> a(no), b2(no);
       hipLaunchKernelGGL((attention_kernel<bf16_t, 0>), grid, dim3(256), 0, st, ap); hipStreamSynchronize(st);
       hipMemcpy(a.data(), o, no * 2, hipMemcpyDeviceToHost);
       hipMemset(o, 0, no * 2);
-      hipLaunchKernelGGL((attention_pipe_kernel<bf16_t, 0>), grid, dim3(256), 0, st, ap); hipStreamSynchronize(st);
+      hipLaunchKernelGGL((attention_pipe_kernel<bf16_t, 0>), grid1, dim3(256), 0, st, ap); hipStreamSynchronize(st);
       hipMemcpy(b2.data(), o, no * 2, hipMemcpyDeviceToHost);
       size_t nd = 0; for (size_t i = 0; i < no; ++i) nd += a[i] != b2[i];
       printf("  pipe vs shipped: %zu of %zu output values differ\n", nd, no);
