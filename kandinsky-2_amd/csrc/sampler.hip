@@ -83,8 +83,9 @@ __device__ __forceinline__ void hist_add_aggregated(int* hist, bool valid, uint3
 // ballot.  Measured: the step's three kernels 76 -> 73 us at 96x96 - the FIRST pass (every key through the ballot-aggregated histogram add,
 // 36 keys x 16 waves on one CU) is what the 60 us are, whatever the digit plan; the lever that is left is spreading that pass over more CUs.
 constexpr int K22_RS_BINS = 2048;
+// floor_key: keys below it are not candidates (the caller counted them: k is the rank among the keys >= floor_key); 0 = all keys.
 template <int KPT>
-__device__ __forceinline__ uint32_t radix_select(const float* v, const uint32_t* keys, int n, int k, int* hist, uint32_t* bc) {
+__device__ __forceinline__ uint32_t radix_select(const float* v, const uint32_t* keys, int n, int k, int* hist, uint32_t* bc, uint32_t floor_key = 0u) {
   const int tid = threadIdx.x;
   uint32_t prefix = 0, mask = 0;
 #pragma unroll 1
@@ -98,7 +99,7 @@ __device__ __forceinline__ uint32_t radix_select(const float* v, const uint32_t*
 #pragma unroll
       for (int j = 0; j < KPT; ++j) {
         const uint32_t key = keys[j];
-        const bool valid = key != 0xffffffffu && (key & mask) == prefix;
+        const bool valid = key != 0xffffffffu && (key & mask) == prefix && key >= floor_key;
         hist_add_aggregated(hist, valid, (key >> shift) & dmask);
       }
     } else {
@@ -159,7 +160,47 @@ __global__ __launch_bounds__(1024) void sampler_threshold_kernel(SamplerParams p
       keys[j] = i < n ? __float_as_uint(fabsf(p.x0_buf[i])) : 0xffffffffu;
     }
   }
-  const uint32_t ka = radix_select<KPT>(p.x0_buf, keys, n, p.n_lo, hist, bc);
+  // Round 6: the order statistic wanted is a HIGH percentile (99.5 %), and the first radix pass - every key through the ballot-aggregated
+  // histogram add, 36 keys x 16 waves on one CU - was ~60 us of this kernel whatever the digit plan.  So the keys are filtered first, exactly:
+  // a pivot is selected from a strided sample of 1024 keys (its 97.3rd percentile: five standard deviations of a sample quantile below
+  // 99.5 %), the keys >= pivot are COUNTED (one compare + ballot per key), and if the wanted rank lies among them - it practically always
+  // does - the three radix passes run on those ~3 % of the keys only, with the rank shifted by the number of keys below the pivot.  If it
+  // does not (or n is small) the select runs over all keys as before: the result is the exact order statistic either way
+  // (tests/test_kernels_gpu.py::test_sampler_threshold_is_the_exact_order_statistic_on_adversarial_keys).  Measured: the step's three
+  // kernels 73 -> 59 us at 96x96 (tools/bench_sampler.py); what is left of this kernel is six short passes of fixed cost (bin clear,
+  // barriers, the one-wave scan) and the key loads.
+  uint32_t floor_key = 0u;
+  int k_sel = p.n_lo;
+  if constexpr (KPT >= 16) {
+    __shared__ unsigned int n_ge;
+    uint32_t skey = 0xffffffffu;
+    const int js = (int)threadIdx.x % KPT;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) skey = (j == js) ? keys[j] : skey;    // element js * 1024 + tid: a stride through every channel / row
+    unsigned int ns_local = skey != 0xffffffffu ? 1u : 0u;
+    if (threadIdx.x == 0) n_ge = 0u;
+    __syncthreads();
+    if (ns_local) atomicAdd(&n_ge, 1u);     // number of valid samples (1024 unless n is not a multiple of 1024)
+    __syncthreads();
+    const int ns = (int)n_ge;
+    __syncthreads();
+    if (ns >= 512) {
+      const uint32_t pivot = radix_select<1>(nullptr, &skey, ns, (int)(ns * 0.973f), hist, bc);
+      if (threadIdx.x == 0) n_ge = 0u;
+      __syncthreads();
+      unsigned int c = 0;
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) c += (keys[j] != 0xffffffffu && keys[j] >= pivot) ? 1u : 0u;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+      if ((threadIdx.x & 63) == 0) atomicAdd(&n_ge, c);
+      __syncthreads();
+      const int below = n - (int)n_ge;      // keys < pivot
+      if (p.n_lo >= below) { floor_key = pivot; k_sel = p.n_lo - below; }
+      __syncthreads();
+    }
+  }
+  const uint32_t ka = radix_select<KPT>(p.x0_buf, keys, n, k_sel, hist, bc, floor_key);
   // the next order statistic: a itself if enough keys are <= a, else the smallest key above a
   if (threadIdx.x == 0) { succ_cnt[0] = 0u; succ_cnt[1] = 0xffffffffu; }
   __syncthreads();

@@ -250,6 +250,51 @@ def test_sampler_step_matches_oracle(N, H, W, inpaint, step):
     assert (xo.cpu() - ref).abs().max().item() <= 1e-5
 
 
+@pytest.mark.parametrize("case", ["ties_at_the_clamp", "all_equal", "mostly_zero", "sample_unrepresentative", "two_values", "ramp"])
+@pytest.mark.parametrize("H,W", [(96, 96), (64, 64)])
+def test_sampler_threshold_is_the_exact_order_statistic_on_adversarial_keys(case, H, W):
+    """Round 6: the threshold kernel filters the keys by a pivot taken from a strided sample before the radix passes.  The result must stay the
+    exact order statistic whatever the sample says: ties at the clamp value (half of a late-step x0 sits at +-2), constant tensors, 98 % zeros,
+    a tensor whose sampled positions are all small while the rest is large (the filter must fall back), two distinct values, a ramp."""
+    N, step = 2, 10
+    d = k22.create_gaussian_diffusion(**dict(k22.DIFFUSION_CONFIG_2_1, timestep_respacing="50"))
+    od = diffusion_ref.RefDiffusion(50)
+    g = torch.Generator().manual_seed(5)
+    n = 4 * H * W
+    if case == "ties_at_the_clamp":
+        x = torch.randn(N, 4, H, W, generator=g) * 3.0
+    elif case == "all_equal":
+        x = torch.full((N, 4, H, W), 0.37)
+    elif case == "mostly_zero":
+        x = torch.randn(N, 4, H, W, generator=g) * (torch.rand(N, 4, H, W, generator=g) > 0.98).float()
+    elif case == "sample_unrepresentative":
+        # thread t samples element (t % KPT) * 1024 + t of image 0: make exactly those small and everything else large
+        kpt = (n + 1023) // 1024
+        flat = torch.rand(N, n, generator=g) + 0.5
+        t = torch.arange(1024)
+        idx = (t % kpt) * 1024 + t
+        flat[0, idx[idx < n]] = 1e-3
+        x = flat.reshape(N, 4, H, W)
+    elif case == "two_values":
+        x = torch.where(torch.rand(N, 4, H, W, generator=g) > 0.996, torch.tensor(0.9), torch.tensor(0.1))
+    else:
+        x = torch.linspace(-1.5, 1.5, N * n).reshape(N, 4, H, W)
+    mo = torch.zeros(N, 8, H, W)
+    nz = torch.randn(N, 4, H, W, generator=g)
+    ref, ref_x0 = od.p_sample(mo, x, step, nz, 4.0, None, None)
+    L = _lib.lib()
+    table = torch.from_numpy(d.step_table()).cuda()
+    scratch = torch.empty(L.k22_sampler_scratch_bytes(N, H * W), dtype=torch.uint8, device="cuda")
+    lo, gamma = k22.percentile_index(n)
+    xo, x0o = torch.empty(N, 4, H, W, device="cuda"), torch.empty(N, 4, H, W, device="cuda")
+    xc, moc, nzc = x.cuda(), mo.cuda(), nz.cuda()
+    _lib.check(L.k22_sampler_step(xc.data_ptr(), moc.data_ptr(), nzc.data_ptr(), None, None, table.data_ptr(),
+                                  step, 4.0, 1, -2.0, 2.0, lo, gamma, scratch.data_ptr(), xo.data_ptr(), x0o.data_ptr(),
+                                  N, H * W, hp.stream()))
+    assert (x0o.cpu() - ref_x0).abs().max().item() <= 5e-6
+    assert (xo.cpu() - ref).abs().max().item() <= 1e-5
+
+
 # ---- 8-wave BM x 128 GEMM kernel (gemm8_kernel, "gemm_algo" = 10) ------------------------------------------------
 def _with_gemm8(fn):
     _lib.check(_lib.lib().k22_set_option(b"gemm_algo", 10))

@@ -1,5 +1,5 @@
 """us per k22_sampler_step (x0 + exact 99.5th-percentile threshold + final) at the C2 latent shape.  (Exactness of the threshold on
-adversarial key distributions is a test: tests/test_sampler_gpu.py.)"""
+adversarial key distributions is a test: tests/test_kernels_gpu.py::test_sampler_threshold_is_the_exact_order_statistic_on_adversarial_keys.)"""
 import os
 import sys
 
