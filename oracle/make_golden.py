@@ -128,7 +128,7 @@ def run_case(name, model_config, inpainting, B, h, w, steps, guidance=4.0, seed_
     torch.save(fix, os.path.join(GOLD, name + ".pt"))
 
 
-def big_case(name, inpainting, bs, lat, steps, guidance=4.0, seed_w=0, keep=(1, 2, 5, 10, 25)):
+def big_case(name, inpainting, bs, lat, steps, guidance=4.0, seed_w=0, keep=(1, 2, 5, 10, 25), store_first=True):
     """BASELINE.json configs at their full shapes (C2: 768^2 bs=1 50 steps; C4: inpainting 768^2 bs=4; SURVEY 8d inputs):
     the REFERENCE create_model(...) (1.23 B params) + verbatim model_fn + SpacedDiffusion.p_sample_loop_progressive
     (gaussian_diffusion.py:426-475; p_sample_loop is `final of the progressive loop`, :413-425) with injected noise.
@@ -199,7 +199,8 @@ def big_case(name, inpainting, bs, lat, steps, guidance=4.0, seed_w=0, keep=(1, 
     print(f"{name}: first forward ref absmax {first['out'].abs().max():.4f}  oracle-vs-ref max|d| {d:.3e}")
     assert d < 2e-4 * max(1.0, first["out"].abs().max().item())
     torch.save(dict(name=name, inpainting=inpainting, bs=bs, B=B, lat=lat, steps=steps, guidance=guidance, seed_w=seed_w,
-                    first_ts=first["ts"], first_out=first["out"], traj=traj, final=final.clone()),
+                    first_ts=first["ts"], first_out=first["out"] if store_first else None, first_scale=first["out"].abs().max().item(),
+                    traj=traj, final=final.clone()),
                os.path.join(GOLD, name + ".pt"))
 
 
@@ -497,6 +498,9 @@ BIG_CASES = {
     # round 5: a 10-STEP LOOP at the C3 per-GPU shape (1024x1024, 4 images per GPU -> CFG batch [8,4,128,128]) - the
     # sampler / dynamic-threshold path at 65 536 values per image (gaussian_diffusion.py:284-294) pinned at loop level; ~25 min on 8 cores
     "c3loop": lambda: big_case("c3_loop", False, bs=4, lat=128, steps=10, keep=(1, 5)),
+    # round 6 ("no 50-step loop golden at the C3 shape"): the FULL 50-step schedule at the C3 per-GPU shape, the schedule the
+    # 1e-3 gate is stated on; the first forward is already pinned by c3_forward / c3_loop and is not stored again; ~2.5 h on 6 cores
+    "c3loop50": lambda: big_case("c3_loop50", False, bs=4, lat=128, steps=50, keep=(25,), store_first=False),
     # the production prior (2048 wide x 20 layers, K = 8192 MLP): transformer forward + a 5-step sample, bs = 2
     "prior": lambda: prior_case("prior_full", k22.PRIOR_HPARAMS_2_1, bs=2, steps=5),
     # MoVQ at real sizes: 32x32 latents (256x256 px, attention over T = 1024) and C2's 96x96 (768x768 px, T = 9216)

@@ -383,6 +383,27 @@ def test_c3_shard_10_step_loop(golden_dir, backend, tol, tol_rms):
     assert ma <= 1e-3   # the north star's gate is stated on the FINAL latent: it holds for every gate-carrying engine here too (f16x2 measured 5.0e-4)
 
 
+@pytest.mark.parametrize("backend,tol,tol_rms", [("f16x3", 1e-4, 1e-5), ("f16x2", 1e-3, 2e-4)])
+def test_c3_shard_50_step_loop(golden_dir, backend, tol, tol_rms):
+    """Round 6 ("there is no 50-step loop golden at the C3 shape"): the FULL 50-step schedule - the one the north star's
+    1e-3 gate is stated on - at the C3 per-GPU shape (1024x1024, 4 images per GPU -> CFG batch [8,4,128,128]): the reference's create_model +
+    SpacedDiffusion.p_sample_loop_progressive with injected noise (oracle/make_golden.py --only c3loop50; ~2.5 h of CPU), latent after step 25 and
+    FINAL latent.  Both gate-carrying engines must hold the gate itself here: max-abs <= 1e-3 on the final latent, no slack factor."""
+    fx = _load(golden_dir, "c3_loop50")
+    assert fx["steps"] == 50 and fx["lat"] == 128 and fx["B"] == 8
+    _, traj = _loop_case(fx, backend)
+    for n in sorted(fx["traj"].keys()):
+        ma, rms = _dist(traj[n], fx["traj"][n])
+        print(f"c3_loop50 {backend}: latent after step {n}: max|d| {ma:.3e} rms {rms:.3e}")
+        _record("c3_loop50", f"{backend}_step{n}", max_abs=ma, rms=rms)
+        assert ma <= 2 * tol and rms <= tol_rms      # mid-loop latents carry the heavy tail the clamp has not yet removed (see the 10-step test)
+    ma, rms = _dist(traj["final"], fx["final"])
+    print(f"c3_loop50 {backend}: FINAL latent (50 steps): max|d| {ma:.3e} rms {rms:.3e}")
+    _record("c3_loop50", f"{backend}_final", max_abs=ma, rms=rms)
+    assert ma <= tol and rms <= tol_rms
+    assert ma <= 1e-3
+
+
 def test_bf16_bits_do_not_depend_on_the_tuner(golden_dir):
     """Fixed-seed reproducibility of the product dtype: at a shape covered by the shipped tile table, an engine that may
     measure tile configurations (autotune on) and one that may not (autotune off) run the SAME configurations and give

@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""Where a small GEMM's time goes (developer tool): k22_gemm through gemm8 (gemm_algo = 10) and the generic igemm on the proj_out / qkv shapes
+of a C2 step, at the real K and at K = 64 (ONE slab: launch + prologue + epilogue only), with / without bias + residual, back to back in one
+stream (HIP events), and with the operands flushed from the caches between launches."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from kandinsky2_amd import _lib
+L = _lib.lib()
+st = torch.cuda.current_stream().cuda_stream
+T = torch.bfloat16
+flush = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
+
+
+def run(M, N, K, algo, bm, bn, splitk, epi, cold, reps=40):
+    a = torch.randn(M, K, device="cuda").to(T)
+    w = torch.randn((N + 63) // 64 * 64, K, device="cuda").to(T)
+    bias = torch.randn(N, device="cuda") if epi else None
+    res = torch.randn(M, N, device="cuda").to(T) if epi else None
+    out = torch.empty(M, N, dtype=T, device="cuda")
+    part = torch.empty(max(1, splitk) * M * N + 64, dtype=torch.float32, device="cuda")
+    _lib.check(L.k22_set_option(b"gemm_algo", algo))
+    call = lambda: _lib.check(L.k22_gemm(a.data_ptr(), None, w.data_ptr(), _lib.ptr(bias), _lib.ptr(res), out.data_ptr(), part.data_ptr(),
+                                         M, N, w.shape[0], K, 0, K, 0, N, N, 0, 0, splitk, bm, bn, _lib.K22_BF16, st))
+    for _ in range(3): call()
+    torch.cuda.synchronize()
+    tot = 0.0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if cold:
+        for _ in range(10):
+            flush.add_(1)
+            e0.record(); call(); e1.record(); torch.cuda.synchronize()
+            tot += e0.elapsed_time(e1)
+        us = tot / 10 * 1e3
+    else:
+        e0.record()
+        for _ in range(reps): call()
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+    _lib.check(L.k22_set_option(b"gemm_algo", 0))
+    return us
+
+
+for (M, N, K, name) in [(4608, 768, 768, "proj_out 48x48"), (4608, 2304, 768, "qkv 48x48"), (1152, 1152, 1152, "proj_out 24x24"), (1152, 3456, 1152, "qkv 24x24"),
+                        (288, 1536, 1536, "proj_out 12x12"), (288, 4608, 1536, "qkv 12x12")]:
+    print(f"{name}: M={M} N={N} K={K}  ({2.0 * M * N * K / 1e9:.1f} GFLOP)")
+    for algo, bm, bn, label in ((10, 128, 0, "gemm8 BM=128"), (10, 256, 0, "gemm8 BM=256"), (0, 128, 128, "igemm 128x128"), (0, 128, 64, "igemm 128x64"), (0, 64, 64, "igemm 64x64")):
+        try:
+            full = run(M, N, K, algo, bm, bn, 1, True, False)
+            one = run(M, N, 64, algo, bm, bn, 1, True, False)
+            noepi = run(M, N, K, algo, bm, bn, 1, False, False)
+            cold = run(M, N, K, algo, bm, bn, 1, True, True)
+            print(f"  {label:14s} warm {full:6.1f} us | K=64 {one:6.1f} | no bias/residual {noepi:6.1f} | cold {cold:6.1f}")
+        except Exception as e:
+            print(f"  {label:14s} failed: {str(e)[:80]}")
