@@ -48,6 +48,7 @@ struct LinearSmallParams {
   const void* W;                // [N][K] (dtype given at launch)
   const float* bias;            // [N] or null
   const float* add; int64_t ld_add;  // optional [M][N] added after the output activation
+  int add_mod;                       // > 0: row m adds row m % add_mod of `add` (the rows of several sampler steps batched in one call)
   float* out; int64_t ldo;
   int M, N, K, act_in, act_out;
   int rows_per_wave;  // set by the launcher

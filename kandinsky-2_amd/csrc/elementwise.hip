@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void linear_smallm_kernel(LinearSmallParams p)
       if (lane == 0 && m < p.M) {
         if (p.bias) v += p.bias[n];
         v = apply_act(v, p.act_out);
-        if (p.add) v += p.add[(int64_t)m * p.ld_add + n];
+        if (p.add) v += p.add[(int64_t)(p.add_mod > 0 ? m % p.add_mod : m) * p.ld_add + n];
         p.out[(int64_t)m * p.ldo + n] = v;
       }
     }

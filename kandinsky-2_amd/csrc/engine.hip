@@ -123,6 +123,34 @@ struct K22UNet {
   std::vector<Slot*> s_ctxkv;  // one per attention block
   int n_attn = 0;
   int64_t film_total = 0;
+  // k22_unet_sample_loop: the time embedding and ALL FiLM vectors of every step of the loop are computed by batched launches before the first
+  // step (the timesteps of a loop are known up front and nothing else feeds them): rows = steps x B, up to 8 rows per launch, so the 231 MB
+  // emb_layers weight stream is read once per 8 / B steps instead of once per step.  Every output row is the same arithmetic as in the per-step
+  // launch (one accumulator per row, same order): the loop stays bit-identical to the stepwise calls (asserted by the GPU tests).
+  float* film_all = nullptr;        // [rows][film_total] | temb [rows][mc] | e1 [rows][ted] | emb [rows][ted]
+  size_t film_all_bytes = 0;
+  int hoist_time = 1;               // K22_HOIST_TIME=0 (measurement only): the loop keeps the per-step time / FiLM launches
+  const float* film_cur = nullptr;  // != null while a hoisted loop runs: this step's [B][film_total]
+  const float* film_base() const { return film_cur ? film_cur : ptr<float>(s_film); }
+  struct TimeW { const float* freqs; const float* w0; const float* b0; const float* w2; const float* b2; const void* we; const float* be; int mc, ted, dt; } tw = {};
+  // rows of (timestep -> sinusoid -> time_embed MLP + conditioning row (m % B) -> SiLU -> emb_layers of every ResBlock): nn.py:101-121, unet.py:159-170
+  int time_rows(const float* t, float* temb, float* e1, float* emb, float* film, int rows, hipStream_t st) {
+    int rc = launch_timestep_embedding(t, tw.freqs, temb, rows, tw.mc / 2, st);
+    if (rc) return rc;
+    LinearSmallParams lp = {};
+    lp.x = temb; lp.ldx = tw.mc; lp.W = tw.w0; lp.bias = tw.b0; lp.out = e1; lp.ldo = tw.ted;
+    lp.M = rows; lp.N = tw.ted; lp.K = tw.mc; lp.act_in = K22_ACT_NONE; lp.act_out = K22_ACT_SILU;
+    rc = launch_linear_smallm(lp, K22_F32, st);
+    if (rc) return rc;
+    lp.x = e1; lp.ldx = tw.ted; lp.W = tw.w2; lp.bias = tw.b2; lp.add = ptr<float>(s_xfproj); lp.ld_add = tw.ted; lp.add_mod = B;
+    lp.out = emb; lp.K = tw.ted; lp.act_out = K22_ACT_NONE;
+    rc = launch_linear_smallm(lp, K22_F32, st);
+    if (rc) return rc;
+    LinearSmallParams le = {};
+    le.x = emb; le.ldx = tw.ted; le.W = tw.we; le.bias = tw.be; le.out = film; le.ldo = film_total;
+    le.M = rows; le.N = (int)film_total; le.K = tw.ted; le.act_in = K22_ACT_SILU; le.act_out = K22_ACT_NONE;
+    return launch_linear_smallm(le, tw.dt, st);
+  }
 
   Slot* new_slot(size_t bytes = 0) { slots.emplace_back(); slots.back().bytes = bytes; return &slots.back(); }
   static void need(Slot* s, size_t bytes) { if (bytes > s->bytes) s->bytes = bytes; }
@@ -161,6 +189,7 @@ struct K22UNet {
     if (loop_exec) (void)hipGraphExecDestroy(loop_exec);
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
+    if (film_all) (void)hipFree(film_all);
   }
 
   // One forward on `st`: the op list in order.  (A variant that forked the time-embedding / FiLM GEMV onto a second stream,
@@ -210,7 +239,7 @@ struct K22UNet {
       }
       cp.HW = HW; cp.C = C; cp.groups = 32; cp.eps = 1e-5f;
       cp.gamma = gamma; cp.beta = beta;
-      cp.film = film_off >= 0 ? ptr<float>(s_film) + film_off : nullptr; cp.film_ld = film_total;
+      cp.film = film_off >= 0 ? film_base() + film_off : nullptr; cp.film_ld = film_total;
       cp.coeff = ptr<float>(s_coeff);
       GnApplyParams ap = {};
       ap.x0 = x0; ap.x1 = x1; ap.C0 = a.C0; ap.C1 = a.C1; ap.B = Bn; ap.H = a.H; ap.W = a.W;
@@ -551,27 +580,15 @@ struct K22UNet {
 
     // ---- time embedding + all FiLM vectors -------------------------------------------------
     {
-      const float* freqs = Wf("time_freqs");
-      const float* w0 = Wf("time_embed.0.weight"); const float* b0 = Wf("time_embed.0.bias");
-      const float* w2 = Wf("time_embed.2.weight"); const float* b2 = Wf("time_embed.2.bias");
-      const void* we = W_("emb_layers.weight"); const float* be = Wf("emb_layers.bias");
-      const int Bn = B, dt = sdt; const int64_t ft = film_total;
+      tw.freqs = Wf("time_freqs");
+      tw.w0 = Wf("time_embed.0.weight"); tw.b0 = Wf("time_embed.0.bias");
+      tw.w2 = Wf("time_embed.2.weight"); tw.b2 = Wf("time_embed.2.bias");
+      tw.we = W_("emb_layers.weight"); tw.be = Wf("emb_layers.bias");
+      tw.mc = mc; tw.ted = ted; tw.dt = sdt;
+      const int Bn = B;
       ops.push_back([=](hipStream_t st) {
-        int rc = launch_timestep_embedding(ptr<float>(s_t), freqs, ptr<float>(s_temb), Bn, mc / 2, st);
-        if (rc) return rc;
-        LinearSmallParams lp = {};
-        lp.x = ptr<float>(s_temb); lp.ldx = mc; lp.W = w0; lp.bias = b0; lp.out = ptr<float>(s_e1); lp.ldo = ted;
-        lp.M = Bn; lp.N = ted; lp.K = mc; lp.act_in = K22_ACT_NONE; lp.act_out = K22_ACT_SILU;
-        rc = launch_linear_smallm(lp, K22_F32, st);
-        if (rc) return rc;
-        lp.x = ptr<float>(s_e1); lp.ldx = ted; lp.W = w2; lp.bias = b2; lp.add = ptr<float>(s_xfproj); lp.ld_add = ted;
-        lp.out = ptr<float>(s_emb); lp.K = ted; lp.act_out = K22_ACT_NONE;
-        rc = launch_linear_smallm(lp, K22_F32, st);
-        if (rc) return rc;
-        LinearSmallParams le = {};
-        le.x = ptr<float>(s_emb); le.ldx = ted; le.W = we; le.bias = be; le.out = ptr<float>(s_film); le.ldo = ft;
-        le.M = Bn; le.N = (int)ft; le.K = ted; le.act_in = K22_ACT_SILU; le.act_out = K22_ACT_NONE;
-        return launch_linear_smallm(le, dt, st);
+        if (film_cur) return (int)K22_OK;   // a hoisted loop computed this step's rows before its first step
+        return time_rows(ptr<float>(s_t), ptr<float>(s_temb), ptr<float>(s_e1), ptr<float>(s_emb), ptr<float>(s_film), Bn, st);
       });
     }
 
@@ -802,6 +819,8 @@ int k22_unet_create(const K22UNetConfig* cfg, const K22Weight* weights, int n_we
     u->fuse_skip = f ? (atoi(f) != 0) : 1;
     const char* xp = getenv("K22_X2_PLAN");   // K22_F16X2 only: which of the top level's convolutions run with two MFMAs (K22UNet::x2_plan)
     u->x2_plan = xp ? (atoi(xp) & 3) : 0;
+    const char* ht = getenv("K22_HOIST_TIME");   // 0 (measurement only) = k22_unet_sample_loop keeps the per-step time-embedding / FiLM launches
+    u->hoist_time = ht ? (atoi(ht) != 0) : 1;
   }
   for (int i = 0; i < n_weights; ++i) u->w[weights[i].name] = weights[i].ptr;
   *out = u;
@@ -941,9 +960,36 @@ int k22_unet_sample_loop(K22UNet* u, float* x, float* x_tmp, const float* timest
   { int rc = u->prepare_run(st); if (rc) return rc; }
   const size_t half = (size_t)(B / 2) * 4 * HW * sizeof(float);
   const size_t pb = (size_t)B;
+  // the time / FiLM rows of all steps up front (K22UNet::film_all): 8 / B steps per batched launch; B > 8 keeps the per-step launches
+  const bool hoist = B <= 8 && u->hoist_time;
+  const int64_t rows_all = (int64_t)n_steps * B;
+  float *fa_film = nullptr, *fa_temb = nullptr, *fa_e1 = nullptr, *fa_emb = nullptr;
+  if (hoist) {
+    const size_t need = (size_t)rows_all * (size_t)(u->film_total + u->tw.mc + 2 * u->tw.ted) * sizeof(float);
+    if (need > u->film_all_bytes) {
+      u->drop_graphs();   // captured loops hold the old buffer's addresses
+      if (u->film_all) { (void)hipStreamSynchronize(st); (void)hipFree(u->film_all); u->film_all = nullptr; u->film_all_bytes = 0; }
+      e = hipMalloc(reinterpret_cast<void**>(&u->film_all), need);
+      if (e != hipSuccess) { u->film_all = nullptr; return k22_set_error_hip(e, __FILE__, __LINE__); }
+      u->film_all_bytes = need;
+    }
+    fa_film = u->film_all;
+    fa_temb = fa_film + rows_all * u->film_total;
+    fa_e1 = fa_temb + rows_all * u->tw.mc;
+    fa_emb = fa_e1 + rows_all * u->tw.ted;
+  }
   // one pass over the loop on `s`: what is captured is exactly what an eager call runs
-  auto run_loop = [&](hipStream_t s) -> int {
+  auto run_loop_body = [&](hipStream_t s) -> int {
     hipError_t er;
+    if (hoist) {
+      const int spl = 8 / B;   // steps per batched launch
+      for (int k0 = 0; k0 < n_steps; k0 += spl) {
+        const int rows = (n_steps - k0 < spl ? n_steps - k0 : spl) * B;
+        const int64_t r0 = (int64_t)k0 * B;
+        const int rc = u->time_rows(timesteps + r0, fa_temb + r0 * u->tw.mc, fa_e1 + r0 * u->tw.ted, fa_emb + r0 * u->tw.ted, fa_film + r0 * u->film_total, rows, s);
+        if (rc) return rc;
+      }
+    }
     if (u->cfg.in_channels == 9) {
       er = hipMemcpyAsync(u->ptr(u->s_img), inpaint_image, pb * 4 * HW * 4, hipMemcpyDeviceToDevice, s);
       if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
@@ -957,8 +1003,12 @@ int k22_unet_sample_loop(K22UNet* u, float* x, float* x_tmp, const float* timest
       if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
       er = hipMemcpyAsync(u->ptr(u->s_xin) + half, cur, half, hipMemcpyDeviceToDevice, s);
       if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
-      er = hipMemcpyAsync(u->ptr(u->s_t), timesteps + (size_t)k * B, (size_t)B * 4, hipMemcpyDeviceToDevice, s);
-      if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
+      if (hoist) {
+        u->film_cur = fa_film + (int64_t)k * B * u->film_total;
+      } else {
+        er = hipMemcpyAsync(u->ptr(u->s_t), timesteps + (size_t)k * B, (size_t)B * 4, hipMemcpyDeviceToDevice, s);
+        if (er != hipSuccess) return k22_set_error_hip(er, __FILE__, __LINE__);
+      }
       int rc = u->exec(s);
       if (rc) return rc;
       SamplerParams p = {};
@@ -977,12 +1027,13 @@ int k22_unet_sample_loop(K22UNet* u, float* x, float* x_tmp, const float* timest
     }
     return K22_OK;
   };
+  auto run_loop = [&](hipStream_t s) -> int { const int rc = run_loop_body(s); u->film_cur = nullptr; return rc; };
   if (!use_graph) return run_loop(st);
   // key of the captured loop: every pointer and scalar baked into its nodes
   std::vector<unsigned long long> key = {(unsigned long long)(uintptr_t)x, (unsigned long long)(uintptr_t)x_tmp, (unsigned long long)(uintptr_t)timesteps,
       (unsigned long long)(uintptr_t)noise_seq, (unsigned long long)(uintptr_t)init_img, (unsigned long long)(uintptr_t)mask,
       (unsigned long long)(uintptr_t)inpaint_image, (unsigned long long)(uintptr_t)inpaint_mask, (unsigned long long)(uintptr_t)table,
-      (unsigned long long)(uintptr_t)scratch, (unsigned long long)n_steps, (unsigned long long)pct_index};
+      (unsigned long long)(uintptr_t)scratch, (unsigned long long)n_steps, (unsigned long long)pct_index, (unsigned long long)(hoist ? 1 : 0)};
   auto bits = [](double v) { unsigned long long b; memcpy(&b, &v, 8); return b; };
   key.push_back(bits(guidance)); key.push_back(bits(clamp_lo)); key.push_back(bits(clamp_hi)); key.push_back(bits(pct_gamma));
   for (int k = 0; k < n_steps; ++k) key.push_back((unsigned long long)table_rows[k]);
