@@ -383,13 +383,14 @@ def test_c3_shard_10_step_loop(golden_dir, backend, tol, tol_rms):
     assert ma <= 1e-3   # the north star's gate is stated on the FINAL latent: it holds for every gate-carrying engine here too (f16x2 measured 5.0e-4)
 
 
-@pytest.mark.parametrize("backend,tol,tol_rms", [("f16x3", 1e-4, 1e-5), ("f16x2", 1e-3, 2e-4)])
+@pytest.mark.parametrize("backend,tol,tol_rms", [("f16x3", 1e-4, 1e-5), ("f16x2", 5e-4, 1e-4)])
 def test_c3_shard_50_step_loop(golden_dir, backend, tol, tol_rms):
     """Round 6 ("there is no 50-step loop golden at the C3 shape"): the FULL 50-step schedule - the one the north star's
     1e-3 gate is stated on - at C3's resolution (1024x1024 -> 128x128 latents, 65 536 values under the dynamic threshold), one image of the shard
     (CFG batch [2,4,128,128]; the images of a shard are independent): the reference's create_model + SpacedDiffusion.p_sample_loop_progressive with
     injected noise (oracle/make_golden.py --only c3loop50; ~2 h of CPU), latent after step 25 and FINAL latent.  Both gate-carrying engines must
-    hold the gate itself here: max-abs <= 1e-3 on the final latent, no slack factor."""
+    hold the gate itself here - and the 5e-4 this repository asserts for f16x2 at C2: measured f16x2 3.0e-4 / 5.0e-5 rms final (3.6e-4 after step 25),
+    f16x3 2.8e-6 / 6.3e-7."""
     fx = _load(golden_dir, "c3_loop50")
     assert fx["steps"] == 50 and fx["lat"] == 128 and fx["B"] == 2
     _, traj = _loop_case(fx, backend)
