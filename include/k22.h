@@ -162,7 +162,10 @@ int k22_unet_forward(K22UNet* u, const float* x, const float* timesteps, const f
  * Device buffers, filled by the caller before the call: x [B][4][HW] (in: x_T, out: the final latent; x_tmp: same-size scratch),
  * timesteps [n_steps][B] in execution order, noise_seq [n_steps][B][4][HW], init_img / mask (inpainting blend of the sampler step, or
  * NULL), inpaint_image / inpaint_mask (9-channel UNet inputs, or NULL), table [T][8]; table_rows: HOST array, schedule row of step k.
- * use_graph != 0: captured on first use and replayed while the same buffers / scalars are passed. */
+ * use_graph != 0: captured on first use and replayed while the same buffers / scalars are passed.
+ * The time embedding, time_embed MLP and FiLM vectors (unet.py:159-170) of ALL n_steps are computed by batched launches before the first
+ * step (the handle keeps an [n_steps * B] x FiLM-width device buffer for them); every row is the arithmetic of the per-step launch, so the
+ * loop equals n_steps calls of k22_unet_forward + k22_sampler_step bit for bit (env K22_HOIST_TIME=0: per-step launches, measurement only). */
 int k22_unet_sample_loop(K22UNet* u, float* x, float* x_tmp, const float* timesteps, const float* noise_seq, const float* init_img,
                          const float* mask, const float* inpaint_image, const float* inpaint_mask, const float* table,
                          const int* table_rows, int n_steps, float guidance, float clamp_lo, float clamp_hi, int pct_index,
