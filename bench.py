@@ -326,8 +326,9 @@ def run(a):
                 sp, k_ = max(ok)
                 gate = {"dtype": k_, "steps_per_s": sp, "p_sample_loop_steps_per_s": sp, "final_latent_max_abs": parity[k_]["final_latent_max_abs"],
                         "protocol": "p_sample_loop (one warm + one timed 50-step loop)",
-                        "scope": "C2 shape, 50-step schedule, FINAL latent (the C3-shard 10-step loop of this engine reads 5.0e-4 final / 1.6e-3 mid-loop; "
-                                 "tests/test_full_size_gpu.py)",
+                        "scope": "measured HERE at the C2 shape, 50-step schedule, FINAL latent; the GPU tests hold the same engine to the same gate on the 50-step "
+                                 "schedule at C3's resolution (3.0e-4) and at C4 (4.9e-5), and on a coarse 10-step C3-shard loop (5.8e-4 final, 2.0e-3 mid-loop): "
+                                 "tests/test_full_size_gpu.py",
                         "what": "fastest engine mode of this build whose reference-p_sampler final latent (C2, 50 steps, fixed seed) is within 1e-3 max-abs"}
                 if k_ != a.dtype:
                     try:
