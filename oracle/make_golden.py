@@ -500,7 +500,7 @@ BIG_CASES = {
     "c3loop": lambda: big_case("c3_loop", False, bs=4, lat=128, steps=10, keep=(1, 5)),
     # round 6 ("no 50-step loop golden at the C3 shape"): the FULL 50-step schedule - the one the 1e-3 gate is stated on - at
     # C3's resolution (1024x1024 -> 128x128 latents, 16 384 x 4 values under the dynamic threshold), ONE image of the shard (CFG batch
-    # [2,4,128,128]: the images of a shard are independent, and the reference at bs = 4 takes ~8 min per step on this container's 8 cores);
+    # [2,4,128,128]: the images of a shard are independent, and the reference at bs = 4 takes ~7 min per step on this container's 8 cores: 5.5 h for the loop);
     # the first forward is pinned by c3_forward / c3_loop and is not stored again; ~2 h on 6 cores
     "c3loop50": lambda: big_case("c3_loop50", False, bs=1, lat=128, steps=50, keep=(25,), store_first=False),
     # the production prior (2048 wide x 20 layers, K = 8192 MLP): transformer forward + a 5-step sample, bs = 2
