@@ -30,3 +30,57 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+# ---- seeded state dicts are built ONCE per session ---------------------------------------------------------------------------------
+# k22.init_*_state_dict fills hundreds of tensors from one CPU generator (4.5 s for the 1/3-width UNet, 13-20 s for the 1.23 B one on a GPU
+# box's host cores): round 6 found that this - re-done by nearly every test because the per-file caches held one entry and the
+# parametrisations alternate - was most of the GPU suite's run time and all of its box-to-box spread (697 s on one box, 1038 s on another).
+# The functions are wrapped with a byte-capped LRU keyed on their arguments; callers get a fresh OrderedDict over the SAME tensors (no test
+# writes into a state dict: load_state_dict copies).
+_SD_CAP_BYTES = int(os.environ.get("K22_TEST_SD_CACHE_GB", "24")) << 30
+
+
+def _install_state_dict_cache():
+    import collections
+    import functools
+    import torch
+    import kandinsky2_amd as k22
+    cache = collections.OrderedDict()   # key -> (value, bytes)
+
+    def nbytes(v):
+        if isinstance(v, torch.Tensor):
+            return v.numel() * v.element_size()
+        if isinstance(v, dict):
+            return sum(nbytes(x) for x in v.values())
+        if isinstance(v, (tuple, list)):
+            return sum(nbytes(x) for x in v)
+        return 0
+
+    def fresh(v):
+        if isinstance(v, dict):
+            return type(v)(v)
+        if isinstance(v, tuple):
+            return tuple(fresh(x) for x in v)
+        return v
+
+    def wrap(name, fn):
+        @functools.wraps(fn)
+        def cached(*args, **kwargs):
+            key = (name, repr(args), repr(sorted(kwargs.items())))
+            if key in cache:
+                cache.move_to_end(key)
+                return fresh(cache[key][0])
+            v = fn(*args, **kwargs)
+            cache[key] = (v, nbytes(v))
+            while len(cache) > 1 and sum(b for _, b in cache.values()) > _SD_CAP_BYTES:
+                cache.popitem(last=False)
+            return fresh(v)
+        return cached
+
+    for name in dir(k22):
+        if name.startswith("init_") and name.endswith("_state_dict") and callable(getattr(k22, name)):
+            setattr(k22, name, wrap(name, getattr(k22, name)))
+
+
+_install_state_dict_cache()
