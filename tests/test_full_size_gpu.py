@@ -50,8 +50,8 @@ _REPORT = {}
 
 
 def _slow_unless_asked(cond, why):
-    if cond and os.environ.get("K22_RUN_SLOW", "0") in ("", "0"):
-        pytest.skip(why + " - K22_RUN_SLOW=1 runs it")
+    if cond and os.environ.get("K22_RUN_SLOW", "1") == "0":
+        pytest.skip(why + " - skipped because K22_RUN_SLOW=0")
 
 
 def _load(golden_dir, name):

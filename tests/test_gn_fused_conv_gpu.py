@@ -10,7 +10,7 @@ import helpers as hp
 from kandinsky2_amd import _lib
 from kandinsky2_amd.pack import to_x3
 
-pytestmark = [pytest.mark.gpu, pytest.mark.slow]   # K22_FUSE_GN ships OFF (21 % slower): K22_RUN_SLOW=1 runs these
+pytestmark = [pytest.mark.gpu, pytest.mark.slow]   # K22_FUSE_GN ships OFF (21 % slower); run by default since round 6, K22_RUN_SLOW=0 skips them
 X3 = _lib.K22_F16X3
 DT = [_lib.K22_BF16, _lib.K22_F16, _lib.K22_F32, X3]
 

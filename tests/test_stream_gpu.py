@@ -26,7 +26,7 @@ _SCRATCH = {}
 def weight_layout(request):
     """Every case can run twice: through the fragment-major copy (k22_stream_repack; the C ABI's test entries repack into this scratch
     before each launch - k22_debug_set_stream_scratch), which is what the engines run, and with the weights read row-major as packed for
-    the other kernels - a form that never won a measurement and that no engine selects: its cases are `slow` (K22_RUN_SLOW=1)."""
+    the other kernels - a form that never won a measurement and that no engine selects: its cases are `slow` (skipped by K22_RUN_SLOW=0)."""
     if request.param == "fragmajor":
         if "buf" not in _SCRATCH:
             _SCRATCH["buf"] = torch.empty(96 << 20, dtype=torch.uint8, device="cuda")

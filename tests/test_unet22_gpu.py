@@ -129,7 +129,7 @@ def test_decoder_loop_vs_oracle_fp32(controlnet, variant):
     assert img.shape == (bs, 8 * h, 8 * w, 3)
 
 
-@pytest.mark.slow   # 17 s on an UNPINNED path (oracle/unet22_ref.py): the tiny-width cases above run by default, this one with K22_RUN_SLOW=1
+@pytest.mark.slow   # 17 s on an UNPINNED path (oracle/unet22_ref.py): skipped by K22_RUN_SLOW=0
 def test_unet22_full_width_forward_vs_oracle_fp32():
     """The 1.25 B-parameter configuration (UNET_CONFIG_2_2) at 32x32 latents, one forward."""
     cfg, sd, m = _unet(False, torch.float32, full=True)
