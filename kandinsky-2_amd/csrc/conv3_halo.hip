@@ -408,6 +408,170 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const IgemmParams p) {
 }
 
 // ================================================================================================================
+// gemm8_spec_kernel (round 6, p.stages == 3 / 4; 16-bit types): gemm8_kernel's tile, ring and epilogue with the eight waves SPECIALISED the way
+// conv3_halo_spec_kernel's are - what the tuning report of the C3 shape asked for: at M = 32 768 the lock-step GEMM ran at 0.18-0.29 of the
+// bf16 peak (qkv 64x64: 161 us for 116 GFLOP) beside 3x3 convolutions of the same tile at 0.57.
+//   waves 0-3 (consumers, one per SIMD): 2 x 2 over the BM x 128 tile, (BM/2) x 64 per wave; per slab they read fragments and issue MFMAs
+//              through the explicit two-set pipeline (reads of k-step ks + 1 interleaved one behind every MFMA of k-step ks; the last k-step
+//              of a slab is multiplied behind the next slab's barrier) - no LDS-DMA, no vmcnt wait;
+//   waves 4-7 (producers): all the LDS-DMA of a slab (BM/32 + 4 pieces each) right behind its barrier, then the counted vmcnt wait.
+// One raw barrier per slab for all eight waves; slot reuse as in gemm8_kernel (iteration s refills the stage iteration s - 1 read; the
+// consumers drain lgkmcnt before the next barrier).  Every accumulator sees the same MFMAs in the same k order as in gemm8_kernel: same bits.
+// ================================================================================================================
+template <typename T, int BM, int NST>
+__global__ __launch_bounds__(512) void gemm8_spec_kernel(const IgemmParams p) {
+  using TR = TT<T>;
+  static_assert(sizeof(T) == 2, "gemm8_spec_kernel: 16-bit operands");
+  constexpr int BK = TR::BK, EPC = TR::EPC, KSTEPS = TR::KSTEPS;
+  static_assert(KSTEPS % 2 == 0, "two-set fragment pipeline");
+  constexpr int BN = HALO_BN, NWL = 4, WM = 2, WN = 2;
+  constexpr int MI = BM / (WM * 32), NI = BN / (WN * 32);
+  constexpr int A_SLOTS = BM / 8 / NWL, B_SLOTS = BN / 8 / NWL, CH = A_SLOTS + B_SLOTS;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;
+  constexpr int GM = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave >= 4;   // wave-uniform
+  const int h = lane >> 5, l31 = lane & 31;
+
+  const int HW = p.H > 0 ? p.H * p.W : p.M;   // rows per image
+  const int TPI = (HW + BM - 1) / BM;
+  const int B = p.M / HW;
+  const int gx = B * TPI, gy = (p.N + BN - 1) / BN;
+  int L = p.xcd_remap ? xcd_remap_h(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int per_z = gx * gy;
+  const int bz = L / per_z;
+  L -= bz * per_z;
+  const int grp = L / (GM * gy);
+  const int first_m = grp * GM;
+  const int gsz = gx - first_m < GM ? gx - first_m : GM;
+  const int lin = L - grp * GM * gy;
+  const int bx = first_m + lin % gsz, by = lin / gsz;
+  const int img = bx / TPI, v0 = (bx - img * TPI) * BM;
+  const int n0 = by * BN;
+
+  const int nslab = p.Kc / BK;
+  int s0 = 0, s1 = nslab;
+  if (p.splitk > 1) {
+    const int per = (nslab + p.splitk - 1) / p.splitk;
+    s0 = bz * per;
+    s1 = s0 + per < nslab ? s0 + per : nslab;
+  }
+
+  f32x16_t acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  if (s0 < s1) {
+    if (producer) {
+      const int lw = wave - 4;
+      const T* __restrict__ A = reinterpret_cast<const T*>(p.A0) + (int64_t)img * HW * p.lda0;
+      const T* __restrict__ Wp = reinterpret_cast<const T*>(p.Wp);
+      int aoff[A_SLOTS], boff[B_SLOTS];
+#pragma unroll
+      for (int i = 0; i < A_SLOTS; ++i) {
+        const int row = 8 * (lw + NWL * i) + (lane >> 3);
+        int v = v0 + row;
+        if (v > HW - 1) v = HW - 1;                 // rows past the image re-read its last pixel; they are never stored
+        aoff[i] = v * (int)p.lda0 + ((lane & 7) ^ ((row >> 1) & 7)) * EPC;
+      }
+#pragma unroll
+      for (int i = 0; i < B_SLOTS; ++i) {
+        const int row = 8 * (lw + NWL * i) + (lane >> 3);
+        int n = n0 + row;
+        if (n > p.Npad - 1) n = p.Npad - 1;
+        boff[i] = n * p.Kc + ((lane & 7) ^ ((row >> 1) & 7)) * EPC;
+      }
+      const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
+#define K22_ISSUE_GS(SLAB, STAGE)                                                                          \
+      {                                                                                                    \
+        int sl_ = (SLAB);                                                                                  \
+        if (sl_ > s1 - 1) sl_ = s1 - 1;   /* past-the-end stages re-read the last slab: uniform counting */ \
+        const unsigned d_ = lds0 + (STAGE) * BUF + lw * 1024;                                              \
+        _Pragma("unroll") for (int i = 0; i < A_SLOTS; ++i)                                                \
+            glds16_asm(A + aoff[i] + sl_ * BK, __builtin_amdgcn_readfirstlane(d_ + i * NWL * 1024));       \
+        _Pragma("unroll") for (int i = 0; i < B_SLOTS; ++i)                                                \
+            glds16w_asm(Wp + boff[i] + sl_ * BK, __builtin_amdgcn_readfirstlane(d_ + A_BYTES + i * NWL * 1024)); \
+      }
+#pragma unroll
+      for (int t = 0; t < NST - 1; ++t) K22_ISSUE_GS(s0 + t, t);
+      int fill = NST - 1;
+      for (int s = s0; s < s1; ++s) {
+        wait_vmcnt<(NST - 2) * CH>();
+        raw_barrier();
+        K22_ISSUE_GS(s + NST - 1, fill);
+        fill = (fill + 1 == NST) ? 0 : fill + 1;
+      }
+#undef K22_ISSUE_GS
+    } else {
+      const int wm = wave >> 1, wn = wave & 1;
+      int arow[MI], brow[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) arow[mi] = (wm * (BM / WM) + mi * 32 + l31) * 128;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) brow[ni] = A_BYTES + (wn * (BN / WN) + ni * 32 + l31) * 128;
+      const int sw = (l31 >> 1) & 7;
+      Frag<T> pa[MI], pb[NI];          // fragments read but not yet multiplied (zero = a no-op group before the first slab)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) pa[mi] = Frag<T>{};
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) pb[ni] = Frag<T>{};
+      constexpr int NRD = MI + NI, NMF = MI * NI, MPR = NMF / NRD;
+#define K22_GS_INTERLEAVE()                                                                                \
+      {                                                                                                    \
+        _Pragma("unroll") for (int i_ = 0; i_ < NRD; ++i_) {                                               \
+          __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);                                             \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                               \
+        }                                                                                                  \
+        if constexpr (NMF - MPR * NRD > 0) __builtin_amdgcn_sched_group_barrier(0x008, NMF - MPR * NRD, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+      }
+      int cur = 0;
+      for (int s = s0; s < s1; ++s) {
+        raw_barrier();
+        const char* St = smem + cur * BUF;
+        Frag<T> ca[MI], cb[NI];
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ks += 2) {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) ld_frag_at(ca[mi], St + arow[mi], sw, ks, h);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) ld_frag_at(cb[ni], St + brow[ni], sw, ks, h);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], pb[ni], pa[mi]);
+          K22_GS_INTERLEAVE();
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) ld_frag_at(pa[mi], St + arow[mi], sw, ks + 1, h);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) ld_frag_at(pb[ni], St + brow[ni], sw, ks + 1, h);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], cb[ni], ca[mi]);
+          K22_GS_INTERLEAVE();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // no fragment read of this stage in flight when the producers refill it after the next barrier
+        cur = (cur + 1 == NST) ? 0 : cur + 1;
+      }
+#undef K22_GS_INTERLEAVE
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) mma_atom(acc[mi][ni], pb[ni], pa[mi]);
+    }
+  }
+  halo_tail<T, BM, true, true>(p, acc, smem, bx, bz, img, v0, n0);
+}
+
+// ================================================================================================================
 // conv3_halo3_kernel: the same LDS-resident halo scheme on 64-BYTE rows.  The K loop walks HALF slabs (32 bf16 / 16 fp32
 // channels); one iteration = the three taps of one filter row (ky) of one half slab = 24 MFMAs per wave between
 // barriers (16 before), its weight tiles (3 x 128 rows x 64 B = 24 KB) sit in an RB-deep ring (RB-1 iterations in
@@ -652,9 +816,33 @@ static int launch_gemm8_cfg(const IgemmParams& p, int splitk, hipStream_t stream
   return K22_OK;
 }
 
+template <typename T, int BM, int NST>
+static int launch_gemm8_spec_cfg(const IgemmParams& p, int splitk, hipStream_t stream) {
+  const size_t smem = gemm8_smem_bytes(BM, NST);
+  static LdsAttrGuard attr_guard;
+  if (int rc_ = k22_ensure_lds_attr(attr_guard, reinterpret_cast<const void*>(&gemm8_spec_kernel<T, BM, NST>), 160 * 1024, __FILE__, __LINE__)) return rc_;
+  IgemmParams q = p;
+  q.splitk = splitk;
+  const int hw = p.H > 0 ? p.H * p.W : p.M;
+  const int nblocks = (p.M / hw) * gemm8_tiles_per_image(p, BM) * ((p.N + HALO_BN - 1) / HALO_BN) * splitk;
+  hipLaunchKernelGGL((gemm8_spec_kernel<T, BM, NST>), dim3(nblocks), dim3(512), smem, stream, q);
+  K22_CHECK_LAUNCH();
+  return K22_OK;
+}
+
+// p.stages == 3 selects the specialised, pipelined form (16-bit types; the split types keep the lock-step kernel)
+bool gemm8_spec_supported(int dtype) { return dtype == K22_BF16 || dtype == K22_F16; }
+
 // Launches gemm8_kernel only (a split-K reduction, if any, is the caller's: launch_igemm).
 int launch_gemm8(const IgemmParams& p, int dtype, int bm, int splitk, hipStream_t stream) {
   if (!gemm8_supported(p, dtype, bm)) return k22_set_error(K22_EINVAL, "gemm8: unsupported problem");
+  if ((p.stages == 3 || p.stages == 4) && gemm8_spec_supported(dtype)) {
+    // 4 (BM = 128 only): 2-deep ring = 68 KB with the epilogue tile, so that TWO workgroups share a CU and one's prologue / epilogue (a burst of
+    // output traffic that every CU of a lock-step round issues at the same time) overlaps the other's K loop - the p.stages == 2 idea of gemm8_kernel
+    if (p.stages == 4 && bm == 128) return dtype == K22_BF16 ? launch_gemm8_spec_cfg<bf16_t, 128, 2>(p, splitk, stream) : launch_gemm8_spec_cfg<f16_t, 128, 2>(p, splitk, stream);
+    if (dtype == K22_BF16) return bm == 256 ? launch_gemm8_spec_cfg<bf16_t, 256, 3>(p, splitk, stream) : launch_gemm8_spec_cfg<bf16_t, 128, 4>(p, splitk, stream);
+    return bm == 256 ? launch_gemm8_spec_cfg<f16_t, 256, 3>(p, splitk, stream) : launch_gemm8_spec_cfg<f16_t, 128, 4>(p, splitk, stream);
+  }
   const int nst = gemm8_nst(bm, p.stages);
   if (dtype == K22_BF16) {
     if (bm == 256) return launch_gemm8_cfg<bf16_t, 256, 3>(p, splitk, stream);

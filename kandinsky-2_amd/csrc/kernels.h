@@ -104,6 +104,7 @@ int launch_conv3_halo(const IgemmParams& p, int dtype, int bm, int splitk, hipSt
 int launch_conv3_halo_trace(const IgemmParams& p, int dtype, hipStream_t stream);
 // 8-wave BM x 128 GEMM on the halo kernels' frame (conv3_halo.hip: gemm8_kernel); p.algo == 10 selects it in launch_igemm
 bool gemm8_supported(const IgemmParams& p, int dtype, int bm);
+bool gemm8_spec_supported(int dtype);   // p.stages == 3: gemm8_spec_kernel (producer / consumer waves, explicit fragment pipeline)
 int gemm8_tiles_per_image(const IgemmParams& p, int bm);
 int launch_gemm8(const IgemmParams& p, int dtype, int bm, int splitk, hipStream_t stream);
 // stream_gemm.hip: weight-streaming kernel for small M (p.algo == 20; bm = 160 / 288 selects 5 / 9 m-blocks per workgroup).

@@ -140,8 +140,9 @@ inline void tuned_make_candidates(Tuned& t, int dtype) {
       const int nb = (p.M / hw) * gemm8_tiles_per_image(p, bm) * ((p.N + 127) / 128);
       for (int sk : {1, 2, 3, 4, 6}) {
         if (sk > 1 && (nkt / sk < 4 || nb * sk > 800 || nb >= 256 || p.out_mode == IG_OUT_QKV)) continue;
-        for (int stg : {0, 2}) {   // 2: two co-resident workgroups per CU with a 2-deep ring (BM = 128 only)
-          if (stg == 2 && bm != 128) continue;
+        for (int stg : {0, 2, 3, 4}) {   // 2: two co-resident workgroups per CU with a 2-deep ring (BM = 128 only); 3 / 4: gemm8_spec_kernel (16-bit types), 4 = its two-per-CU form
+          if ((stg == 2 || stg == 4) && bm != 128) continue;
+          if (stg >= 3 && !gemm8_spec_supported(dtype)) continue;
           Cfg c; c.algo = 10; c.bm = bm; c.bn = 0; c.splitk = sk; c.stages = stg;
           all.push_back(c);
         }

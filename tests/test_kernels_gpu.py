@@ -309,7 +309,7 @@ def _with_gemm8(fn):
     (256, 256, 128, 256, 1), (300, 192, 192, 128, 1), (77, 768, 1024, 128, 1), (1000, 136, 384, 256, 1),
     (288, 384, 1152, 128, 4), (512, 128, 64, 0, 1), (4608, 768, 768, 256, 2), (150, 1536, 1536, 256, 3),
 ])
-@pytest.mark.parametrize("stages", [-1, 2])
+@pytest.mark.parametrize("stages", [-1, 2, 3, 4])   # 3 / 4: gemm8_spec_kernel (16-bit types; the others keep the lock-step kernel)
 def test_gemm8(dtype, M, N, K, bm, splitk, stages):
     A, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
     bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
@@ -319,6 +319,62 @@ def test_gemm8(dtype, M, N, K, bm, splitk, stages):
     finally:
         _lib.check(_lib.lib().k22_set_option(b"igemm_stages", -1))
     close(out, a @ w.T + bias + r, dtype, f"gemm8 {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("dtype", [_lib.K22_BF16, _lib.K22_F16])
+@pytest.mark.parametrize("M,N,K,bm,splitk", [(4608, 768, 768, 128, 1), (4608, 2304, 768, 256, 1), (1000, 136, 384, 256, 1), (288, 1536, 1536, 128, 3),
+                                             (32768, 768, 768, 256, 1), (150, 1536, 1536, 256, 3)])
+def test_gemm8_spec_kernel_gives_the_lock_step_kernels_bits(dtype, M, N, K, bm, splitk):
+    """gemm8_spec_kernel (producer / consumer waves, explicit fragment pipeline; "igemm_stages" = 3) feeds every accumulator the same MFMAs in
+    the same k order as gemm8_kernel: equal bits, plain epilogue, GroupNorm partial sums and the qkv-projection layout alike."""
+    A, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    outs = []
+    for stages in (-1, 3, 4):
+        _lib.check(_lib.lib().k22_set_option(b"igemm_stages", stages))
+        try:
+            outs.append(_with_gemm8(lambda: hp.gemm(A, W, bias, res, dtype=dtype, splitk=splitk, bm=bm, bn=0))[0])
+        finally:
+            _lib.check(_lib.lib().k22_set_option(b"igemm_stages", -1))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("dtype", [_lib.K22_BF16, _lib.K22_F16])
+def test_gemm8_spec_kernel_qkv_and_statistics_epilogues(dtype):
+    import ctypes as C
+    T_ = hp.tdt(dtype)
+    res = []
+    for stages in (-1, 3, 4):
+        _lib.check(_lib.lib().k22_set_option(b"igemm_stages", stages))
+        try:
+            B, H, T, S, K, bm = 2, 12, 2304, 87, 768, (128 if stages == 4 else 256)
+            Cc, Tkp = 64 * H, (S + T + 63) // 64 * 64
+            x, W, bias = rnd(B * T, K, seed=1), rnd(3 * Cc, K, seed=2, scale=K ** -0.5), rnd(3 * Cc, seed=3)
+            xt, wt = x.to(T_).contiguous(), W.to(T_).contiguous()
+            q = torch.empty(B * T, Cc, dtype=T_, device="cuda")
+            kall = torch.full((B, H, Tkp, 64), 7.0, dtype=T_, device="cuda")
+            vtall = torch.full((B, H, 64, Tkp), 7.0, dtype=T_, device="cuda")
+            _with_gemm8(lambda: _lib.check(_lib.lib().k22_qkv_project(xt.data_ptr(), wt.data_ptr(), bias.data_ptr(), q.data_ptr(), kall.data_ptr(),
+                                                                      vtall.data_ptr(), B, H, T, S, K, bm, 0, dtype, hp.stream())))
+            B2, H2, W2, N, K2 = 2, 48, 48, 768, 768
+            M = B2 * H2 * W2
+            A, Wg, bg, rg = rnd(M, K2, seed=5), rnd(N, K2, seed=6, scale=K2 ** -0.5), rnd(N, seed=7), rnd(M, N, seed=8)
+            a, w, r = A.to(T_).contiguous(), hp.pad_rows(Wg.to(T_)), rg.to(T_).contiguous()
+            out = torch.empty(M, N, dtype=T_, device="cuda")
+            partial = torch.empty(M * N + 64, dtype=torch.float32, device="cuda")
+            cap = B2 * (H2 * W2 // 16 + 2)
+            sbuf = torch.zeros((cap, N, 2), dtype=torch.float32, device="cuda")
+            rpi = C.c_int(0)
+            _lib.check(_lib.lib().k22_gemm_gnstats(a.data_ptr(), w.data_ptr(), bg.data_ptr(), r.data_ptr(), out.data_ptr(), partial.data_ptr(),
+                                                   B2, H2, W2, N, w.shape[0], K2, 1, 256, sbuf.data_ptr(), cap, C.byref(rpi), dtype, hp.stream()))
+            res.append((q.clone(), kall.clone(), vtall.clone(), out.clone(), sbuf[: B2 * rpi.value].clone()))
+        finally:
+            _lib.check(_lib.lib().k22_set_option(b"igemm_stages", -1))
+    for x0, x1 in zip(res[0][:3], res[1][:3]):
+        assert torch.equal(x0, x1)
+    for x0, x2 in zip(res[0][:3], res[2][:3]):   # (the BM = 128 form has its own partial-sum row count: only the projections are compared)
+        assert torch.equal(x0, x2)
+    assert torch.equal(res[0][3], res[1][3]) and torch.equal(res[0][4], res[1][4])
 
 
 def test_gemm8_asymmetric_layout():
