@@ -61,6 +61,6 @@ for (M, N, K, name) in SHAPES:
             one = run(M, N, 64, algo, bm, bn, 1, True, False, stages=stg)
             noepi = run(M, N, K, algo, bm, bn, 1, False, False, stages=stg)
             cold = run(M, N, K, algo, bm, bn, 1, True, True, stages=stg)
-            print(f"  {label:14s} warm {full:6.1f} us ({gf / full / 1e3 * 1e3:7.1f} TFLOP/s) | K=64 {one:6.1f} | no bias/residual {noepi:6.1f} | cold {cold:6.1f}")
+            print(f"  {label:14s} warm {full:6.1f} us ({gf / full / 1e3:5.2f} PFLOP/s) | K=64 {one:6.1f} | no bias/residual {noepi:6.1f} | cold {cold:6.1f}")
         except Exception as e:
             print(f"  {label:14s} failed: {str(e)[:80]}")
