@@ -258,6 +258,37 @@ def test_plms_sampler_final_latent_vs_reference_golden_fp32(golden_dir, name):
     assert err <= 1e-3 * max(1.0, scale)
 
 
+# of the reference latent's scale (116 / 130 at C2: the un-clamped latent of a random-weight UNet).  Measured: f16x3 1.7e-6 / 1.2e-6 (DDIM / PLMS),
+# f16x2 1.2e-4 / 9.2e-5 - the bounds are the 1e-3 gate class for f16x3 (x 1e-2: two decimal places inside it) and 2x measured for f16x2
+_SPLIT_SAMPLER_BOUNDS = {("ddim", "f16x3"): 1e-5, ("ddim", "f16x2"): 2.5e-4, ("plms", "f16x3"): 1e-5, ("plms", "f16x2"): 2e-4}
+
+
+@pytest.mark.parametrize("which", ["ddim", "plms"])
+@pytest.mark.parametrize("backend", ["f16x3", "f16x2"])
+def test_ddim_plms_at_c2_on_the_split_engines(golden_dir, which, backend):
+    """SURVEY 8f-1 on the gate-carrying engines (round 6): the reference DDIMSampler / PLMSSampler goldens of the 1.23 B UNet at the C2 shape,
+    20 steps (c2_ddim.pt / c2_plms.pt), run through the f16x3 and f16x2 engines."""
+    fx = _load(golden_dir, "c2_" + which)
+    arch = k22.make_arch(fx["model_config"])
+    sd = _state_dict(fx)
+    m = k22.Text2ImUNetHIP(arch, backend_dtype=backend, use_graph=True)
+    m.load_state_dict(sd)
+    m = m.to("cuda").eval()
+    full, pooled, image = k22.make_conditioning(arch, fx["B"], seed=2)
+    kw = dict(full_emb=full.cuda(), pooled_emb=pooled.cuda(), image_emb=image.cuda())
+    g = torch.Generator().manual_seed(42 if which == "ddim" else 43)
+    x_T = torch.randn(fx["B"], 4, fx["h"], fx["w"], generator=g)
+    old = k22.create_gaussian_diffusion(**k22.DIFFUSION_CONFIG_2_1)
+    sampler = (k22.DDIMSamplerHIP if which == "ddim" else k22.PLMSSamplerHIP)(m, old, fx["guidance"])
+    out, _ = sampler.sample(fx["steps"], fx["B"], (4, fx["h"], fx["w"]), conditioning=kw, x_T=x_T.cuda())
+    ref = fx["final"]
+    scale = ref.abs().max().item()
+    d = (out.cpu() - ref)
+    err, rms = d.abs().max().item(), d.pow(2).mean().sqrt().item()
+    print(f"{which} {fx['steps']} steps {backend}: max|d|={err:.3e} rms={rms:.3e} scale={scale:.2f} -> {err / scale:.3e} of scale")
+    assert err <= _SPLIT_SAMPLER_BOUNDS[(which, backend)] * max(1.0, scale)
+
+
 def test_plms_step_kernel_matches_the_oracle_arithmetic():
     """k22_plms_step alone against the oracle's tensor expressions, every order: the guided eps bit-exact (same roundings, no
     fma), the DDIM update to a few ulp (device sqrt / divide against the host's)."""
