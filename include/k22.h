@@ -65,7 +65,8 @@ const char* k22_last_error(void);
  * instruction class behind the one wrong-result kernel pair rounds 4-5 found under concurrency (0 of 900 victim launches wrong with every
  * offender, against 148-227 of 900 in a packed build on the same box: profiles/r06_two_stream_probe.txt).  k22_build_flags() lets a
  * host assert it: a library built with NOPK=0 reports K22_BUILD_PACKED_FP32 and must be driven one stream at a time.
- * Knobs: "igemm_stages" = 2..4 LDS-DMA pipeline depth (-1 default);
+ * Knobs: "igemm_stages" = 2..4 LDS-DMA pipeline depth (-1 default; with "gemm_algo" = 10: 2 = two workgroups per CU at BM = 128, 3 / 4 = the
+ * specialised, pipelined gemm8_spec_kernel for the 16-bit types and its two-per-CU form - same bits as the lock-step kernel);
  * "igemm_xcd_remap" = 0/1 XCD-aware workgroup renumbering; "conv_algo" = 0 auto, 1 generic implicit GEMM,
  * 2 LDS-resident halo kernel for the 3x3 convolutions (3-7: its variants, see conv3_halo.hip; 8-9: measurement only);
  * "gemm_algo" = 0 generic implicit-GEMM kernel, 10 = 8-wave BM x 128 tile kernel where it applies;
